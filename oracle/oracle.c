@@ -1,0 +1,436 @@
+/*
+ * oracle.c -- CPU restatement of the gsplat.js per-frame hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (gsplat.js_amd/,
+ * include/) may link, load or call this file.  Only tests/, bench.py's
+ * `cpu_baseline` leg and __graft_entry__.smoke() use it, as the checker.
+ *
+ * Parity status
+ *   sort path   (orc_sort)        PINNED: checked bit-for-bit against the
+ *                                 reference's own wasm/wasm.cpp compiled from
+ *                                 source (oracle/_ref, tests/test_oracle_ref.py)
+ *                                 and against tests/golden/ fixtures generated
+ *                                 from it (tests/golden/make_golden.py).
+ *   scene pack  (orc_scene_pack)  pinned by fixtures produced by running the
+ *                                 reference's floatToHalf text under Node
+ *                                 (tests/golden/make_golden_half.js).
+ *   render path (orc_project, orc_render)
+ *                                 PARITY UNPINNED: the reference renders with
+ *                                 GLSL on a WebGL2 context, which cannot run in
+ *                                 this container (no GL, no GPU) and its repo
+ *                                 holds no test images.  These functions restate
+ *                                 vertex.glsl.ts / frag.glsl.ts / the GL blend
+ *                                 state line by line; known-answer tests in
+ *                                 tests/test_oracle_render.py check closed forms.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fPIC -shared (see oracle/Makefile).
+ * -ffp-contract=off is REQUIRED: FMA contraction changes the sort result
+ * (SURVEY.md section 8(c)).
+ *
+ * All citations are relative to /root/reference.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_DEPTH_RANGE 65536u /* wasm/wasm.cpp:33  (256*256) */
+
+/* ------------------------------------------------------------------------
+ * A1-A4: depth key, min/max, 16-bit quantise, stable counting sort.
+ * Follows wasm/wasm.cpp:8-52 statement by statement.
+ *
+ * Defined semantics for the reference's max-bucket overflow:
+ * the key domain is [0, 65536] (17 bits); splats whose key is 65536 go LAST,
+ * in ascending original index.  The unmodified reference produces exactly
+ * this when starts[65536] is preset to N - #{q==65536} (oracle/ref_driver.c
+ * does that); here the counting arrays simply have 65537 entries.
+ * Degenerate maxDepth==minDepth (reference: 0*inf = NaN, undefined cast):
+ * every key is 0, identity permutation.
+ *
+ * keys_out (nullable): the 17-bit key of every splat.
+ * minmax   (nullable): {minDepth, maxDepth}.
+ * ---------------------------------------------------------------------- */
+int orc_sort(const float *vp, uint32_t n, const float *pos,
+             uint32_t *depth_index, uint32_t *keys_out, int32_t *minmax)
+{
+    uint32_t *depth = (uint32_t *)malloc((size_t)(n ? n : 1) * 4);
+    uint32_t *counts = (uint32_t *)calloc(ORC_DEPTH_RANGE + 1, 4);
+    uint32_t *starts = (uint32_t *)malloc((ORC_DEPTH_RANGE + 1) * 4);
+    if (!depth || !counts || !starts) { free(depth); free(counts); free(starts); return -1; }
+
+    /* wasm.cpp:14-31 */
+    int32_t minDepth = 0x7fffffff;
+    int32_t maxDepth = (int32_t)0x80000000;
+    for (uint32_t i = 0; i < n; i++) {
+        float f0 = vp[2] * pos[3 * i + 0];
+        float f1 = vp[6] * pos[3 * i + 1];
+        float f2 = vp[10] * pos[3 * i + 2];
+        int32_t d = (int32_t)((f0 + f1 + f2) * 4096);
+        depth[i] = (uint32_t)d;
+        if (d > maxDepth) maxDepth = d;
+        if (d < minDepth) minDepth = d;
+    }
+    if (minmax) { minmax[0] = minDepth; minmax[1] = maxDepth; }
+
+    /* wasm.cpp:33-40 */
+    if (n && maxDepth != minDepth) {
+        const float depthInv = (float)ORC_DEPTH_RANGE / (maxDepth - minDepth);
+        for (uint32_t i = 0; i < n; i++) {
+            depth[i] = (uint32_t)((depth[i] - (uint32_t)minDepth) * depthInv);
+            if (depth[i] > ORC_DEPTH_RANGE) depth[i] = ORC_DEPTH_RANGE; /* never taken for in-range data */
+            counts[depth[i]]++;
+        }
+    } else {
+        for (uint32_t i = 0; i < n; i++) depth[i] = 0;
+        counts[0] = n;
+    }
+
+    /* wasm.cpp:42-46, extended by the one extra bucket */
+    starts[0] = 0;
+    for (uint32_t i = 1; i <= ORC_DEPTH_RANGE; i++) starts[i] = starts[i - 1] + counts[i - 1];
+
+    /* wasm.cpp:48-51 */
+    for (uint32_t i = 0; i < n; i++) depth_index[starts[depth[i]]++] = i;
+
+    if (keys_out) memcpy(keys_out, depth, (size_t)n * 4);
+    free(depth); free(counts); free(starts);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------
+ * D2: Scene.setData -- .splat rows -> scene.data (8 u32 per splat) + positions.
+ * Follows src/core/Scene.ts:126-177 in f64 (JS number) arithmetic, with
+ * src/math/Matrix3.ts:33-47,63-80 and src/utils.ts:16-48.
+ * ---------------------------------------------------------------------- */
+
+/* src/utils.ts:16-43 floatToHalf: truncating, with JS's ">>" taking the shift
+ * count modulo 32 for f32 exponents below 81. */
+uint32_t orc_float_to_half(double value)
+{
+    float fv = (float)value; /* _floatView[0] = float (RNE to f32) */
+    int32_t f;
+    memcpy(&f, &fv, 4);
+    int32_t sign = (f >> 31) & 0x0001;
+    int32_t exp = (f >> 23) & 0x00ff;
+    int32_t frac = f & 0x007fffff;
+    int32_t newExp;
+    if (exp == 0) {
+        newExp = 0;
+    } else if (exp < 113) {
+        newExp = 0;
+        frac |= 0x00800000;
+        frac = frac >> ((113 - exp) & 31);
+        if (frac & 0x01000000) { newExp = 1; frac = 0; }
+    } else if (exp < 142) {
+        newExp = exp - 112;
+    } else {
+        newExp = 31;
+        frac = 0;
+    }
+    return (uint32_t)((sign << 15) | (newExp << 10) | (frac >> 13));
+}
+
+/* src/utils.ts:46-48 */
+uint32_t orc_pack_half2x16(double x, double y)
+{
+    return (orc_float_to_half(x) | (orc_float_to_half(y) << 16));
+}
+
+void orc_scene_pack(const uint8_t *rows, uint32_t n, uint32_t *data, float *positions)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        const uint8_t *row = rows + (size_t)32 * i;
+        float f[6];
+        memcpy(f, row, 24);
+        uint32_t *d = data + (size_t)8 * i;
+        /* Scene.ts:128-143 */
+        positions[3 * i + 0] = f[0]; positions[3 * i + 1] = f[1]; positions[3 * i + 2] = f[2];
+        memcpy(&d[0], &f[0], 4); memcpy(&d[1], &f[1], 4); memcpy(&d[2], &f[2], 4);
+        d[3] = 0;
+        /* Scene.ts:145-148 */
+        d[7] = (uint32_t)row[24] | ((uint32_t)row[25] << 8) | ((uint32_t)row[26] << 16) | ((uint32_t)row[27] << 24);
+        /* Scene.ts:132-135 (stored in a Float32Array: exact) */
+        double r0 = ((double)row[28] - 128) / 128, r1 = ((double)row[29] - 128) / 128;
+        double r2 = ((double)row[30] - 128) / 128, r3 = ((double)row[31] - 128) / 128;
+        /* Scene.ts:150-157: Quaternion(x=r1, y=r2, z=r3, w=-r0); Matrix3.ts:67-80 */
+        double qx = r1, qy = r2, qz = r3, qw = -r0;
+        double R[9] = {
+            1 - 2 * qy * qy - 2 * qz * qz, 2 * qx * qy - 2 * qz * qw, 2 * qx * qz + 2 * qy * qw,
+            2 * qx * qy + 2 * qz * qw, 1 - 2 * qx * qx - 2 * qz * qz, 2 * qy * qz - 2 * qx * qw,
+            2 * qx * qz - 2 * qy * qw, 2 * qy * qz + 2 * qx * qw, 1 - 2 * qx * qx - 2 * qy * qy,
+        };
+        /* Scene.ts:159-163: Diagonal(scale).multiply(rot); Matrix3.ts:33-47 with a = diag, b = R */
+        double a[9] = { (double)f[3], 0, 0, 0, (double)f[4], 0, 0, 0, (double)f[5] };
+        const double *b = R;
+        double M[9] = {
+            b[0] * a[0] + b[3] * a[1] + b[6] * a[2], b[1] * a[0] + b[4] * a[1] + b[7] * a[2], b[2] * a[0] + b[5] * a[1] + b[8] * a[2],
+            b[0] * a[3] + b[3] * a[4] + b[6] * a[5], b[1] * a[3] + b[4] * a[4] + b[7] * a[5], b[2] * a[3] + b[5] * a[4] + b[8] * a[5],
+            b[0] * a[6] + b[3] * a[7] + b[6] * a[8], b[1] * a[6] + b[4] * a[7] + b[7] * a[8], b[2] * a[6] + b[5] * a[7] + b[8] * a[8],
+        };
+        /* Scene.ts:165-172 */
+        double s0 = M[0] * M[0] + M[3] * M[3] + M[6] * M[6];
+        double s1 = M[0] * M[1] + M[3] * M[4] + M[6] * M[7];
+        double s2 = M[0] * M[2] + M[3] * M[5] + M[6] * M[8];
+        double s3 = M[1] * M[1] + M[4] * M[4] + M[7] * M[7];
+        double s4 = M[1] * M[2] + M[4] * M[5] + M[7] * M[8];
+        double s5 = M[2] * M[2] + M[5] * M[5] + M[8] * M[8];
+        /* Scene.ts:174-176 */
+        d[4] = orc_pack_half2x16(4 * s0, 4 * s1);
+        d[5] = orc_pack_half2x16(4 * s2, 4 * s3);
+        d[6] = orc_pack_half2x16(4 * s4, 4 * s5);
+    }
+}
+
+/* ------------------------------------------------------------------------
+ * B1-B6: per-splat vertex stage, src/renderers/webgl/shaders/vertex.glsl.ts:130-231
+ * (non-SH colour branch :207, scalingFactor = 1), in f32.  GLSL leaves the
+ * evaluation order of matrix products open; this restatement fixes it as
+ * left-to-right sums of products with no fused multiply-add, division and
+ * square root correctly rounded, normalize(v) = v / sqrt(dot(v,v)).  The HIP
+ * kernel uses the identical sequence, so every field below is compared
+ * bit-for-bit.
+ *
+ * Outputs per splat
+ *   raw[12]  the shader's own varyings, GL conventions (window y up):
+ *            0,1 centre in window px  2,3 majorAxis  4,5 minorAxis (px, y up)
+ *            6 opacity  7,8,9 rgb  10 pos2d.w  11 visible flag (1/0)
+ *   rec[8]   the 32-byte record the tile blender consumes, IMAGE conventions
+ *            (row 0 = top): cx, cy, ux, uy, wx, wy, log2(opacity), rgb8
+ *            where u = 2*major/|major|^2, w = 2*minor/|minor|^2 (y flipped),
+ *            so that vPosition at pixel p is (dot(p-c,u), dot(p-c,w)).
+ *   bbox[4]  x0,y0,x1,y1 inclusive pixel bounds (clamped to the image) of the
+ *            |vPosition| <= 2 ellipse's bounding box; x0 > x1 when invisible.
+ * ---------------------------------------------------------------------- */
+
+static float half_to_float(uint32_t h)
+{
+    uint32_t s = (h >> 15) & 1, e = (h >> 10) & 0x1f, m = h & 0x3ff;
+    float v;
+    if (e == 0) v = ldexpf((float)m, -24);
+    else if (e == 31) v = m ? NAN : INFINITY;
+    else v = ldexpf((float)(m | 0x400), (int)e - 25);
+    return s ? -v : v;
+}
+
+/* r = a*b for 3x3 matrices held column-major (GLSL): m[c*3+r] */
+static void mat3_mul(const float *a, const float *b, float *r)
+{
+    for (int c = 0; c < 3; c++)
+        for (int ro = 0; ro < 3; ro++) {
+            float s = a[0 * 3 + ro] * b[c * 3 + 0];
+            s = s + a[1 * 3 + ro] * b[c * 3 + 1];
+            s = s + a[2 * 3 + ro] * b[c * 3 + 2];
+            r[c * 3 + ro] = s;
+        }
+}
+
+static void mat3_transpose(const float *a, float *r)
+{
+    for (int c = 0; c < 3; c++)
+        for (int ro = 0; ro < 3; ro++) r[c * 3 + ro] = a[ro * 3 + c];
+}
+
+#define ORC_INVISIBLE(bb) do { (bb)[0] = 1; (bb)[1] = 1; (bb)[2] = 0; (bb)[3] = 0; } while (0)
+
+void orc_project(const uint32_t *data, uint32_t n, const float *view, const float *proj,
+                 float fx, float fy, int W, int H,
+                 float *rec_out /*8n, nullable*/, int32_t *bbox_out /*4n, nullable*/, float *raw_out /*12n, nullable*/)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t *d = data + (size_t)8 * i;
+        float raw[12];
+        float rec[8];
+        int32_t bb[4];
+        uint32_t recu7 = 0;
+        memset(raw, 0, sizeof raw);
+        memset(rec, 0, sizeof rec);
+        ORC_INVISIBLE(bb);
+        do {
+            /* :133-136 */
+            float p[3];
+            memcpy(p, d, 12);
+            float cam[4], pos2d[4];
+            for (int r = 0; r < 4; r++) {
+                float s = view[0 * 4 + r] * p[0];
+                s = s + view[1 * 4 + r] * p[1];
+                s = s + view[2 * 4 + r] * p[2];
+                s = s + view[3 * 4 + r];
+                cam[r] = s;
+            }
+            for (int r = 0; r < 4; r++) {
+                float s = proj[0 * 4 + r] * cam[0];
+                s = s + proj[1 * 4 + r] * cam[1];
+                s = s + proj[2 * 4 + r] * cam[2];
+                s = s + proj[3 * 4 + r] * cam[3];
+                pos2d[r] = s;
+            }
+            raw[10] = pos2d[3];
+            /* :138-142 */
+            float clip = 1.2f * pos2d[3];
+            if (pos2d[2] < -pos2d[3] || pos2d[0] < -clip || pos2d[0] > clip || pos2d[1] < -clip || pos2d[1] > clip) break;
+            /* :144-146 */
+            float u1x = half_to_float(d[4] & 0xffff), u1y = half_to_float(d[4] >> 16);
+            float u2x = half_to_float(d[5] & 0xffff), u2y = half_to_float(d[5] >> 16);
+            float u3x = half_to_float(d[6] & 0xffff), u3y = half_to_float(d[6] >> 16);
+            float Vrk[9] = { u1x, u1y, u2x, u1y, u2y, u3x, u2x, u3x, u3y };
+            /* :148-152 */
+            float zz = cam[2] * cam[2];
+            float J[9] = {
+                fx / cam[2], 0.f, -(fx * cam[0]) / zz,
+                0.f, -fy / cam[2], (fy * cam[1]) / zz,
+                0.f, 0.f, 0.f,
+            };
+            /* :154-155 */
+            float V3[9] = { view[0], view[1], view[2], view[4], view[5], view[6], view[8], view[9], view[10] };
+            float V3t[9], T[9], Tt[9], TtV[9], cov2d[9];
+            mat3_transpose(V3, V3t);
+            mat3_mul(V3t, J, T);
+            mat3_transpose(T, Tt);
+            mat3_mul(Tt, Vrk, TtV);
+            mat3_mul(TtV, T, cov2d);
+            /* :158-159 */
+            float a = cov2d[0] + 0.3f;       /* [0][0] */
+            float b = cov2d[1];              /* [0][1] */
+            float c = cov2d[4] + 0.3f;       /* [1][1] */
+            /* :161-163 */
+            float det = a * c - b * b;
+            if (det == 0.0f) break;
+            /* :166-171 */
+            float mid = (a + c) / 2.0f;
+            float rad = mid * mid - det;
+            float sq = sqrtf((0.1f < rad) ? rad : 0.1f); /* GLSL max(0.1, x) */
+            float lambda1 = mid + sq;
+            float lambda2 = mid - sq;
+            if (lambda2 < 0.0f) break;
+            /* :173-175 */
+            float dvx = b, dvy = lambda1 - a;
+            float len = sqrtf(dvx * dvx + dvy * dvy);
+            float dgx = dvx / len, dgy = dvy / len;
+            float smaj = sqrtf(2.0f * lambda1), smin = sqrtf(2.0f * lambda2);
+            smaj = (1024.0f < smaj) ? 1024.0f : smaj; /* GLSL min(x, 1024) */
+            smin = (1024.0f < smin) ? 1024.0f : smin;
+            float majx = smaj * dgx, majy = smaj * dgy;
+            float minx = smin * dgy, miny = smin * -dgx;
+            if (!(isfinite(majx) && isfinite(majy) && isfinite(minx) && isfinite(miny))) break; /* normalize(0,0): dropped */
+            /* :177-178, :207 */
+            uint32_t cw = d[7];
+            float opacity = (float)((cw >> 24) & 0xff) / 255.0f;
+            float cr = (float)(cw & 0xff) / 255.0f, cg = (float)((cw >> 8) & 0xff) / 255.0f, cb = (float)((cw >> 16) & 0xff) / 255.0f;
+            /* :226-229 + the GL viewport transform */
+            float vcx = pos2d[0] / pos2d[3], vcy = pos2d[1] / pos2d[3];
+            float xw = ((vcx + 1.0f) * 0.5f) * (float)W;
+            float yw = ((vcy + 1.0f) * 0.5f) * (float)H;
+            raw[0] = xw; raw[1] = yw; raw[2] = majx; raw[3] = majy; raw[4] = minx; raw[5] = miny;
+            raw[6] = opacity; raw[7] = cr; raw[8] = cg; raw[9] = cb; raw[11] = 1.0f;
+
+            /* ---- derived record (this build's own, image conventions) ---- */
+            float cx = xw;
+            float cy = ((1.0f - vcy) * 0.5f) * (float)H;
+            float m2 = majx * majx + majy * majy;
+            float n2 = minx * minx + miny * miny;
+            float im = 2.0f / m2, in = 2.0f / n2;
+            float ux = majx * im, uy = -majy * im;
+            float wx = minx * in, wy = -miny * in;
+            if (!(isfinite(ux) && isfinite(uy) && isfinite(wx) && isfinite(wy) && isfinite(cx) && isfinite(cy))) { raw[11] = 0.f; break; }
+            float ex = sqrtf(majx * majx + minx * minx);
+            float ey = sqrtf(majy * majy + miny * miny);
+            float fx0 = floorf(cx - ex - 0.5f), fx1 = ceilf(cx + ex - 0.5f);
+            float fy0 = floorf(cy - ey - 0.5f), fy1 = ceilf(cy + ey - 0.5f);
+            fx0 = fmaxf(fx0, 0.0f); fy0 = fmaxf(fy0, 0.0f);
+            fx1 = fminf(fx1, (float)(W - 1)); fy1 = fminf(fy1, (float)(H - 1));
+            rec[0] = cx; rec[1] = cy; rec[2] = ux; rec[3] = uy; rec[4] = wx; rec[5] = wy;
+            rec[6] = log2f(opacity); /* compared with a 2-ulp tolerance, not bitwise: v_log_f32 */
+            recu7 = cw & 0x00ffffffu;
+            if (fx0 > fx1 || fy0 > fy1) break; /* off-screen: keeps raw visible flag, empty bbox */
+            bb[0] = (int32_t)fx0; bb[1] = (int32_t)fy0; bb[2] = (int32_t)fx1; bb[3] = (int32_t)fy1;
+        } while (0);
+        if (raw_out) memcpy(raw_out + (size_t)12 * i, raw, sizeof raw);
+        if (rec_out) {
+            memcpy(rec_out + (size_t)8 * i, rec, sizeof rec);
+            memcpy(rec_out + (size_t)8 * i + 7, &recu7, 4);
+        }
+        if (bbox_out) memcpy(bbox_out + (size_t)4 * i, bb, sizeof bb);
+    }
+}
+
+/* Counts used by the bench's byte model: V = splats with a
+ * non-empty bbox, D = sum over them of TILE x TILE tiles their bbox overlaps. */
+void orc_tile_stats(const int32_t *bbox, uint32_t n, int tile, uint64_t *V, uint64_t *D)
+{
+    uint64_t v = 0, d = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const int32_t *b = bbox + (size_t)4 * i;
+        if (b[0] > b[2] || b[1] > b[3]) continue;
+        v++;
+        d += (uint64_t)(b[2] / tile - b[0] / tile + 1) * (uint64_t)(b[3] / tile - b[1] / tile + 1);
+    }
+    *V = v; *D = d;
+}
+
+/* ------------------------------------------------------------------------
+ * C1-C2: fragment stage + blend, frag.glsl.ts:13-21 with the blend state of
+ * WebGLRenderer.ts:139-142,279-285: clear (0,0,0,0); per fragment, in
+ * depth_index order:  dst.rgb += (1-dst.a)*B*rgb ; dst.a += (1-dst.a)*B.
+ * Accumulation is f64 (the browser's RGBA8 ROP rounding is NOT reproduced).
+ *
+ * mode 0 "ideal":    vPosition solved in f64 from the f32 varyings (raw),
+ *                    window coordinates, coverage |vPosition|^2 <= 4.
+ * mode 1 "restated": vPosition from the f32 record with the exact f32
+ *                    expression the HIP kernel uses, so the discard decision
+ *                    (A < -4) is bit-identical; weight and sums in f64.
+ * out: W*H*4 floats, premultiplied RGBA, row 0 = top.
+ * y_begin/y_end restrict rows (lets callers thread over row bands).
+ * ---------------------------------------------------------------------- */
+void orc_render(uint32_t n, const uint32_t *depth_index, const float *raw, const float *rec,
+                const int32_t *bbox, int W, int H, int mode, int y_begin, int y_end, float *out)
+{
+    size_t np = (size_t)W * (size_t)(y_end - y_begin);
+    double *acc = (double *)calloc(np * 4, sizeof(double));
+    for (uint32_t k = 0; k < n; k++) {
+        uint32_t i = depth_index[k];
+        const int32_t *b = bbox + (size_t)4 * i;
+        if (b[0] > b[2] || b[1] > b[3]) continue;
+        int y0 = b[1] < y_begin ? y_begin : b[1];
+        int y1 = b[3] >= y_end ? y_end - 1 : b[3];
+        const float *rw = raw + (size_t)12 * i;
+        const float *rc = rec + (size_t)8 * i;
+        uint32_t rgb8;
+        memcpy(&rgb8, rc + 7, 4);
+        double opacity = rw[6];
+        double cr = rw[7], cg = rw[8], cb = rw[9];
+        double M2 = (double)rw[2] * rw[2] + (double)rw[3] * rw[3];
+        double N2 = (double)rw[4] * rw[4] + (double)rw[5] * rw[5];
+        for (int y = y0; y <= y1; y++) {
+            for (int x = b[0]; x <= b[2]; x++) {
+                double B;
+                if (mode == 0) {
+                    double dx = (x + 0.5) - (double)rw[0];
+                    double dy = ((double)H - (y + 0.5)) - (double)rw[1];
+                    double vx = 2.0 * (dx * rw[2] + dy * rw[3]) / M2;
+                    double vy = 2.0 * (dx * rw[4] + dy * rw[5]) / N2;
+                    double A = -(vx * vx + vy * vy);
+                    if (A < -4.0) continue;
+                    B = exp(A) * opacity;
+                } else {
+                    float dx = ((float)x + 0.5f) - rc[0];
+                    float dy = ((float)y + 0.5f) - rc[1];
+                    float vx = rc[2] * dx + rc[3] * dy;
+                    float vy = rc[4] * dx + rc[5] * dy;
+                    float q = vx * vx + vy * vy;
+                    if (q > 4.0f) continue;
+                    B = exp(-(double)q) * opacity;
+                }
+                if (B > 1.0) B = 1.0;
+                if (B < 0.0) B = 0.0;
+                double *px = acc + ((size_t)(y - y_begin) * W + x) * 4;
+                double t = 1.0 - px[3];
+                px[0] += t * B * cr; px[1] += t * B * cg; px[2] += t * B * cb; px[3] += t * B;
+            }
+        }
+        (void)rgb8;
+    }
+    float *o = out + (size_t)y_begin * W * 4;
+    for (size_t j = 0; j < np * 4; j++) o[j] = (float)acc[j];
+    free(acc);
+}
