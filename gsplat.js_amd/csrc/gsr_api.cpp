@@ -1,0 +1,566 @@
+// C ABI of libgsplat_hip.so (see include/gsplat_hip.h).  Host side only: owns
+// the device buffers, enqueues the per-frame kernels on one HIP stream, and
+// never touches a CPU fallback: without a usable AMD GPU every entry point
+// fails with GSR_ERR_NO_DEVICE / GSR_ERR_HIP.
+#include "../../include/gsplat_hip.h"
+#include "gsr_internal.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace gsr;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+enum Stage { EV_BEGIN = 0, EV_PROJECT, EV_SORT, EV_BIN, EV_BLEND, EV_COUNT };
+
+struct FrameState {  // small per-frame device words, (re)initialised by one memcpy per frame
+    int32_t minmax[2];
+    uint32_t overflow;
+    uint32_t pad;
+    uint64_t visible;
+    uint32_t digit_total[RADIX_LO_BINS + RADIX_HI_BINS];
+};
+
+}  // namespace
+
+struct gsr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+    gsr_options opt{};
+    int W = 0, H = 0;
+    int band_x0 = 0, band_x1 = 0;
+
+    // scene
+    uint32_t n = 0;
+    float *px = nullptr, *py = nullptr, *pz = nullptr;
+    uint32_t *cov0 = nullptr, *cov1 = nullptr, *cov2 = nullptr, *rgba = nullptr;
+    // per frame, sized by n
+    int32_t* depth = nullptr;
+    uint32_t *keys = nullptr, *keys_tmp = nullptr, *idx_tmp = nullptr, *depth_index = nullptr;
+    uint32_t* block_hist = nullptr;
+    Record* rec = nullptr;
+    uint2* bbox = nullptr;
+    uint32_t sort_blocks = 0, sort_kpb = 0;
+    // binning
+    uint32_t *bin_table = nullptr, *bin_total = nullptr, *bin_start = nullptr, *bin_list = nullptr;
+    uint32_t bin_blocks = 0, bin_capacity = 0, bin_table_elems = 0, bin_nbins_alloc = 0;
+    // frame words
+    FrameState* fstate = nullptr;       // device
+    FrameState* fstate_init = nullptr;  // device, constant image copied into fstate every frame
+    FrameState* fstate_host = nullptr;  // pinned
+    // output
+    float4* fb = nullptr;
+    uint32_t* fb8 = nullptr;
+    size_t fb_pixels = 0;
+
+    CamParams cam{};
+    bool have_cam = false, have_frame = false, have_sort = false;
+
+    hipEvent_t ev[EV_COUNT]{};
+    bool ev_valid = false, ev_recorded = false, ev_render = false;
+    gsr_timings tm{};
+};
+
+namespace {
+
+int fail(gsr_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->error = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return fail((c), GSR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T>
+int dev_alloc(gsr_ctx* c, T** p, size_t count)
+{
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (!count) count = 1;
+    HIP_TRY(c, hipMalloc((void**)p, count * sizeof(T)));
+    return GSR_OK;
+}
+
+template <class T>
+void dev_free(T** p)
+{
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+}
+
+BinGrid make_grid(const gsr_ctx* c)
+{
+    BinGrid g;
+    g.W = c->W; g.H = c->H;
+    g.nbx = (c->W + BIN_PX - 1) / BIN_PX;
+    g.nby = (c->H + BIN_PX - 1) / BIN_PX;
+    if (c->band_x1 > c->band_x0) {
+        g.bx_lo = c->band_x0 / BIN_PX;
+        g.bx_hi = std::min((c->band_x1 + BIN_PX - 1) / BIN_PX, g.nbx);
+    } else {
+        g.bx_lo = 0; g.bx_hi = g.nbx;
+    }
+    return g;
+}
+
+int alloc_bins(gsr_ctx* c)
+{
+    if (!c->n || !c->W) return GSR_OK;
+    const BinGrid g = make_grid(c);
+    const uint32_t nbins = (uint32_t)((g.bx_hi - g.bx_lo) * g.nby);
+    c->bin_blocks = (c->n + 2047) / 2048;
+    const size_t table = (size_t)c->bin_blocks * nbins;
+    if (table > c->bin_table_elems) {
+        if (int r = dev_alloc(c, &c->bin_table, table)) return r;
+        c->bin_table_elems = (uint32_t)table;
+    }
+    if (nbins > c->bin_nbins_alloc) {
+        if (int r = dev_alloc(c, &c->bin_total, nbins)) return r;
+        if (int r = dev_alloc(c, &c->bin_start, nbins + 1)) return r;
+        c->bin_nbins_alloc = nbins;
+    }
+    if (!c->bin_capacity) {
+        c->bin_capacity = std::max<uint32_t>(4u * c->n + (1u << 20), 1u << 22);
+        if (int r = dev_alloc(c, &c->bin_list, c->bin_capacity)) return r;
+    }
+    return GSR_OK;
+}
+
+int alloc_fb(gsr_ctx* c)
+{
+    const size_t np = (size_t)c->W * c->H;
+    if (np > c->fb_pixels) {
+        if (int r = dev_alloc(c, &c->fb, np)) return r;
+        if (int r = dev_alloc(c, &c->fb8, np)) return r;
+        c->fb_pixels = np;
+    }
+    launch_clear_fb(c->fb, c->W, c->H, c->stream);
+    return GSR_OK;
+}
+
+// enqueue: frame words reset, projection + depth key, sort, (bin, blend)
+int enqueue_frame(gsr_ctx* c, bool render)
+{
+    if (!c->have_cam) return fail(c, GSR_ERR_ARG, "gsr_set_camera has not been called");
+    if (render && (!c->W || !c->H)) return fail(c, GSR_ERR_ARG, "framebuffer size is 0");
+    hipStream_t s = c->stream;
+    const bool timing = c->ev_valid;
+    c->cam.W = c->W; c->cam.H = c->H;
+    HIP_TRY(c, hipMemcpyAsync(c->fstate, c->fstate_init, sizeof(FrameState), hipMemcpyDeviceToDevice, s));
+    if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BEGIN], s));
+    if (c->n) {
+        SceneSoA sc{c->px, c->py, c->pz, c->cov0, c->cov1, c->cov2, c->rgba};
+        launch_project_key(sc, c->n, c->cam, render ? 1 : 0, c->depth, c->fstate->minmax, c->rec, c->bbox, s);
+    }
+    if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_PROJECT], s));
+    if (c->n) {
+        SortBuffers sb{c->depth, c->fstate->minmax, c->keys, c->keys_tmp, c->idx_tmp, c->depth_index,
+                       c->block_hist, c->fstate->digit_total, c->sort_kpb, c->sort_blocks};
+        launch_sort(sb, c->n, s);
+    }
+    if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_SORT], s));
+    if (render) {
+        const BinGrid g = make_grid(c);
+        const int nbins = (g.bx_hi - g.bx_lo) * g.nby;
+        HIP_TRY(c, hipMemsetAsync(c->bin_total, 0, sizeof(uint32_t) * nbins, s));
+        HIP_TRY(c, hipMemsetAsync(c->bin_start, 0, sizeof(uint32_t) * (nbins + 1), s));
+        if (c->n) {
+            BinBuffers bb{c->depth_index, c->bbox, c->bin_table, c->bin_total, c->bin_start, c->bin_list,
+                          &c->fstate->overflow, &c->fstate->visible, c->bin_capacity, 2048, c->bin_blocks};
+            launch_bin(bb, g, c->n, s);
+        }
+        if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BIN], s));
+        launch_blend(c->bin_start, c->bin_list, c->rec, c->bbox, c->fb, g, c->opt.early_out_eps, s);
+        if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BLEND], s));
+    }
+    HIP_TRY(c, hipGetLastError());
+    c->ev_recorded = timing;
+    c->ev_render = render;
+    c->have_sort = true;
+    c->have_frame = c->have_frame || render;
+    return GSR_OK;
+}
+
+int finish_frame(gsr_ctx* c)
+{
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->ev_recorded) {
+        float a = 0, b = 0, d = 0, e = 0, t = 0;
+        HIP_TRY(c, hipEventElapsedTime(&a, c->ev[EV_BEGIN], c->ev[EV_PROJECT]));
+        HIP_TRY(c, hipEventElapsedTime(&b, c->ev[EV_PROJECT], c->ev[EV_SORT]));
+        t = a + b;
+        if (c->ev_render) {
+            HIP_TRY(c, hipEventElapsedTime(&d, c->ev[EV_SORT], c->ev[EV_BIN]));
+            HIP_TRY(c, hipEventElapsedTime(&e, c->ev[EV_BIN], c->ev[EV_BLEND]));
+            HIP_TRY(c, hipEventElapsedTime(&t, c->ev[EV_BEGIN], c->ev[EV_BLEND]));
+        }
+        c->tm.ms_project_key = a; c->tm.ms_sort = b; c->tm.ms_bin = d; c->tm.ms_blend = e; c->tm.ms_total = t;
+        c->tm.sum_ms_project_key += a; c->tm.sum_ms_sort += b; c->tm.sum_ms_bin += d; c->tm.sum_ms_blend += e;
+        c->tm.sum_ms_total += t;
+        c->tm.frames++;
+        c->ev_recorded = false;
+    }
+    return GSR_OK;
+}
+
+// after a synchronised render: pull the frame words, regrow the bin list if it overflowed
+int check_frame_words(gsr_ctx* c, bool* overflowed)
+{
+    HIP_TRY(c, hipMemcpyAsync(c->fstate_host, c->fstate, 32, hipMemcpyDeviceToHost, c->stream));
+    uint32_t total = 0;
+    const BinGrid g = make_grid(c);
+    const int nbins = (g.bx_hi - g.bx_lo) * g.nby;
+    HIP_TRY(c, hipMemcpyAsync(&total, c->bin_start + nbins, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->tm.visible = c->fstate_host->visible;
+    c->tm.bin_entries = total;
+    c->tm.n = c->n;
+    *overflowed = c->fstate_host->overflow != 0;
+    if (*overflowed) {
+        const uint64_t want = (uint64_t)total + (total >> 2) + (1u << 20);
+        if (want > 0xfffffff0ull) return fail(c, GSR_ERR_OVERFLOW, "bin list would need %llu entries", (unsigned long long)want);
+        c->bin_capacity = (uint32_t)want;
+        if (int r = dev_alloc(c, &c->bin_list, c->bin_capacity)) return r;
+    }
+    return GSR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gsr_last_error(gsr_ctx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int gsr_create(gsr_ctx** out, const gsr_options* opt)
+{
+    if (!out) return fail(nullptr, GSR_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(nullptr, GSR_ERR_NO_DEVICE, "no HIP device is visible (this library has no CPU path)");
+    gsr_options o{};
+    if (opt) o = *opt;
+    if (o.device < 0 || o.device >= count) return fail(nullptr, GSR_ERR_ARG, "device %d out of range (%d visible)", o.device, count);
+    if (o.width < 0 || o.height < 0 || o.width > 65535 || o.height > 65535) return fail(nullptr, GSR_ERR_ARG, "bad framebuffer size %dx%d", o.width, o.height);
+    if (!(o.early_out_eps >= 0.0f && o.early_out_eps < 1.0f)) return fail(nullptr, GSR_ERR_ARG, "early_out_eps must be in [0,1)");
+    gsr_ctx* c = new gsr_ctx();
+    c->device = o.device;
+    c->opt = o;
+    auto bail = [&](int code) {
+        g_create_error = c->error;
+        gsr_destroy(c);
+        return code;
+    };
+#define CREATE_TRY(expr)                                                                                          \
+    do {                                                                                                          \
+        hipError_t e_ = (expr);                                                                                   \
+        if (e_ != hipSuccess) { fail(c, GSR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); return bail(GSR_ERR_HIP); } \
+    } while (0)
+    CREATE_TRY(hipSetDevice(c->device));
+    CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipMalloc((void**)&c->fstate, sizeof(FrameState)));
+    CREATE_TRY(hipMalloc((void**)&c->fstate_init, sizeof(FrameState)));
+    CREATE_TRY(hipHostMalloc((void**)&c->fstate_host, sizeof(FrameState), hipHostMallocDefault));
+    memset(c->fstate_host, 0, sizeof(FrameState));
+    c->fstate_host->minmax[0] = 0x7fffffff;            // wasm/wasm.cpp:14
+    c->fstate_host->minmax[1] = (int32_t)0x80000000;   // wasm/wasm.cpp:15
+    CREATE_TRY(hipMemcpy(c->fstate_init, c->fstate_host, sizeof(FrameState), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(c->fstate, c->fstate_host, sizeof(FrameState), hipMemcpyHostToDevice));
+    if (o.flags & GSR_FLAG_TIMING) {
+        for (auto& e : c->ev) CREATE_TRY(hipEventCreate(&e));
+        c->ev_valid = true;
+    }
+#undef CREATE_TRY
+    *out = c;
+    if (o.width && o.height) {
+        int r = gsr_resize(c, o.width, o.height);
+        if (r) { *out = nullptr; return bail(r); }
+        if (o.band_x1 > o.band_x0) {
+            r = gsr_set_band(c, o.band_x0, o.band_x1);
+            if (r) { *out = nullptr; return bail(r); }
+        }
+    }
+    return GSR_OK;
+}
+
+int gsr_destroy(gsr_ctx* c)
+{
+    if (!c) return GSR_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    dev_free(&c->px); dev_free(&c->py); dev_free(&c->pz);
+    dev_free(&c->cov0); dev_free(&c->cov1); dev_free(&c->cov2); dev_free(&c->rgba);
+    dev_free(&c->depth); dev_free(&c->keys); dev_free(&c->keys_tmp); dev_free(&c->idx_tmp); dev_free(&c->depth_index);
+    dev_free(&c->block_hist); dev_free(&c->rec); dev_free(&c->bbox);
+    dev_free(&c->bin_table); dev_free(&c->bin_total); dev_free(&c->bin_start); dev_free(&c->bin_list);
+    dev_free(&c->fstate); dev_free(&c->fstate_init); dev_free(&c->fb); dev_free(&c->fb8);
+    if (c->fstate_host) (void)hipHostFree(c->fstate_host);
+    if (c->ev_valid) for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return GSR_OK;
+}
+
+int gsr_set_scene(gsr_ctx* c, const uint32_t* data, const float* positions, uint32_t n)
+{
+    if (!c) return GSR_ERR_ARG;
+    if (n && (!data || !positions)) return fail(c, GSR_ERR_ARG, "data/positions is NULL");
+    if (n > 0x7fffffffu / 8) return fail(c, GSR_ERR_ARG, "too many splats");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->n = 0; c->have_frame = false; c->have_sort = false;
+    int r;
+    if ((r = dev_alloc(c, &c->px, n)) || (r = dev_alloc(c, &c->py, n)) || (r = dev_alloc(c, &c->pz, n)) ||
+        (r = dev_alloc(c, &c->cov0, n)) || (r = dev_alloc(c, &c->cov1, n)) || (r = dev_alloc(c, &c->cov2, n)) ||
+        (r = dev_alloc(c, &c->rgba, n)) || (r = dev_alloc(c, &c->depth, n)) || (r = dev_alloc(c, &c->keys, n)) ||
+        (r = dev_alloc(c, &c->keys_tmp, n)) || (r = dev_alloc(c, &c->idx_tmp, n)) ||
+        (r = dev_alloc(c, &c->depth_index, n)) || (r = dev_alloc(c, &c->rec, n)) || (r = dev_alloc(c, &c->bbox, n)))
+        return r;
+    c->sort_kpb = 2048;
+    c->sort_blocks = (n + c->sort_kpb - 1) / c->sort_kpb;
+    if ((r = dev_alloc(c, &c->block_hist, (size_t)std::max(c->sort_blocks, 1u) * RADIX_HI_BINS))) return r;
+    if (n) {
+        uint32_t* d_data = nullptr; float* d_pos = nullptr; uint32_t* d_flag = nullptr;
+        if ((r = dev_alloc(c, &d_data, (size_t)n * 8)) || (r = dev_alloc(c, &d_pos, (size_t)n * 3)) || (r = dev_alloc(c, &d_flag, 1))) {
+            dev_free(&d_data); dev_free(&d_pos); dev_free(&d_flag);
+            return r;
+        }
+        hipError_t e1 = hipMemcpyAsync(d_data, data, (size_t)n * 32, hipMemcpyHostToDevice, c->stream);
+        hipError_t e2 = hipMemcpyAsync(d_pos, positions, (size_t)n * 12, hipMemcpyHostToDevice, c->stream);
+        hipError_t e3 = hipMemsetAsync(d_flag, 0, 4, c->stream);
+        launch_repack_scene(d_data, d_pos, n, c->px, c->py, c->pz, c->cov0, c->cov1, c->cov2, c->rgba, d_flag, c->stream);
+        uint32_t flag = 0;
+        hipError_t e4 = hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, c->stream);
+        hipError_t e5 = hipStreamSynchronize(c->stream);
+        dev_free(&d_data); dev_free(&d_pos); dev_free(&d_flag);
+        for (hipError_t e : {e1, e2, e3, e4, e5, hipGetLastError()})
+            if (e != hipSuccess) return fail(c, GSR_ERR_HIP, "scene upload failed: %s", hipGetErrorString(e));
+        if (flag) return fail(c, GSR_ERR_SCENE, "positions differ from data words 0..2 (Scene.ts:141-143 keeps them equal)");
+    }
+    c->n = n;
+    c->bin_capacity = 0;
+    return alloc_bins(c);
+}
+
+int gsr_resize(gsr_ctx* c, int32_t w, int32_t h)
+{
+    if (!c) return GSR_ERR_ARG;
+    if (w <= 0 || h <= 0 || w > 65535 || h > 65535) return fail(c, GSR_ERR_ARG, "bad framebuffer size %dx%d", w, h);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->W = w; c->H = h;
+    c->band_x0 = c->band_x1 = 0;
+    c->have_frame = false;
+    if (int r = alloc_fb(c)) return r;
+    return alloc_bins(c);
+}
+
+int gsr_set_band(gsr_ctx* c, int32_t x0, int32_t x1)
+{
+    if (!c) return GSR_ERR_ARG;
+    if (x0 == 0 && x1 == 0) { c->band_x0 = c->band_x1 = 0; return alloc_bins(c); }
+    if (x0 < 0 || x1 <= x0 || x0 % BIN_PX) return fail(c, GSR_ERR_ARG, "band [%d,%d) must start on a multiple of %d", x0, x1, BIN_PX);
+    if (x1 > c->W) x1 = c->W;
+    if (x0 >= c->W) return fail(c, GSR_ERR_ARG, "band starts outside the image");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->band_x0 = x0; c->band_x1 = x1;
+    launch_clear_fb(c->fb, c->W, c->H, c->stream);
+    return alloc_bins(c);
+}
+
+int gsr_set_camera(gsr_ctx* c, const float* view, const float* proj, const float* vp, float fx, float fy)
+{
+    if (!c) return GSR_ERR_ARG;
+    if (!view || !proj || !vp) return fail(c, GSR_ERR_ARG, "matrix pointer is NULL");
+    memcpy(c->cam.view, view, 64);
+    memcpy(c->cam.proj, proj, 64);
+    c->cam.vp2 = vp[2]; c->cam.vp6 = vp[6]; c->cam.vp10 = vp[10];
+    c->cam.fx = fx; c->cam.fy = fy;
+    c->have_cam = true;
+    return GSR_OK;
+}
+
+int gsr_render_async(gsr_ctx* c)
+{
+    if (!c) return GSR_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->ev_recorded) { if (int r = finish_frame(c)) return r; }
+    return enqueue_frame(c, true);
+}
+
+int gsr_sync(gsr_ctx* c)
+{
+    if (!c) return GSR_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (int r = finish_frame(c)) return r;
+    if (c->have_frame && c->ev_render) {
+        bool ov = false;
+        if (int r = check_frame_words(c, &ov)) return r;
+        if (ov) {  // the list was too small: it has been regrown, redo the last frame once
+            if (int r = enqueue_frame(c, true)) return r;
+            if (int r = finish_frame(c)) return r;
+            if (int r = check_frame_words(c, &ov)) return r;
+            if (ov) return fail(c, GSR_ERR_OVERFLOW, "bin list overflow after regrowth");
+        }
+    }
+    return GSR_OK;
+}
+
+int gsr_render(gsr_ctx* c)
+{
+    if (int r = gsr_render_async(c)) return r;
+    c->ev_render = true;
+    return gsr_sync(c);
+}
+
+int gsr_sort(gsr_ctx* c)
+{
+    if (!c) return GSR_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->ev_recorded) { if (int r = finish_frame(c)) return r; }
+    if (int r = enqueue_frame(c, false)) return r;
+    return finish_frame(c);
+}
+
+int gsr_read_depth_index(gsr_ctx* c, uint32_t* out)
+{
+    if (!c || !out) return c ? fail(c, GSR_ERR_ARG, "out is NULL") : GSR_ERR_ARG;
+    if (!c->have_sort) return fail(c, GSR_ERR_ARG, "no sort has run yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(out, c->depth_index, (size_t)c->n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return GSR_OK;
+}
+
+int gsr_read_pixels_rgba32f(gsr_ctx* c, float* out)
+{
+    if (!c || !out) return c ? fail(c, GSR_ERR_ARG, "out is NULL") : GSR_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(out, c->fb, (size_t)c->W * c->H * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return GSR_OK;
+}
+
+int gsr_read_pixels_rgba8(gsr_ctx* c, uint8_t* out)
+{
+    if (!c || !out) return c ? fail(c, GSR_ERR_ARG, "out is NULL") : GSR_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t np = (uint32_t)c->W * (uint32_t)c->H;
+    launch_to_rgba8(c->fb, c->fb8, np, c->stream);
+    HIP_TRY(c, hipMemcpyAsync(out, c->fb8, (size_t)np * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return GSR_OK;
+}
+
+int gsr_get_timings(gsr_ctx* c, gsr_timings* out)
+{
+    if (!c || !out) return GSR_ERR_ARG;
+    if (c->ev_recorded) { if (int r = finish_frame(c)) return r; }
+    *out = c->tm;
+    return GSR_OK;
+}
+
+int gsr_reset_timings(gsr_ctx* c)
+{
+    if (!c) return GSR_ERR_ARG;
+    if (c->ev_recorded) { if (int r = finish_frame(c)) return r; }
+    const uint64_t v = c->tm.visible, b = c->tm.bin_entries;
+    c->tm = gsr_timings{};
+    c->tm.visible = v; c->tm.bin_entries = b; c->tm.n = c->n;
+    return GSR_OK;
+}
+
+int gsr_read_keys(gsr_ctx* c, uint32_t* keys, int32_t* minmax)
+{
+    if (!c) return GSR_ERR_ARG;
+    if (!c->have_sort) return fail(c, GSR_ERR_ARG, "no sort has run yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (keys) HIP_TRY(c, hipMemcpyAsync(keys, c->keys, (size_t)c->n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (minmax) HIP_TRY(c, hipMemcpyAsync(minmax, c->fstate->minmax, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return GSR_OK;
+}
+
+int gsr_read_records(gsr_ctx* c, float* rec, int32_t* bbox)
+{
+    if (!c) return GSR_ERR_ARG;
+    if (!c->have_frame) return fail(c, GSR_ERR_ARG, "no frame has been rendered yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (rec) HIP_TRY(c, hipMemcpyAsync(rec, c->rec, (size_t)c->n * 32, hipMemcpyDeviceToHost, c->stream));
+    std::vector<uint2> tmp;
+    if (bbox) {
+        tmp.resize(c->n);
+        HIP_TRY(c, hipMemcpyAsync(tmp.data(), c->bbox, (size_t)c->n * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (bbox)
+        for (uint32_t i = 0; i < c->n; i++) {
+            bbox[4 * (size_t)i + 0] = (int32_t)(tmp[i].x & 0xffff);
+            bbox[4 * (size_t)i + 1] = (int32_t)(tmp[i].y & 0xffff);
+            bbox[4 * (size_t)i + 2] = (int32_t)(tmp[i].x >> 16);
+            bbox[4 * (size_t)i + 3] = (int32_t)(tmp[i].y >> 16);
+        }
+    return GSR_OK;
+}
+
+void* gsr_framebuffer_device_ptr(gsr_ctx* c) { return c ? (void*)c->fb : nullptr; }
+void* gsr_stream_handle(gsr_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int gsr_device_info(gsr_ctx* c, char* name, int32_t name_len, int32_t* cus, int32_t* clock_khz)
+{
+    if (!c) return GSR_ERR_ARG;
+    hipDeviceProp_t p;
+    HIP_TRY(c, hipGetDeviceProperties(&p, c->device));
+    if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s (%s)", p.name, p.gcnArchName);
+    if (cus) *cus = p.multiProcessorCount;
+    if (clock_khz) *clock_khz = p.clockRate;
+    return GSR_OK;
+}
+
+// ---- wasm `sort` drop-in (wasm/wasm.cpp:8-13; call site Worker.ts:39) ----
+void gsplat_sort_host(const float* viewProj, uint32_t vertexCount, const float* fBuffer, uint32_t* depthBuffer,
+                      uint32_t* depthIndex, uint32_t* starts, uint32_t* counts)
+{
+    (void)starts; (void)counts;
+    static std::mutex mu;
+    static gsr_ctx* ctx = nullptr;
+    static const float* last_buf = nullptr;
+    static uint32_t last_n = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ctx) {
+        gsr_options o{};
+        if (gsr_create(&ctx, &o) != GSR_OK) { fprintf(stderr, "gsplat_sort_host: %s\n", gsr_last_error(nullptr)); return; }
+    }
+    // The worker copies positions once per scene (Worker.ts:26-27); here the scene is re-uploaded
+    // whenever the buffer identity or size changes.
+    if (fBuffer != last_buf || vertexCount != last_n) {
+        std::vector<uint32_t> data((size_t)vertexCount * 8, 0u);
+        for (uint32_t i = 0; i < vertexCount; i++) memcpy(&data[(size_t)8 * i], fBuffer + (size_t)3 * i, 12);
+        if (gsr_set_scene(ctx, data.data(), fBuffer, vertexCount) != GSR_OK) { fprintf(stderr, "gsplat_sort_host: %s\n", gsr_last_error(ctx)); return; }
+        last_buf = fBuffer; last_n = vertexCount;
+    }
+    float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    if (gsr_set_camera(ctx, ident, ident, viewProj, 1.f, 1.f) != GSR_OK || gsr_sort(ctx) != GSR_OK ||
+        gsr_read_depth_index(ctx, depthIndex) != GSR_OK || (depthBuffer && gsr_read_keys(ctx, depthBuffer, nullptr) != GSR_OK))
+        fprintf(stderr, "gsplat_sort_host: %s\n", gsr_last_error(ctx));
+}
+
+}  // extern "C"

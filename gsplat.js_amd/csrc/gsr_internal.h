@@ -1,0 +1,95 @@
+// Internal declarations shared by the HIP translation units of libgsplat_hip.so.
+// gfx950 (MI355X) only: wave64, 256 CUs in 8 XCDs, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gsr {
+
+constexpr int WAVE = 64;
+constexpr uint32_t DEPTH_RANGE = 65536u;   // wasm/wasm.cpp:33
+constexpr int KEY_BITS = 17;               // keys are in [0, 65536]
+constexpr int RADIX_LO_BITS = 8;           // pass 1 digit: key & 0xff
+constexpr int RADIX_HI_BITS = 9;           // pass 2 digit: key >> 8  (0..256)
+constexpr int RADIX_LO_BINS = 1 << RADIX_LO_BITS;
+constexpr int RADIX_HI_BINS = 1 << RADIX_HI_BITS;
+
+constexpr int TILE = 16;                   // pixels per tile side: one wave per tile, 4 px per lane
+constexpr int BIN_TILES = 2;               // tiles per coarse-bin side
+constexpr int BIN_PX = TILE * BIN_TILES;   // 32 px: one workgroup (4 waves) per bin
+
+// Camera constants passed by value (kernarg -> SGPRs).
+struct CamParams {
+    float view[16];
+    float proj[16];
+    float vp2, vp6, vp10;   // row 2 of viewProj: wasm/wasm.cpp:18-20
+    float fx, fy;
+    int32_t W, H;
+};
+
+// 32-byte projected record consumed by the tile compositor (image coordinates, row 0 = top).
+//   vPosition at pixel centre p is (dot(p-c,u), dot(p-c,w)); coverage |vPosition|^2 <= 4.
+struct __attribute__((aligned(16))) Record {
+    float cx, cy, ux, uy;
+    float wx, wy, la;       // la = log2(opacity)
+    uint32_t rgb8;          // r | g<<8 | b<<16
+};
+static_assert(sizeof(Record) == 32, "record must be 32 bytes");
+
+// Packed inclusive pixel bounding box: x = x0 | x1<<16, y = y0 | y1<<16; invisible when x0 > x1.
+constexpr uint32_t BBOX_INVISIBLE_X = 1u;  // x0 = 1, x1 = 0
+constexpr uint32_t BBOX_INVISIBLE_Y = 1u;
+
+struct SceneSoA {
+    const float *px, *py, *pz;
+    const uint32_t *cov0, *cov1, *cov2, *rgba;
+};
+
+// ---- launchers (each enqueues on `s`; none synchronises) ----
+void launch_repack_scene(const uint32_t* data, const float* positions, uint32_t n, float* px, float* py, float* pz,
+                         uint32_t* cov0, uint32_t* cov1, uint32_t* cov2, uint32_t* rgba, uint32_t* mismatch, hipStream_t s);
+
+void launch_project_key(const SceneSoA& sc, uint32_t n, const CamParams& cam, int do_project, int32_t* depth,
+                        int32_t* minmax, Record* rec, uint2* bbox, hipStream_t s);
+
+// radix sort of the 17-bit keys; see k_sort.hip
+struct SortBuffers {
+    const int32_t* depth;      // n
+    const int32_t* minmax;     // 2
+    uint32_t* keys;            // n   17-bit keys, original order
+    uint32_t* keys_tmp;        // n   keys after pass 1
+    uint32_t* idx_tmp;         // n   indices after pass 1
+    uint32_t* depth_index;     // n   result
+    uint32_t* block_hist;      // nblocks * RADIX_HI_BINS
+    uint32_t* digit_total;     // RADIX_LO_BINS + RADIX_HI_BINS
+    uint32_t keys_per_block;
+    uint32_t nblocks;
+};
+void launch_sort(const SortBuffers& b, uint32_t n, hipStream_t s);
+
+struct BinGrid {
+    int32_t nbx, nby;          // bins across / down the whole image
+    int32_t bx_lo, bx_hi;      // bin columns of this context's band [lo, hi)
+    int32_t W, H;
+};
+struct BinBuffers {
+    const uint32_t* depth_index; // n
+    const uint2* bbox;           // n
+    uint32_t* table;             // nblocks * nbins  (counts, then per-block bases)
+    uint32_t* bin_total;         // nbins
+    uint32_t* bin_start;         // nbins + 1
+    uint32_t* list;              // capacity entries (splat indices, depth order inside each bin)
+    uint32_t* overflow;          // set to 1 if an entry did not fit
+    uint64_t* visible;           // V counter
+    uint32_t capacity;
+    uint32_t ranks_per_block;
+    uint32_t nblocks;
+};
+void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s);
+
+void launch_blend(const uint32_t* bin_start, const uint32_t* list, const Record* rec, const uint2* bbox,
+                  float4* fb, const BinGrid& g, float early_out_eps, hipStream_t s);
+void launch_clear_fb(float4* fb, int32_t W, int32_t H, hipStream_t s);
+void launch_to_rgba8(const float4* fb, uint32_t* out, uint32_t npix, hipStream_t s);
+
+}  // namespace gsr

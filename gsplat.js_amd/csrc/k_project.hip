@@ -1,0 +1,221 @@
+// Per-splat stage: scene repack (once per scene) and the fused
+// depth-key + min/max + projection kernel (once per frame).
+//
+// Compiled with -ffp-contract=off: every f32 operation below is a single
+// correctly rounded IEEE operation in the written order, so the depth key is
+// bit-identical to wasm/wasm.cpp:14-31 and every projected field is
+// bit-identical to the CPU restatement of vertex.glsl.ts:130-231.
+#include "gsr_internal.h"
+
+namespace gsr {
+
+// ---------------------------------------------------------------------------
+// Scene.data (AoS, 8 u32 per splat: the RGBA32UI texel pair of
+// WebGLRenderer.ts:185-195) -> SoA arrays, so the per-frame kernels read
+// 28 B/splat fully coalesced instead of 32-B gathers.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_repack_scene(const uint4* __restrict__ data, const float* __restrict__ positions,
+                                                      uint32_t n, float* __restrict__ px, float* __restrict__ py,
+                                                      float* __restrict__ pz, uint32_t* __restrict__ cov0,
+                                                      uint32_t* __restrict__ cov1, uint32_t* __restrict__ cov2,
+                                                      uint32_t* __restrict__ rgba, uint32_t* __restrict__ mismatch)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint4 a = data[2 * (size_t)i], b = data[2 * (size_t)i + 1];
+    float x = positions[3 * (size_t)i], y = positions[3 * (size_t)i + 1], z = positions[3 * (size_t)i + 2];
+    if (__float_as_uint(x) != a.x || __float_as_uint(y) != a.y || __float_as_uint(z) != a.z) atomicOr(mismatch, 1u);
+    px[i] = x; py[i] = y; pz[i] = z;
+    cov0[i] = b.x; cov1[i] = b.y; cov2[i] = b.z; rgba[i] = b.w;
+}
+
+void launch_repack_scene(const uint32_t* data, const float* positions, uint32_t n, float* px, float* py, float* pz,
+                         uint32_t* cov0, uint32_t* cov1, uint32_t* cov2, uint32_t* rgba, uint32_t* mismatch, hipStream_t s)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_repack_scene, dim3((n + 255) / 256), dim3(256), 0, s, (const uint4*)data, positions, n, px, py,
+                       pz, cov0, cov1, cov2, rgba, mismatch);
+}
+
+// ---------------------------------------------------------------------------
+// helpers (column-major 3x3, GLSL conventions: m[c*3+r])
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void mat3_mul(const float* a, const float* b, float* r)
+{
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int ro = 0; ro < 3; ro++) {
+            float s = a[0 * 3 + ro] * b[c * 3 + 0];
+            s = s + a[1 * 3 + ro] * b[c * 3 + 1];
+            s = s + a[2 * 3 + ro] * b[c * 3 + 2];
+            r[c * 3 + ro] = s;
+        }
+}
+
+__device__ __forceinline__ float half_bits_to_float(uint32_t h)
+{
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)(h & 0xffffu));  // v_cvt_f32_f16: exact
+}
+
+__device__ __forceinline__ bool finite4(float a, float b, float c, float d)
+{
+    return isfinite(a) && isfinite(b) && isfinite(c) && isfinite(d);
+}
+
+// ---------------------------------------------------------------------------
+// One thread per splat, original order (fully coalesced SoA reads).
+//   A1  depth key + min/max        wasm/wasm.cpp:14-31
+//   B1-B6 projection               vertex.glsl.ts:130-231 (non-SH colour branch, scalingFactor 1)
+// Writes depth[i] always; rec[i] for splats that survive the culls; bbox[i] always
+// (x0 > x1 marks "nothing to draw").
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_project_key(SceneSoA sc, uint32_t n, CamParams cam, int do_project,
+                                                     int32_t* __restrict__ depth, int32_t* __restrict__ minmax,
+                                                     Record* __restrict__ rec, uint2* __restrict__ bbox)
+{
+    __shared__ int32_t s_min[4], s_max[4];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    int32_t dmin = 0x7fffffff, dmax = (int32_t)0x80000000;
+
+    if (i < n) {
+        const float x = sc.px[i], y = sc.py[i], z = sc.pz[i];
+        // ---- A1: three separate f32 multiplies, left-to-right adds, *4096 in f32, truncate ----
+        const float f0 = cam.vp2 * x;
+        const float f1 = cam.vp6 * y;
+        const float f2 = cam.vp10 * z;
+        const int32_t d = (int32_t)(((f0 + f1) + f2) * 4096.0f);
+        depth[i] = d;
+        dmin = d; dmax = d;
+
+        if (do_project) {
+            uint2 bb = make_uint2(BBOX_INVISIBLE_X, BBOX_INVISIBLE_Y);
+            do {
+                // :133-136  cam = view * vec4(p,1); pos2d = projection * cam
+                float camv[4], pos2d[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float s = cam.view[0 * 4 + r] * x;
+                    s = s + cam.view[1 * 4 + r] * y;
+                    s = s + cam.view[2 * 4 + r] * z;
+                    s = s + cam.view[3 * 4 + r];
+                    camv[r] = s;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float s = cam.proj[0 * 4 + r] * camv[0];
+                    s = s + cam.proj[1 * 4 + r] * camv[1];
+                    s = s + cam.proj[2 * 4 + r] * camv[2];
+                    s = s + cam.proj[3 * 4 + r] * camv[3];
+                    pos2d[r] = s;
+                }
+                // :138-142
+                const float clip = 1.2f * pos2d[3];
+                if (pos2d[2] < -pos2d[3] || pos2d[0] < -clip || pos2d[0] > clip || pos2d[1] < -clip || pos2d[1] > clip) break;
+
+                // :144-146
+                const uint32_t c0 = sc.cov0[i], c1 = sc.cov1[i], c2 = sc.cov2[i], cw = sc.rgba[i];
+                const float u1x = half_bits_to_float(c0), u1y = half_bits_to_float(c0 >> 16);
+                const float u2x = half_bits_to_float(c1), u2y = half_bits_to_float(c1 >> 16);
+                const float u3x = half_bits_to_float(c2), u3y = half_bits_to_float(c2 >> 16);
+                const float Vrk[9] = {u1x, u1y, u2x, u1y, u2y, u3x, u2x, u3x, u3y};
+                // :148-152
+                const float zz = camv[2] * camv[2];
+                const float J[9] = {cam.fx / camv[2], 0.f, -(cam.fx * camv[0]) / zz,
+                                    0.f, -cam.fy / camv[2], (cam.fy * camv[1]) / zz,
+                                    0.f, 0.f, 0.f};
+                // :154-155  T = transpose(mat3(view)) * J; cov2d = transpose(T) * Vrk * T
+                const float V3t[9] = {cam.view[0], cam.view[4], cam.view[8], cam.view[1], cam.view[5],
+                                      cam.view[9], cam.view[2], cam.view[6], cam.view[10]};
+                float T[9], Tt[9], TtV[9], cov2d[9];
+                mat3_mul(V3t, J, T);
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+#pragma unroll
+                    for (int r = 0; r < 3; r++) Tt[c * 3 + r] = T[r * 3 + c];
+                mat3_mul(Tt, Vrk, TtV);
+                mat3_mul(TtV, T, cov2d);
+                // :158-163
+                const float a = cov2d[0] + 0.3f;
+                const float b = cov2d[1];
+                const float c = cov2d[4] + 0.3f;
+                const float det = a * c - b * b;
+                if (det == 0.0f) break;
+                // :166-171
+                const float mid = (a + c) / 2.0f;
+                const float rad = mid * mid - det;
+                const float sq = sqrtf((0.1f < rad) ? rad : 0.1f);
+                const float lambda1 = mid + sq;
+                const float lambda2 = mid - sq;
+                if (lambda2 < 0.0f) break;
+                // :173-175
+                const float dvx = b, dvy = lambda1 - a;
+                const float len = sqrtf(dvx * dvx + dvy * dvy);
+                const float dgx = dvx / len, dgy = dvy / len;
+                float smaj = sqrtf(2.0f * lambda1), smin = sqrtf(2.0f * lambda2);
+                smaj = (1024.0f < smaj) ? 1024.0f : smaj;
+                smin = (1024.0f < smin) ? 1024.0f : smin;
+                const float majx = smaj * dgx, majy = smaj * dgy;
+                const float minx = smin * dgy, miny = smin * -dgx;
+                if (!finite4(majx, majy, minx, miny)) break;  // normalize(0,0) -> NaN: splat dropped
+                // :177-178: opacity; colour stays packed (:207 divides by 255 at composite time)
+                const float opacity = (float)((cw >> 24) & 0xffu) / 255.0f;
+                // :226-229 + viewport transform, image rows top-down
+                const float vcx = pos2d[0] / pos2d[3], vcy = pos2d[1] / pos2d[3];
+                const float cx = ((vcx + 1.0f) * 0.5f) * (float)cam.W;
+                const float cy = ((1.0f - vcy) * 0.5f) * (float)cam.H;
+                const float m2 = majx * majx + majy * majy;
+                const float n2 = minx * minx + miny * miny;
+                const float im = 2.0f / m2, in = 2.0f / n2;
+                Record r;
+                r.cx = cx; r.cy = cy;
+                r.ux = majx * im; r.uy = -majy * im;
+                r.wx = minx * in; r.wy = -miny * in;
+                if (!(finite4(r.ux, r.uy, r.wx, r.wy) && isfinite(cx) && isfinite(cy))) break;
+                r.la = __log2f(opacity);
+                r.rgb8 = cw & 0x00ffffffu;
+                // bounding box of the |vPosition| <= 2 ellipse, pixel centres at +0.5
+                const float ex = sqrtf(majx * majx + minx * minx);
+                const float ey = sqrtf(majy * majy + miny * miny);
+                float fx0 = floorf(cx - ex - 0.5f), fx1 = ceilf(cx + ex - 0.5f);
+                float fy0 = floorf(cy - ey - 0.5f), fy1 = ceilf(cy + ey - 0.5f);
+                fx0 = fmaxf(fx0, 0.0f); fy0 = fmaxf(fy0, 0.0f);
+                fx1 = fminf(fx1, (float)(cam.W - 1)); fy1 = fminf(fy1, (float)(cam.H - 1));
+                // the record is written even when the bbox is empty (parity read-back)
+                float4* rp = reinterpret_cast<float4*>(rec + i);
+                rp[0] = make_float4(r.cx, r.cy, r.ux, r.uy);
+                rp[1] = make_float4(r.wx, r.wy, r.la, __uint_as_float(r.rgb8));
+                if (fx0 > fx1 || fy0 > fy1) break;
+                bb.x = (uint32_t)(int32_t)fx0 | ((uint32_t)(int32_t)fx1 << 16);
+                bb.y = (uint32_t)(int32_t)fy0 | ((uint32_t)(int32_t)fy1 << 16);
+            } while (0);
+            bbox[i] = bb;
+        }
+    }
+
+    // ---- block min/max -> two global atomics per block ----
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        dmin = min(dmin, __shfl_xor(dmin, off));
+        dmax = max(dmax, __shfl_xor(dmax, off));
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_min[wave] = dmin; s_max[wave] = dmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        dmin = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
+        dmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+        atomicMin(&minmax[0], dmin);
+        atomicMax(&minmax[1], dmax);
+    }
+}
+
+void launch_project_key(const SceneSoA& sc, uint32_t n, const CamParams& cam, int do_project, int32_t* depth,
+                        int32_t* minmax, Record* rec, uint2* bbox, hipStream_t s)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_project_key, dim3((n + 255) / 256), dim3(256), 0, s, sc, n, cam, do_project, depth, minmax, rec,
+                       bbox);
+}
+
+}  // namespace gsr

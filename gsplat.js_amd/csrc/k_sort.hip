@@ -1,0 +1,214 @@
+// Depth-key quantisation (wasm/wasm.cpp:33-40) and a stable 2-pass LSD radix
+// sort of the 17-bit keys (8 low bits, then 9 high bits), which reproduces the
+// reference's stable counting sort (wasm/wasm.cpp:42-51) exactly: ascending
+// key, ties by ascending original index.
+//
+// Each pass is histogram -> per-digit scan -> stable scatter.  Stability inside
+// a workgroup comes from wave64 ballot matching: for every key the set of lanes
+// holding the same digit is built from one __ballot per digit bit, and a key's
+// rank among equal digits is the population count of that set below its lane.
+//
+// Compiled with -ffp-contract=off (the quantisation is f32 arithmetic that
+// must match the reference bit for bit).
+#include "gsr_internal.h"
+
+namespace gsr {
+
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_WAVES = SORT_THREADS / WAVE;
+
+__device__ __forceinline__ uint32_t lanes_below(uint64_t mask)
+{
+    // number of set bits of `mask` in lanes lower than this one (v_mbcnt)
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// Lanes of this wave whose `digit` equals mine (lanes with valid == false match nobody).
+template <int BITS>
+__device__ __forceinline__ uint64_t match_digit(uint32_t digit, bool valid)
+{
+    uint64_t m = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < BITS; b++) {
+        const bool bit = (digit >> b) & 1u;
+        const uint64_t bal = __ballot(bit);
+        m &= bit ? bal : ~bal;
+    }
+    return valid ? m : 0ull;
+}
+
+// ---------------------------------------------------------------------------
+// A2: q = (uint32)((float)(uint32)(depth - minDepth) * depthInv), plus the
+// workgroup histogram of the pass-1 digit (and, through atomics, the global
+// digit totals of both passes).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(SORT_THREADS) void k_quantise_hist(const int32_t* __restrict__ depth,
+                                                                const int32_t* __restrict__ minmax, uint32_t n,
+                                                                uint32_t keys_per_block, uint32_t* __restrict__ keys,
+                                                                uint32_t* __restrict__ block_hist,
+                                                                uint32_t* __restrict__ digit_total)
+{
+    __shared__ uint32_t h_lo[RADIX_LO_BINS];
+    __shared__ uint32_t h_hi[RADIX_HI_BINS];
+    for (int d = threadIdx.x; d < RADIX_HI_BINS; d += SORT_THREADS) {
+        h_hi[d] = 0;
+        if (d < RADIX_LO_BINS) h_lo[d] = 0;
+    }
+    __syncthreads();
+
+    const int32_t minDepth = minmax[0], maxDepth = minmax[1];
+    const bool degenerate = (maxDepth == minDepth);
+    // wasm.cpp:34: (float)depthRange / (maxDepth - minDepth): int subtract, int->f32 RNE, f32 divide RNE
+    const float depthInv = degenerate ? 0.0f : (float)DEPTH_RANGE / (float)(maxDepth - minDepth);
+
+    const uint32_t begin = blockIdx.x * keys_per_block;
+    const uint32_t end = min(begin + keys_per_block, n);
+    for (uint32_t i = begin + threadIdx.x; i < end; i += SORT_THREADS) {
+        // wasm.cpp:38: u32 wrap-around subtract, u32->f32 RNE, f32 multiply, truncate
+        const uint32_t rel = (uint32_t)depth[i] - (uint32_t)minDepth;
+        uint32_t q = degenerate ? 0u : (uint32_t)((float)rel * depthInv);
+        q = min(q, DEPTH_RANGE);
+        keys[i] = q;
+        atomicAdd(&h_lo[q & (RADIX_LO_BINS - 1)], 1u);
+        atomicAdd(&h_hi[q >> RADIX_LO_BITS], 1u);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < RADIX_HI_BINS; d += SORT_THREADS) {
+        if (d < RADIX_LO_BINS) {
+            const uint32_t c = h_lo[d];
+            block_hist[(size_t)blockIdx.x * RADIX_LO_BINS + d] = c;
+            if (c) atomicAdd(&digit_total[d], c);
+        }
+        const uint32_t c2 = h_hi[d];
+        if (c2) atomicAdd(&digit_total[RADIX_LO_BINS + d], c2);
+    }
+}
+
+// Workgroup histogram of the pass-2 digit over the pass-1 output order.
+__global__ __launch_bounds__(SORT_THREADS) void k_hist_hi(const uint32_t* __restrict__ keys, uint32_t n,
+                                                          uint32_t keys_per_block, uint32_t* __restrict__ block_hist)
+{
+    __shared__ uint32_t h[RADIX_HI_BINS];
+    for (int d = threadIdx.x; d < RADIX_HI_BINS; d += SORT_THREADS) h[d] = 0;
+    __syncthreads();
+    const uint32_t begin = blockIdx.x * keys_per_block;
+    const uint32_t end = min(begin + keys_per_block, n);
+    for (uint32_t i = begin + threadIdx.x; i < end; i += SORT_THREADS) atomicAdd(&h[keys[i] >> RADIX_LO_BITS], 1u);
+    __syncthreads();
+    for (int d = threadIdx.x; d < RADIX_HI_BINS; d += SORT_THREADS) block_hist[(size_t)blockIdx.x * RADIX_HI_BINS + d] = h[d];
+}
+
+// ---------------------------------------------------------------------------
+// One wave per digit d: base[b][d] = sum(total[d'] for d' < d) + sum(hist[b'][d] for b' < b).
+// In place over block_hist (block-major so the histogram and scatter kernels
+// touch it coalesced; this small kernel takes the strided accesses).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(SORT_THREADS) void k_digit_scan(uint32_t* __restrict__ block_hist,
+                                                             const uint32_t* __restrict__ total, int nbins,
+                                                             uint32_t nblocks)
+{
+    const int lane = threadIdx.x & 63;
+    const int d = blockIdx.x * SORT_WAVES + (threadIdx.x >> 6);
+    if (d >= nbins) return;
+    uint32_t acc = 0;
+    for (int j = lane; j < d; j += WAVE) acc += total[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    uint32_t run = acc;  // exclusive prefix over all smaller digits
+    for (uint32_t b0 = 0; b0 < nblocks; b0 += WAVE) {
+        const uint32_t b = b0 + lane;
+        const uint32_t v = (b < nblocks) ? block_hist[(size_t)b * nbins + d] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (b < nblocks) block_hist[(size_t)b * nbins + d] = run + incl - v;
+        run += __shfl(incl, WAVE - 1);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Stable scatter of one pass.  Workgroup = 4 waves over keys_per_block keys;
+// wave w owns the w-th quarter (contiguous), walked in 64-key steps, so the
+// order of equal digits is: workgroup, then wave, then step, then lane = input
+// order.  Phase 1 counts per wave, phase 2 turns the counts into running
+// destinations, phase 3 ranks with ballot matching and scatters.
+// ---------------------------------------------------------------------------
+template <int BITS, int SHIFT, bool FIRST>
+__global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint32_t* __restrict__ keys_in,
+                                                          const uint32_t* __restrict__ idx_in, uint32_t n,
+                                                          uint32_t keys_per_block, const uint32_t* __restrict__ base,
+                                                          uint32_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out)
+{
+    constexpr int BINS = 1 << BITS;
+    __shared__ uint32_t cnt[SORT_WAVES][BINS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int d = threadIdx.x; d < SORT_WAVES * BINS; d += SORT_THREADS) (&cnt[0][0])[d] = 0;
+    __syncthreads();
+
+    const uint32_t per_wave = keys_per_block / SORT_WAVES;  // multiple of 64
+    const uint32_t wbegin = blockIdx.x * keys_per_block + wave * per_wave;
+    const uint32_t wend = min(wbegin + per_wave, n);
+
+    // phase 1: per-wave digit counts
+    for (uint32_t i0 = wbegin; i0 < wend; i0 += WAVE) {
+        const uint32_t i = i0 + lane;
+        if (i < wend) atomicAdd(&cnt[wave][(keys_in[i] >> SHIFT) & (BINS - 1)], 1u);
+    }
+    __syncthreads();
+    // phase 2: cnt[w][d] <- global base of digit d for this workgroup + counts of earlier waves
+    for (int d = threadIdx.x; d < BINS; d += SORT_THREADS) {
+        uint32_t run = base[(size_t)blockIdx.x * BINS + d];
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; w++) {
+            const uint32_t c = cnt[w][d];
+            cnt[w][d] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    // phase 3: rank + scatter (cnt[wave][*] is private to this wave from here on)
+    for (uint32_t i0 = wbegin; i0 < wend; i0 += WAVE) {
+        const uint32_t i = i0 + lane;
+        const bool valid = i < wend;
+        const uint32_t key = valid ? keys_in[i] : 0u;
+        const uint32_t digit = (key >> SHIFT) & (BINS - 1);
+        const uint64_t m = match_digit<BITS>(digit, valid);
+        const uint32_t rank = lanes_below(m);
+        // All lanes read their digit's running destination, THEN the lowest lane of every
+        // group of equal digits advances it.  One wave, LDS is in order; the volatile
+        // accesses and wave barriers keep the compiler from sinking the read below the write.
+        volatile uint32_t* wc = cnt[wave];
+        const uint32_t start = wc[digit];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == 0) wc[digit] = start + (uint32_t)__popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            const uint32_t dst = start + rank;
+            if (keys_out) keys_out[dst] = key;
+            idx_out[dst] = FIRST ? i : idx_in[i];
+        }
+    }
+}
+
+void launch_sort(const SortBuffers& b, uint32_t n, hipStream_t s)
+{
+    if (!n) return;
+    const dim3 grid(b.nblocks), block(SORT_THREADS);
+    hipLaunchKernelGGL(k_quantise_hist, grid, block, 0, s, b.depth, b.minmax, n, b.keys_per_block, b.keys, b.block_hist,
+                       b.digit_total);
+    hipLaunchKernelGGL(k_digit_scan, dim3(RADIX_LO_BINS / SORT_WAVES), block, 0, s, b.block_hist, b.digit_total,
+                       RADIX_LO_BINS, b.nblocks);
+    hipLaunchKernelGGL((k_scatter<RADIX_LO_BITS, 0, true>), grid, block, 0, s, (const uint32_t*)b.keys,
+                       (const uint32_t*)nullptr, n, b.keys_per_block, (const uint32_t*)b.block_hist, b.keys_tmp, b.idx_tmp);
+    hipLaunchKernelGGL(k_hist_hi, grid, block, 0, s, (const uint32_t*)b.keys_tmp, n, b.keys_per_block, b.block_hist);
+    hipLaunchKernelGGL(k_digit_scan, dim3(RADIX_HI_BINS / SORT_WAVES), block, 0, s, b.block_hist,
+                       b.digit_total + RADIX_LO_BINS, RADIX_HI_BINS, b.nblocks);
+    hipLaunchKernelGGL((k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, false>), grid, block, 0, s, (const uint32_t*)b.keys_tmp,
+                       (const uint32_t*)b.idx_tmp, n, b.keys_per_block, (const uint32_t*)b.block_hist,
+                       (uint32_t*)nullptr, b.depth_index);
+}
+
+}  // namespace gsr

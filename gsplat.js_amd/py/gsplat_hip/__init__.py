@@ -1,0 +1,318 @@
+"""Python (ctypes) host harness over the C ABI of libgsplat_hip.so.
+
+This is plumbing for the tests and bench.py: it mirrors the reference's
+interface for the hot path -- `Scene.setData`, `Camera.update`,
+`renderer.render(scene, camera)` (src/core/Scene.ts:58-180,
+src/cameras/Camera.ts:81-92, src/renderers/WebGLRenderer.ts:241-296) -- and
+calls the HIP library for everything the GPU does.  There is no CPU fallback:
+if the library or a GPU is missing, construction raises.
+The Node/JavaScript host (the reference's own language) lives in ../../js.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from .camera import Camera, orbit_camera, orbit_pose  # noqa: F401
+from . import synth  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libgsplat_hip.so"))
+
+GSR_FLAG_TIMING = 1
+
+
+class GsrOptions(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int32), ("width", ctypes.c_int32), ("height", ctypes.c_int32),
+                ("early_out_eps", ctypes.c_float), ("band_x0", ctypes.c_int32), ("band_x1", ctypes.c_int32),
+                ("flags", ctypes.c_int32)]
+
+
+class GsrTimings(ctypes.Structure):
+    _fields_ = [("ms_project_key", ctypes.c_float), ("ms_sort", ctypes.c_float), ("ms_bin", ctypes.c_float),
+                ("ms_blend", ctypes.c_float), ("ms_total", ctypes.c_float), ("visible", ctypes.c_uint64),
+                ("bin_entries", ctypes.c_uint64), ("n", ctypes.c_uint32), ("frames", ctypes.c_uint32),
+                ("sum_ms_project_key", ctypes.c_double), ("sum_ms_sort", ctypes.c_double),
+                ("sum_ms_bin", ctypes.c_double), ("sum_ms_blend", ctypes.c_double), ("sum_ms_total", ctypes.c_double)]
+
+
+class GsplatError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# every symbol include/gsplat_hip.h declares
+EXPORTS = [
+    "gsr_create", "gsr_destroy", "gsr_last_error", "gsr_set_scene", "gsr_resize", "gsr_set_band", "gsr_set_camera",
+    "gsr_sort", "gsr_render", "gsr_render_async", "gsr_sync", "gsr_read_depth_index", "gsr_read_pixels_rgba32f",
+    "gsr_read_pixels_rgba8", "gsr_get_timings", "gsr_reset_timings", "gsr_read_keys", "gsr_read_records",
+    "gsr_framebuffer_device_ptr", "gsr_stream_handle", "gsr_device_info", "gsplat_sort_host",
+]
+
+
+def load_library(path=None):
+    """Load libgsplat_hip.so and declare its prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise GsplatError("libgsplat_hip.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`" % p)
+    L = ctypes.CDLL(p)
+    vp = ctypes.c_void_p
+    L.gsr_create.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(GsrOptions)]
+    L.gsr_destroy.argtypes = [vp]
+    L.gsr_last_error.argtypes = [vp]
+    L.gsr_last_error.restype = ctypes.c_char_p
+    L.gsr_set_scene.argtypes = [vp, vp, vp, ctypes.c_uint32]
+    L.gsr_resize.argtypes = [vp, ctypes.c_int32, ctypes.c_int32]
+    L.gsr_set_band.argtypes = [vp, ctypes.c_int32, ctypes.c_int32]
+    L.gsr_set_camera.argtypes = [vp, vp, vp, vp, ctypes.c_float, ctypes.c_float]
+    for name in ("gsr_sort", "gsr_render", "gsr_render_async", "gsr_sync", "gsr_reset_timings"):
+        getattr(L, name).argtypes = [vp]
+    L.gsr_read_depth_index.argtypes = [vp, vp]
+    L.gsr_read_pixels_rgba32f.argtypes = [vp, vp]
+    L.gsr_read_pixels_rgba8.argtypes = [vp, vp]
+    L.gsr_get_timings.argtypes = [vp, ctypes.POINTER(GsrTimings)]
+    L.gsr_read_keys.argtypes = [vp, vp, vp]
+    L.gsr_read_records.argtypes = [vp, vp, vp]
+    L.gsr_framebuffer_device_ptr.argtypes = [vp]
+    L.gsr_framebuffer_device_ptr.restype = vp
+    L.gsr_stream_handle.argtypes = [vp]
+    L.gsr_stream_handle.restype = vp
+    L.gsr_device_info.argtypes = [vp, ctypes.c_char_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
+                                  ctypes.POINTER(ctypes.c_int32)]
+    L.gsplat_sort_host.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, vp]
+    L.gsplat_sort_host.restype = None
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if fn.restype is ctypes.c_int and name not in ("gsplat_sort_host",):
+            fn.restype = ctypes.c_int
+    if path is None:
+        _lib = L
+    return L
+
+
+# ---------------------------------------------------------------------------
+# Scene: mirror of src/core/Scene.ts (setData only: the producer of the buffers
+# the hot path consumes), vectorised in numpy float64 = JS number arithmetic.
+# ---------------------------------------------------------------------------
+def _float_to_half(x64):
+    """src/utils.ts:16-43 (truncating; JS `>>` shift count taken modulo 32)."""
+    f = np.asarray(x64, dtype=np.float64).astype(np.float32).view(np.int32).astype(np.int64)
+    sign = (f >> 31) & 1
+    exp = (f >> 23) & 0xFF
+    frac = f & 0x007FFFFF
+    sub = (exp > 0) & (exp < 113)
+    shift = np.where(sub, (113 - exp) & 31, 0)
+    frac_sub = (frac | 0x00800000) >> shift
+    carry = sub & ((frac_sub & 0x01000000) != 0)
+    new_exp = np.where(exp == 0, 0, np.where(exp < 113, 0, np.where(exp < 142, exp - 112, 31)))
+    new_exp = np.where(carry, 1, new_exp)
+    frac_out = np.where(sub, frac_sub, frac)
+    frac_out = np.where(carry | (exp >= 142), 0, frac_out)
+    return ((sign << 15) | (new_exp << 10) | (frac_out >> 13)).astype(np.uint32)
+
+
+def pack_half2x16(x, y):
+    """src/utils.ts:46-48."""
+    return (_float_to_half(x) | (_float_to_half(y) << np.uint32(16))).astype(np.uint32)
+
+
+class Scene:
+    RowLength = 32  # src/core/Scene.ts:9
+
+    def __init__(self):
+        self._listeners = {}
+        self.data = np.zeros(0, dtype=np.uint32)
+        self.positions = np.zeros(0, dtype=np.float32)
+        self.vertexCount = 0
+        self.width = 2048
+        self.height = 0
+
+    # EventDispatcher surface used by the renderer (src/core/EventDispatcher.ts)
+    def addEventListener(self, kind, fn):
+        self._listeners.setdefault(kind, []).append(fn)
+
+    def removeEventListener(self, kind, fn):
+        if fn in self._listeners.get(kind, []):
+            self._listeners[kind].remove(fn)
+
+    def dispatchEvent(self, kind):
+        for fn in list(self._listeners.get(kind, [])):
+            fn({"type": kind})
+
+    def setData(self, rows):
+        """Scene.ts:58-180 without the SH branch."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint8).reshape(-1)
+        if rows.size % self.RowLength:
+            raise ValueError("data length must be a multiple of %d" % self.RowLength)
+        n = rows.size // self.RowLength
+        self.vertexCount = n
+        self.height = -(-(2 * n) // self.width)
+        r = rows.reshape(n, 32)
+        f = r[:, :24].copy().view(np.float32).reshape(n, 6)
+        self.positions = f[:, 0:3].copy().reshape(-1)
+        data = np.zeros((self.width * self.height * 4) if n else 0, dtype=np.uint32)
+        d = data[:8 * n].reshape(n, 8)
+        d[:, 0:3] = f[:, 0:3].copy().view(np.uint32)
+        d[:, 7] = r[:, 24:28].copy().view(np.uint32).reshape(n)
+        rot = (r[:, 28:32].astype(np.float64) - 128.0) / 128.0
+        qx, qy, qz, qw = rot[:, 1], rot[:, 2], rot[:, 3], -rot[:, 0]
+        R = [1 - 2 * qy * qy - 2 * qz * qz, 2 * qx * qy - 2 * qz * qw, 2 * qx * qz + 2 * qy * qw,
+             2 * qx * qy + 2 * qz * qw, 1 - 2 * qx * qx - 2 * qz * qz, 2 * qy * qz - 2 * qx * qw,
+             2 * qx * qz - 2 * qy * qw, 2 * qy * qz + 2 * qx * qw, 1 - 2 * qx * qx - 2 * qy * qy]
+        s = f[:, 3:6].astype(np.float64)
+        z = np.zeros(n)
+        a = [s[:, 0], z, z, z, s[:, 1], z, z, z, s[:, 2]]
+        b = R
+        M = [b[0] * a[0] + b[3] * a[1] + b[6] * a[2], b[1] * a[0] + b[4] * a[1] + b[7] * a[2], b[2] * a[0] + b[5] * a[1] + b[8] * a[2],
+             b[0] * a[3] + b[3] * a[4] + b[6] * a[5], b[1] * a[3] + b[4] * a[4] + b[7] * a[5], b[2] * a[3] + b[5] * a[4] + b[8] * a[5],
+             b[0] * a[6] + b[3] * a[7] + b[6] * a[8], b[1] * a[6] + b[4] * a[7] + b[7] * a[8], b[2] * a[6] + b[5] * a[7] + b[8] * a[8]]
+        sg = [M[0] * M[0] + M[3] * M[3] + M[6] * M[6], M[0] * M[1] + M[3] * M[4] + M[6] * M[7],
+              M[0] * M[2] + M[3] * M[5] + M[6] * M[8], M[1] * M[1] + M[4] * M[4] + M[7] * M[7],
+              M[1] * M[2] + M[4] * M[5] + M[7] * M[8], M[2] * M[2] + M[5] * M[5] + M[8] * M[8]]
+        d[:, 4] = pack_half2x16(4 * sg[0], 4 * sg[1])
+        d[:, 5] = pack_half2x16(4 * sg[2], 4 * sg[3])
+        d[:, 6] = pack_half2x16(4 * sg[4], 4 * sg[5])
+        self.data = data
+        self.dispatchEvent("change")
+
+
+# ---------------------------------------------------------------------------
+# HIPRenderer: the drop-in for WebGLRenderer's render path
+# ---------------------------------------------------------------------------
+class HIPRenderer:
+    """renderer.render(scene, camera) on an MI355X (WebGLRenderer.ts:241-296)."""
+
+    def __init__(self, width=1920, height=1080, device=0, early_out_eps=0.0, band=None, timing=False, lib_path=None):
+        self._L = load_library(lib_path)
+        self._ctx = ctypes.c_void_p()
+        opt = GsrOptions(device, width, height, early_out_eps, band[0] if band else 0, band[1] if band else 0,
+                         GSR_FLAG_TIMING if timing else 0)
+        rc = self._L.gsr_create(ctypes.byref(self._ctx), ctypes.byref(opt))
+        if rc:
+            raise GsplatError("gsr_create failed (%d): %s" % (rc, self._L.gsr_last_error(None).decode()))
+        self.width, self.height = width, height
+        self._scene = None
+        self._camera = None
+        self._n = 0
+        self._on_change = lambda _e: self._upload(self._scene)
+
+    # -- helpers --
+    def _check(self, rc):
+        if rc:
+            raise GsplatError("libgsplat_hip error %d: %s" % (rc, self._L.gsr_last_error(self._ctx).decode()))
+
+    def _upload(self, scene):
+        data = np.ascontiguousarray(scene.data, dtype=np.uint32)
+        pos = np.ascontiguousarray(scene.positions, dtype=np.float32)
+        self._check(self._L.gsr_set_scene(self._ctx, data.ctypes.data, pos.ctypes.data, scene.vertexCount))
+        self._n = scene.vertexCount
+
+    # -- reference surface --
+    def setSize(self, width, height):
+        self._check(self._L.gsr_resize(self._ctx, width, height))
+        self.width, self.height = width, height
+
+    def set_band(self, x0, x1):
+        self._check(self._L.gsr_set_band(self._ctx, x0, x1))
+
+    def set_raw_scene(self, data, positions):
+        """Upload Scene.data / Scene.positions arrays directly (no Scene object)."""
+        data = np.ascontiguousarray(data, dtype=np.uint32)
+        pos = np.ascontiguousarray(positions, dtype=np.float32)
+        n = pos.size // 3
+        self._check(self._L.gsr_set_scene(self._ctx, data.ctypes.data, pos.ctypes.data, n))
+        self._n = n
+        self._scene = None
+
+    def set_camera(self, camera):
+        camera.update(self.width, self.height)
+        v, p, vp = camera.f32()
+        self._check(self._L.gsr_set_camera(self._ctx, v.ctypes.data, p.ctypes.data, vp.ctypes.data, camera.fx, camera.fy))
+        self._camera = camera
+
+    def render(self, scene, camera, sync=True):
+        if scene is not None and scene is not self._scene:
+            if self._scene is not None:
+                self._scene.removeEventListener("change", self._on_change)
+            self._scene = scene
+            scene.addEventListener("change", self._on_change)
+            self._upload(scene)
+        self.set_camera(camera)
+        self._check(self._L.gsr_render(self._ctx) if sync else self._L.gsr_render_async(self._ctx))
+
+    def render_async(self):
+        self._check(self._L.gsr_render_async(self._ctx))
+
+    def sync(self):
+        self._check(self._L.gsr_sync(self._ctx))
+
+    def sort(self, camera=None):
+        if camera is not None:
+            self.set_camera(camera)
+        self._check(self._L.gsr_sort(self._ctx))
+
+    def dispose(self):
+        if self._ctx:
+            self._L.gsr_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.dispose()
+        except Exception:
+            pass
+
+    # -- results --
+    def lastDepthIndex(self):
+        out = np.empty(self._n, dtype=np.uint32)
+        self._check(self._L.gsr_read_depth_index(self._ctx, out.ctypes.data))
+        return out
+
+    def readPixelsFloat(self):
+        out = np.empty((self.height, self.width, 4), dtype=np.float32)
+        self._check(self._L.gsr_read_pixels_rgba32f(self._ctx, out.ctypes.data))
+        return out
+
+    def readPixels(self):
+        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        self._check(self._L.gsr_read_pixels_rgba8(self._ctx, out.ctypes.data))
+        return out
+
+    def read_keys(self):
+        keys = np.empty(self._n, dtype=np.uint32)
+        mm = np.zeros(2, dtype=np.int32)
+        self._check(self._L.gsr_read_keys(self._ctx, keys.ctypes.data, mm.ctypes.data))
+        return keys, (int(mm[0]), int(mm[1]))
+
+    def read_records(self):
+        rec = np.empty((self._n, 8), dtype=np.float32)
+        bbox = np.empty((self._n, 4), dtype=np.int32)
+        self._check(self._L.gsr_read_records(self._ctx, rec.ctypes.data, bbox.ctypes.data))
+        return rec, bbox
+
+    def stats(self):
+        t = GsrTimings()
+        self._check(self._L.gsr_get_timings(self._ctx, ctypes.byref(t)))
+        return {k: getattr(t, k) for k, _ in GsrTimings._fields_}
+
+    def reset_stats(self):
+        self._check(self._L.gsr_reset_timings(self._ctx))
+
+    def device_info(self):
+        name = ctypes.create_string_buffer(256)
+        cus, clk = ctypes.c_int32(0), ctypes.c_int32(0)
+        self._check(self._L.gsr_device_info(self._ctx, name, 256, ctypes.byref(cus), ctypes.byref(clk)))
+        return {"name": name.value.decode(), "compute_units": cus.value, "clock_khz": clk.value}
+
+    def framebuffer_ptr(self):
+        return self._L.gsr_framebuffer_device_ptr(self._ctx)
+
+    def stream_handle(self):
+        return self._L.gsr_stream_handle(self._ctx)
+
+
+WebGLRenderer = HIPRenderer  # the name callers of the reference use (src/index.ts:5)

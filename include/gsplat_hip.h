@@ -1,0 +1,122 @@
+/*
+ * gsplat_hip.h -- C ABI of libgsplat_hip.so, the MI355X-native drop-in for the
+ * per-frame hot path of Lanv1/gsplat.js (sort + project + composite).
+ *
+ * Plain C: opaque context, plain pointers and sizes, int return codes
+ * (0 = ok, <0 = error, text via gsr_last_error).  No function throws, aborts
+ * or keeps a caller's pointer after it returns (inputs are copied to the
+ * device during the call).  A context is bound to one host thread at a time;
+ * distinct contexts are independent.
+ *
+ * Reference interfaces replaced (paths relative to the reference tree):
+ *   wasm `sort(...)`                 wasm/wasm.cpp:8-13, called at
+ *                                    src/renderers/webgl/utils/Worker.ts:39
+ *                                      -> gsplat_sort_host (same 7 arguments) / gsr_sort
+ *   worker scene init                Worker.ts:23-34 (positions copied once per scene)
+ *   + texImage2D(scene.data)         src/renderers/WebGLRenderer.ts:185-195
+ *                                      -> gsr_set_scene
+ *   uniforms projection/view/focal/viewport + postMessage({viewProj})
+ *                                    WebGLRenderer.ts:144-159,268-269,275
+ *                                      -> gsr_set_camera, gsr_resize
+ *   drawArraysInstanced + blend state WebGLRenderer.ts:279-290 with
+ *   vertex.glsl.ts:130-231, frag.glsl.ts:13-21
+ *                                      -> gsr_render
+ *   worker.onmessage depthIndex      WebGLRenderer.ts:223-229
+ *                                      -> gsr_read_depth_index
+ */
+#ifndef GSPLAT_HIP_H
+#define GSPLAT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_OK 0
+#define GSR_ERR_ARG (-1)      /* bad argument / call order */
+#define GSR_ERR_HIP (-2)      /* a HIP runtime call failed */
+#define GSR_ERR_NO_DEVICE (-3)/* no usable AMD GPU */
+#define GSR_ERR_SCENE (-4)    /* scene buffers inconsistent */
+#define GSR_ERR_OVERFLOW (-5) /* internal list capacity exceeded even after regrowth */
+
+typedef struct gsr_ctx gsr_ctx;
+
+typedef struct gsr_options {
+    int32_t device;         /* HIP device ordinal */
+    int32_t width, height;  /* framebuffer size in pixels (canvas.width/height) */
+    float early_out_eps;    /* 0: composite every splat like the reference (no early
+                               termination); >0: a 16x16 tile stops once every pixel's
+                               remaining transmittance 1-alpha is below this value */
+    int32_t band_x0, band_x1; /* multi-GPU: this context composites only pixel columns
+                               [band_x0, band_x1) (multiples of 64); 0,0 = whole image */
+    int32_t flags;          /* GSR_FLAG_* */
+} gsr_options;
+
+#define GSR_FLAG_TIMING 1   /* record HIP events around every stage (gsr_get_timings) */
+
+/* Per-stage device times of the last completed gsr_render / gsr_sort, measured
+ * with HIP events on the context's stream, plus the frame's list sizes. */
+typedef struct gsr_timings {
+    float ms_project_key; /* projection + depth key + min/max            */
+    float ms_sort;        /* quantise + 2 radix passes -> depthIndex      */
+    float ms_bin;         /* coarse bin count/scan/scatter                */
+    float ms_blend;       /* tile composite (the dominant kernel)         */
+    float ms_total;       /* first event -> last event                    */
+    uint64_t visible;     /* V: splats with a non-empty screen bbox (within the band) */
+    uint64_t bin_entries; /* entries in the coarse bin lists              */
+    uint32_t n;           /* splats                                       */
+    uint32_t frames;      /* frames accumulated in the sums below         */
+    double sum_ms_project_key, sum_ms_sort, sum_ms_bin, sum_ms_blend, sum_ms_total;
+} gsr_timings;
+
+/* ---- lifetime ---- */
+int gsr_create(gsr_ctx **out, const gsr_options *opt);
+int gsr_destroy(gsr_ctx *ctx);
+const char *gsr_last_error(gsr_ctx *ctx); /* ctx may be NULL: error of the failed gsr_create */
+
+/* ---- per scene ---- */
+/* data: Scene.data layout, 8 u32 per splat (src/core/Scene.ts:141-148,174-176);
+ * positions: Scene.positions, 3 f32 per splat, must equal data words 0..2.
+ * Repacked once into SoA on the device. */
+int gsr_set_scene(gsr_ctx *ctx, const uint32_t *data, const float *positions, uint32_t n);
+
+/* ---- per resize / per frame ---- */
+int gsr_resize(gsr_ctx *ctx, int32_t width, int32_t height);
+int gsr_set_band(gsr_ctx *ctx, int32_t x0, int32_t x1);
+/* view, proj, view_proj: column-major f32[16] exactly as `new Float32Array(m.buffer)`
+ * of Camera.viewMatrix / projectionMatrix / viewProj (src/cameras/Camera.ts:81-92). */
+int gsr_set_camera(gsr_ctx *ctx, const float *view, const float *proj, const float *view_proj, float fx, float fy);
+
+int gsr_sort(gsr_ctx *ctx);         /* depth key + sort only (blocking)                    */
+int gsr_render(gsr_ctx *ctx);       /* sort + project + bin + composite (blocking)         */
+int gsr_render_async(gsr_ctx *ctx); /* enqueue one frame on the context's stream           */
+int gsr_sync(gsr_ctx *ctx);         /* wait for the stream; reports deferred errors        */
+
+/* ---- results ---- */
+int gsr_read_depth_index(gsr_ctx *ctx, uint32_t *out /* n */);
+int gsr_read_pixels_rgba32f(gsr_ctx *ctx, float *out /* w*h*4, premultiplied, row 0 = top */);
+int gsr_read_pixels_rgba8(gsr_ctx *ctx, uint8_t *out /* w*h*4, round(clamp(x,0,1)*255)   */);
+int gsr_get_timings(gsr_ctx *ctx, gsr_timings *out);
+int gsr_reset_timings(gsr_ctx *ctx);
+
+/* ---- parity/debug read-backs (intermediate device buffers of the last frame) ---- */
+int gsr_read_keys(gsr_ctx *ctx, uint32_t *keys /* n, 17-bit */, int32_t *minmax /* 2 */);
+int gsr_read_records(gsr_ctx *ctx, float *rec /* 8n */, int32_t *bbox /* 4n: x0,y0,x1,y1 */);
+
+/* ---- device interop (torch / RCCL plumbing in the harness) ---- */
+void *gsr_framebuffer_device_ptr(gsr_ctx *ctx); /* float4[h][w] on the device */
+void *gsr_stream_handle(gsr_ctx *ctx);          /* hipStream_t */
+int gsr_device_info(gsr_ctx *ctx, char *name, int32_t name_len, int32_t *compute_units, int32_t *clock_khz);
+
+/* ---- drop-in for the wasm export, same argument list as wasm/wasm.cpp:8-13.
+ * Host pointers; depthBuffer/starts/counts may be NULL (depthBuffer, when given,
+ * receives the 17-bit keys like the reference leaves them).  Uses a process-wide
+ * context on device 0; returns nothing, like the reference. */
+void gsplat_sort_host(const float *viewProj, uint32_t vertexCount, const float *fBuffer, uint32_t *depthBuffer,
+                      uint32_t *depthIndex, uint32_t *starts, uint32_t *counts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -377,7 +377,8 @@ void orc_tile_stats(const int32_t *bbox, uint32_t n, int tile, uint64_t *V, uint
  * mode 0 "ideal":    vPosition solved in f64 from the f32 varyings (raw),
  *                    window coordinates, coverage |vPosition|^2 <= 4.
  * mode 1 "restated": vPosition from the f32 record with the exact f32
- *                    expression the HIP kernel uses, so the discard decision
+ *                    expression the HIP kernel uses (explicit fmaf = v_fma_f32,
+ *                    everything else unfused), so the discard decision
  *                    (A < -4) is bit-identical; weight and sums in f64.
  * out: W*H*4 floats, premultiplied RGBA, row 0 = top.
  * y_begin/y_end restrict rows (lets callers thread over row bands).
@@ -415,9 +416,9 @@ void orc_render(uint32_t n, const uint32_t *depth_index, const float *raw, const
                 } else {
                     float dx = ((float)x + 0.5f) - rc[0];
                     float dy = ((float)y + 0.5f) - rc[1];
-                    float vx = rc[2] * dx + rc[3] * dy;
-                    float vy = rc[4] * dx + rc[5] * dy;
-                    float q = vx * vx + vy * vy;
+                    float vx = fmaf(rc[2], dx, rc[3] * dy);
+                    float vy = fmaf(rc[4], dx, rc[5] * dy);
+                    float q = fmaf(vy, vy, vx * vx);
                     if (q > 4.0f) continue;
                     B = exp(-(double)q) * opacity;
                 }
