@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/sec (and sorted-splats/sec) of the gsplat.js hot path
+-- depth key + sort + projection + binning + front-to-back composite -- on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W        (N=1: plain process; N>1: torch.distributed.run)
+
+A step is one full frame (renderer.render(scene, camera)) at the next pose of a
+120-frame orbit.  Workload at every N: BASELINE.json configs[2] = C3, 1M synthetic
+gaussians at 1920x1080 (scene bytes resident in HBM before the timed region).
+N>1 splits ONE frame across ranks by screen-tile columns and all-gathers the
+framebuffer over RCCL: fixed total work, so `scaling` is "strong".
+Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "gsplat.js_amd", "py"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ORBIT_FRAMES = 120
+
+
+class _DevArray:
+    """Expose a raw device pointer to torch (zero copy) through __cuda_array_interface__."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+def cpu_baseline(gh, cfg, data, pos, sample_frames=2, sort_calls=10):
+    """The reference's CPU path timed on this host.  Sort: the reference's own wasm/wasm.cpp compiled
+    natively (oracle/_ref) when present, else the bit-identical restatement; 1 thread like the
+    reference's single worker.  Project + composite have no CPU implementation in the reference
+    (they run in WebGL): the oracle's restatement stands in, on `cores` threads."""
+    from oracle import oracle as O
+    cores = min(os.cpu_count() or 1, 16)
+    cams = [gh.orbit_camera(k * 7, ORBIT_FRAMES, cfg["width"], cfg["height"], cfg["fx"]) for k in range(max(sort_calls, sample_frames))]
+    use_ref = O.ref_available()
+    t_sort = []
+    for cam in cams[:sort_calls]:
+        vp = cam.f32()[2]
+        t0 = time.perf_counter()
+        if use_ref:
+            O.ref_sort(vp, pos, calls=1)  # two reference calls inside (count + sort): halve below
+        else:
+            O.sort(vp, pos)
+        t_sort.append((time.perf_counter() - t0) / (2.0 if use_ref else 1.0))
+    t_sort = float(np.median(t_sort))
+    t_frame = []
+    for cam in cams[:sample_frames]:
+        v, p, vp = cam.f32()
+        t0 = time.perf_counter()
+        di, _, _ = O.sort(vp, pos)
+        rec, bbox, raw = O.project(data, v, p, cfg["fx"], cfg["fx"], cfg["width"], cfg["height"])
+        O.render(di, raw, rec, bbox, cfg["width"], cfg["height"], 1, cores)
+        t_frame.append(time.perf_counter() - t0)
+    t_frame = float(np.mean(t_frame))
+    n = pos.size // 3
+    return {
+        "value": 1.0 / t_frame, "unit": "frames/s", "cores": cores, "kind": "port",
+        "sample": "%d full frames of the same 1M-splat 1080p workload (sort 1 thread + project 1 thread + composite on %d threads)"
+                  % (sample_frames, cores),
+        "sort_splats_per_s": n / t_sort, "sort_ms": t_sort * 1e3, "sort_cores": 1,
+        "sort_kind": "reference" if use_ref else "port",
+        "sort_sample": "%d sorts of the 1M-splat scene, median" % sort_calls,
+        "frame_ms": t_frame * 1e3,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=240)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="C3")
+    ap.add_argument("--early-out-eps", type=float, default=0.0,
+                    help="0 = composite every splat like the reference (default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import torch
+    import gsplat_hip as gh
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = gh.synth.CONFIGS[args.config]
+    W, H, N = cfg["width"], cfg["height"], cfg["n"]
+    rows = gh.synth.config_rows(args.config)
+    scene = gh.Scene()
+    scene.setData(rows)
+
+    # tile-column bands: whole 32-px bins per rank, last band may be narrower
+    from gsplat_hip import bands
+    x0, x1 = bands.band_edges(W, world)[rank]
+    band = (x0, x1) if world > 1 else None
+    r = gh.HIPRenderer(W, H, device=local_rank, early_out_eps=args.early_out_eps, band=band if (band and x1 > x0) else None,
+                       timing=True)
+    r.render(scene, gh.orbit_camera(0, ORBIT_FRAMES, W, H, cfg["fx"]))  # uploads the scene, first frame
+
+    fb = xchg = None
+    if world > 1:
+        fb = torch.as_tensor(_DevArray(r.framebuffer_ptr(), (H, W, 4)), device="cuda:%d" % local_rank)
+        xchg = bands.FrameExchange(dist, torch, W, H, rank, world, fb.device)
+
+    # Camera.update for the 120 poses is host JS/Python f64 work outside the device path: precomputed
+    poses = [gh.orbit_camera(k, ORBIT_FRAMES, W, H, cfg["fx"]).f32() for k in range(ORBIT_FRAMES)]
+
+    def step(k):
+        v, p, vp = poses[k % ORBIT_FRAMES]
+        r.set_camera_arrays(v, p, vp, cfg["fx"], cfg["fx"])
+        r.render_async()
+        if world > 1:
+            r.sync()  # the library's stream -> host; torch's stream takes over for the exchange
+            xchg.exchange(fb)
+
+    def fence():
+        r.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    fence()
+    r.reset_stats()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda:%d" % local_rank)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    st = r.stats()
+    frames = max(int(st["frames"]), 1)
+    ms = {k: st["sum_ms_" + k] / frames for k in ("project_key", "sort", "bin", "blend", "total")}
+    sf = max(int(st["sum_frames"]), 1)
+    V, D, E = st["sum_visible"] / sf, st["sum_tile_entries"] / sf, st["sum_bin_entries"] / sf
+    band_px = ((x1 - x0) if world > 1 else W) * H
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        fps = args.steps / elapsed
+        # algorithmic bytes per frame, SURVEY.md 8(d): B_sort = 52N, B_proj = 16N + 48V,
+        # B_bin = 8D, B_blend = 32D + 16P (per launch of the compositor, this rank's band)
+        b_blend = 32.0 * D + 16.0 * band_px
+        b_sort = 52.0 * N
+        b_proj = 16.0 * N + 48.0 * V
+        b_bin = 8.0 * D
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "blend_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        ach = b_blend / (ms["blend"] * 1e-3) / 1e9 if ms["blend"] > 0 else 0.0
+        out = {
+            "metric": "frames_per_sec", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %d synthetic gaussians (seed %d), %dx%d, 120-pose orbit, full render(scene,camera) "
+                                   "= depth key + 17-bit sort + projection + binning + composite"
+                                   % (args.config, N, cfg["seed"], W, H),
+                       "early_out_eps": args.early_out_eps, "parallelism": "tile-column bands x%d" % world,
+                       "output": "RGBA f32 premultiplied, left in HBM"},
+            "sorted_splats_per_sec": N / ((ms["project_key"] + ms["sort"]) * 1e-3),
+            "stage_ms": ms,
+            "counts": {"N": N, "V": V, "D_tiles16": D, "bin_entries32": E, "P": band_px},
+            "roofline": {"bound": "hbm", "kernel": "k_blend", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": b_blend, "avg_launch_ms": ms["blend"],
+                         "note": "the compositor is VALU/LDS-bound, not HBM-bound (SURVEY 8(d) honest note)"},
+            "stage_roofline": {
+                "sort": {"bytes": b_sort, "ms": ms["sort"], "GBps": b_sort / (ms["sort"] * 1e-3) / 1e9 if ms["sort"] else 0,
+                         "frac": b_sort / (ms["sort"] * 1e-3) / 1e9 / HBM_PEAK_GBS if ms["sort"] else 0},
+                "project_key": {"bytes": b_proj + 16.0 * N, "ms": ms["project_key"],
+                                "GBps": (b_proj + 16.0 * N) / (ms["project_key"] * 1e-3) / 1e9 if ms["project_key"] else 0},
+                "bin": {"bytes": b_bin, "ms": ms["bin"], "GBps": b_bin / (ms["bin"] * 1e-3) / 1e9 if ms["bin"] else 0},
+                "frame": {"bytes": b_sort + b_proj + b_bin + b_blend, "ms": ms_step,
+                          "frac": (b_sort + b_proj + b_bin + b_blend) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            },
+            "device": r.device_info(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(gh, cfg, scene.data[:8 * N], scene.positions)
+        print(json.dumps(out))
+    r.dispose()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -26,6 +26,7 @@ struct FrameState {  // small per-frame device words, (re)initialised by one mem
     uint32_t overflow;
     uint32_t pad;
     uint64_t visible;
+    uint64_t tile_entries;
     uint32_t digit_total[RADIX_LO_BINS + RADIX_HI_BINS];
 };
 
@@ -57,6 +58,7 @@ struct gsr_ctx {
     FrameState* fstate = nullptr;       // device
     FrameState* fstate_init = nullptr;  // device, constant image copied into fstate every frame
     FrameState* fstate_host = nullptr;  // pinned
+    uint64_t* accum = nullptr;          // device [4]: sums over frames (visible, bin entries, tile entries, frames)
     // output
     float4* fb = nullptr;
     uint32_t* fb8 = nullptr;
@@ -65,7 +67,13 @@ struct gsr_ctx {
     CamParams cam{};
     bool have_cam = false, have_frame = false, have_sort = false;
 
-    hipEvent_t ev[EV_COUNT]{};
+    // timing: a ring of event sets so that frames can be enqueued back to back without a host
+    // sync per frame; gsr_sync / gsr_get_timings drain the ring
+    static constexpr int EV_RING = 128;
+    hipEvent_t evring[EV_RING][EV_COUNT]{};
+    bool ev_is_render[EV_RING]{};
+    int ev_head = 0, ev_pending = 0;
+    hipEvent_t* ev = nullptr;  // the set being recorded
     bool ev_valid = false, ev_recorded = false, ev_render = false;
     gsr_timings tm{};
 };
@@ -155,6 +163,8 @@ int alloc_fb(gsr_ctx* c)
     return GSR_OK;
 }
 
+int finish_frame(gsr_ctx* c);
+
 // enqueue: frame words reset, projection + depth key, sort, (bin, blend)
 int enqueue_frame(gsr_ctx* c, bool render)
 {
@@ -162,6 +172,12 @@ int enqueue_frame(gsr_ctx* c, bool render)
     if (render && (!c->W || !c->H)) return fail(c, GSR_ERR_ARG, "framebuffer size is 0");
     hipStream_t s = c->stream;
     const bool timing = c->ev_valid;
+    if (timing) {
+        if (c->ev_pending == gsr_ctx::EV_RING) { if (int r = finish_frame(c)) return r; }
+        const int slot = (c->ev_head + c->ev_pending) % gsr_ctx::EV_RING;
+        c->ev = c->evring[slot];
+        c->ev_is_render[slot] = render;
+    }
     c->cam.W = c->W; c->cam.H = c->H;
     HIP_TRY(c, hipMemcpyAsync(c->fstate, c->fstate_init, sizeof(FrameState), hipMemcpyDeviceToDevice, s));
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BEGIN], s));
@@ -183,7 +199,7 @@ int enqueue_frame(gsr_ctx* c, bool render)
         HIP_TRY(c, hipMemsetAsync(c->bin_start, 0, sizeof(uint32_t) * (nbins + 1), s));
         if (c->n) {
             BinBuffers bb{c->depth_index, c->bbox, c->bin_table, c->bin_total, c->bin_start, c->bin_list,
-                          &c->fstate->overflow, &c->fstate->visible, c->bin_capacity, 2048, c->bin_blocks};
+                          &c->fstate->overflow, &c->fstate->visible, &c->fstate->tile_entries, c->accum, c->bin_capacity, 2048, c->bin_blocks};
             launch_bin(bb, g, c->n, s);
         }
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BIN], s));
@@ -191,6 +207,7 @@ int enqueue_frame(gsr_ctx* c, bool render)
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BLEND], s));
     }
     HIP_TRY(c, hipGetLastError());
+    if (timing) c->ev_pending++;
     c->ev_recorded = timing;
     c->ev_render = render;
     c->have_sort = true;
@@ -201,22 +218,26 @@ int enqueue_frame(gsr_ctx* c, bool render)
 int finish_frame(gsr_ctx* c)
 {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->ev_recorded) {
+    while (c->ev_pending > 0) {
+        hipEvent_t* ev = c->evring[c->ev_head];
+        const bool render = c->ev_is_render[c->ev_head];
         float a = 0, b = 0, d = 0, e = 0, t = 0;
-        HIP_TRY(c, hipEventElapsedTime(&a, c->ev[EV_BEGIN], c->ev[EV_PROJECT]));
-        HIP_TRY(c, hipEventElapsedTime(&b, c->ev[EV_PROJECT], c->ev[EV_SORT]));
+        HIP_TRY(c, hipEventElapsedTime(&a, ev[EV_BEGIN], ev[EV_PROJECT]));
+        HIP_TRY(c, hipEventElapsedTime(&b, ev[EV_PROJECT], ev[EV_SORT]));
         t = a + b;
-        if (c->ev_render) {
-            HIP_TRY(c, hipEventElapsedTime(&d, c->ev[EV_SORT], c->ev[EV_BIN]));
-            HIP_TRY(c, hipEventElapsedTime(&e, c->ev[EV_BIN], c->ev[EV_BLEND]));
-            HIP_TRY(c, hipEventElapsedTime(&t, c->ev[EV_BEGIN], c->ev[EV_BLEND]));
+        if (render) {
+            HIP_TRY(c, hipEventElapsedTime(&d, ev[EV_SORT], ev[EV_BIN]));
+            HIP_TRY(c, hipEventElapsedTime(&e, ev[EV_BIN], ev[EV_BLEND]));
+            HIP_TRY(c, hipEventElapsedTime(&t, ev[EV_BEGIN], ev[EV_BLEND]));
         }
         c->tm.ms_project_key = a; c->tm.ms_sort = b; c->tm.ms_bin = d; c->tm.ms_blend = e; c->tm.ms_total = t;
         c->tm.sum_ms_project_key += a; c->tm.sum_ms_sort += b; c->tm.sum_ms_bin += d; c->tm.sum_ms_blend += e;
         c->tm.sum_ms_total += t;
         c->tm.frames++;
-        c->ev_recorded = false;
+        c->ev_head = (c->ev_head + 1) % gsr_ctx::EV_RING;
+        c->ev_pending--;
     }
+    c->ev_recorded = false;
     return GSR_OK;
 }
 
@@ -228,8 +249,12 @@ int check_frame_words(gsr_ctx* c, bool* overflowed)
     const BinGrid g = make_grid(c);
     const int nbins = (g.bx_hi - g.bx_lo) * g.nby;
     HIP_TRY(c, hipMemcpyAsync(&total, c->bin_start + nbins, 4, hipMemcpyDeviceToHost, c->stream));
+    uint64_t acc[4] = {0, 0, 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(acc, c->accum, sizeof acc, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->tm.sum_visible = acc[0]; c->tm.sum_bin_entries = acc[1]; c->tm.sum_tile_entries = acc[2]; c->tm.sum_frames = acc[3];
     c->tm.visible = c->fstate_host->visible;
+    c->tm.tile_entries = c->fstate_host->tile_entries;
     c->tm.bin_entries = total;
     c->tm.n = c->n;
     *overflowed = c->fstate_host->overflow != 0;
@@ -277,6 +302,8 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
     CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CREATE_TRY(hipMalloc((void**)&c->fstate, sizeof(FrameState)));
     CREATE_TRY(hipMalloc((void**)&c->fstate_init, sizeof(FrameState)));
+    CREATE_TRY(hipMalloc((void**)&c->accum, 4 * sizeof(uint64_t)));
+    CREATE_TRY(hipMemset(c->accum, 0, 4 * sizeof(uint64_t)));
     CREATE_TRY(hipHostMalloc((void**)&c->fstate_host, sizeof(FrameState), hipHostMallocDefault));
     memset(c->fstate_host, 0, sizeof(FrameState));
     c->fstate_host->minmax[0] = 0x7fffffff;            // wasm/wasm.cpp:14
@@ -284,7 +311,8 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
     CREATE_TRY(hipMemcpy(c->fstate_init, c->fstate_host, sizeof(FrameState), hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(c->fstate, c->fstate_host, sizeof(FrameState), hipMemcpyHostToDevice));
     if (o.flags & GSR_FLAG_TIMING) {
-        for (auto& e : c->ev) CREATE_TRY(hipEventCreate(&e));
+        for (auto& set : c->evring)
+            for (auto& e : set) CREATE_TRY(hipEventCreate(&e));
         c->ev_valid = true;
     }
 #undef CREATE_TRY
@@ -310,9 +338,10 @@ int gsr_destroy(gsr_ctx* c)
     dev_free(&c->depth); dev_free(&c->keys); dev_free(&c->keys_tmp); dev_free(&c->idx_tmp); dev_free(&c->depth_index);
     dev_free(&c->block_hist); dev_free(&c->rec); dev_free(&c->bbox);
     dev_free(&c->bin_table); dev_free(&c->bin_total); dev_free(&c->bin_start); dev_free(&c->bin_list);
-    dev_free(&c->fstate); dev_free(&c->fstate_init); dev_free(&c->fb); dev_free(&c->fb8);
+    dev_free(&c->fstate); dev_free(&c->fstate_init); dev_free(&c->accum); dev_free(&c->fb); dev_free(&c->fb8);
     if (c->fstate_host) (void)hipHostFree(c->fstate_host);
-    if (c->ev_valid) for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& set : c->evring)
+        for (auto& e : set) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return GSR_OK;
@@ -402,7 +431,6 @@ int gsr_render_async(gsr_ctx* c)
 {
     if (!c) return GSR_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    if (c->ev_recorded) { if (int r = finish_frame(c)) return r; }
     return enqueue_frame(c, true);
 }
 
@@ -435,7 +463,6 @@ int gsr_sort(gsr_ctx* c)
 {
     if (!c) return GSR_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    if (c->ev_recorded) { if (int r = finish_frame(c)) return r; }
     if (int r = enqueue_frame(c, false)) return r;
     return finish_frame(c);
 }
@@ -482,9 +509,10 @@ int gsr_reset_timings(gsr_ctx* c)
 {
     if (!c) return GSR_ERR_ARG;
     if (c->ev_recorded) { if (int r = finish_frame(c)) return r; }
-    const uint64_t v = c->tm.visible, b = c->tm.bin_entries;
+    const uint64_t v = c->tm.visible, b = c->tm.bin_entries, d = c->tm.tile_entries;
     c->tm = gsr_timings{};
-    c->tm.visible = v; c->tm.bin_entries = b; c->tm.n = c->n;
+    HIP_TRY(c, hipMemsetAsync(c->accum, 0, 4 * sizeof(uint64_t), c->stream));
+    c->tm.visible = v; c->tm.bin_entries = b; c->tm.tile_entries = d; c->tm.n = c->n;
     return GSR_OK;
 }
 

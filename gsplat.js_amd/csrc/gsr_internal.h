@@ -81,6 +81,8 @@ struct BinBuffers {
     uint32_t* list;              // capacity entries (splat indices, depth order inside each bin)
     uint32_t* overflow;          // set to 1 if an entry did not fit
     uint64_t* visible;           // V counter
+    uint64_t* tile_entries;      // D counter (16x16 tiles overlapped by visible bboxes)
+    uint64_t* accum;             // [4] running sums over frames: visible, bin entries, tile entries, frames
     uint32_t capacity;
     uint32_t ranks_per_block;
     uint32_t nblocks;

@@ -45,20 +45,27 @@ __device__ __forceinline__ uint32_t lanes_below64(uint64_t mask)
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __restrict__ depth_index,
                                                            const uint2* __restrict__ bbox, uint32_t n, BinGrid g,
                                                            uint32_t* __restrict__ table, uint32_t* __restrict__ bin_total,
-                                                           uint64_t* __restrict__ visible)
+                                                           uint64_t* __restrict__ visible, uint64_t* __restrict__ tile_entries,
+                                                           uint64_t* __restrict__ accum)
 {
     extern __shared__ uint32_t s_cnt[];  // nbins
     const int nbxb = g.bx_hi - g.bx_lo, nbins = nbxb * g.nby;
     for (int b = threadIdx.x; b < nbins; b += BIN_THREADS) s_cnt[b] = 0;
     __syncthreads();
     const uint32_t begin = blockIdx.x * BIN_RANKS_PER_BLOCK;
-    uint32_t vis = 0;
+    uint32_t vis = 0, tiles = 0;
 #pragma unroll
     for (int st = 0; st < BIN_STEPS; st++) {
         const uint32_t r = begin + st * BIN_THREADS + threadIdx.x;
         if (r < n) {
-            const BinRect br = bin_rect(bbox[depth_index[r]], g);
-            if (br.x0 <= br.x1) vis++;
+            const uint2 bb = bbox[depth_index[r]];
+            const BinRect br = bin_rect(bb, g);
+            if (br.x0 <= br.x1) {
+                vis++;
+                const int tx0 = max((int)(bb.x & 0xffff) / TILE, g.bx_lo * BIN_TILES);
+                const int tx1 = min((int)(bb.x >> 16) / TILE, g.bx_hi * BIN_TILES - 1);
+                tiles += (uint32_t)((tx1 - tx0 + 1) * ((int)(bb.y >> 16) / TILE - (int)(bb.y & 0xffff) / TILE + 1));
+            }
             for (int y = br.y0; y <= br.y1; y++)
                 for (int x = br.x0; x <= br.x1; x++) atomicAdd(&s_cnt[y * nbxb + x], 1u);
         }
@@ -70,8 +77,16 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
         if (c) atomicAdd(&bin_total[b], c);
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) vis += __shfl_xor(vis, off);
-    if ((threadIdx.x & 63) == 0 && vis) atomicAdd((unsigned long long*)visible, (unsigned long long)vis);
+    for (int off = 32; off > 0; off >>= 1) {
+        vis += __shfl_xor(vis, off);
+        tiles += __shfl_xor(tiles, off);
+    }
+    if ((threadIdx.x & 63) == 0 && vis) {
+        atomicAdd((unsigned long long*)visible, (unsigned long long)vis);
+        atomicAdd((unsigned long long*)tile_entries, (unsigned long long)tiles);
+        atomicAdd((unsigned long long*)&accum[0], (unsigned long long)vis);
+        atomicAdd((unsigned long long*)&accum[2], (unsigned long long)tiles);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -81,7 +96,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_scan(uint32_t* __restrict__ table,
                                                           const uint32_t* __restrict__ bin_total, int nbins,
-                                                          uint32_t nblocks, uint32_t* __restrict__ bin_start)
+                                                          uint32_t nblocks, uint32_t* __restrict__ bin_start,
+                                                          uint64_t* __restrict__ accum)
 {
     const int lane = threadIdx.x & 63;
     const int bin = blockIdx.x * BIN_WAVES + (threadIdx.x >> 6);
@@ -92,7 +108,12 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_scan(uint32_t* __restrict__
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
     if (lane == 0) {
         bin_start[bin] = acc;
-        if (bin == nbins - 1) bin_start[nbins] = acc + bin_total[bin];
+        if (bin == nbins - 1) {
+            const uint32_t total = acc + bin_total[bin];
+            bin_start[nbins] = total;
+            atomicAdd((unsigned long long*)&accum[1], (unsigned long long)total);
+            atomicAdd((unsigned long long*)&accum[3], 1ull);
+        }
     }
     uint32_t run = acc;
     for (uint32_t b0 = 0; b0 < nblocks; b0 += WAVE) {
@@ -211,9 +232,9 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
     const int nbxb = g.bx_hi - g.bx_lo, nbins = nbxb * g.nby;
     const dim3 grid(b.nblocks), block(BIN_THREADS);
     hipLaunchKernelGGL(k_bin_count, grid, block, nbins * sizeof(uint32_t), s, b.depth_index, b.bbox, n, g, b.table,
-                       b.bin_total, b.visible);
+                       b.bin_total, b.visible, b.tile_entries, b.accum);
     hipLaunchKernelGGL(k_bin_scan, dim3((nbins + BIN_WAVES - 1) / BIN_WAVES), block, 0, s, b.table,
-                       (const uint32_t*)b.bin_total, nbins, b.nblocks, b.bin_start);
+                       (const uint32_t*)b.bin_total, nbins, b.nblocks, b.bin_start, b.accum);
     const size_t lds = (size_t)((BIN_WAVES * nbins + 1) & ~1) * 4 + (size_t)BIN_WAVES * (nbxb + g.nby) * 8;
     static bool lds_raised = false;  // allow up to the CU's full 160 KiB of dynamic LDS (4K: 8160 bins)
     if (!lds_raised) {

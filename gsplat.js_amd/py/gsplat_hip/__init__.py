@@ -31,9 +31,11 @@ class GsrOptions(ctypes.Structure):
 class GsrTimings(ctypes.Structure):
     _fields_ = [("ms_project_key", ctypes.c_float), ("ms_sort", ctypes.c_float), ("ms_bin", ctypes.c_float),
                 ("ms_blend", ctypes.c_float), ("ms_total", ctypes.c_float), ("visible", ctypes.c_uint64),
-                ("bin_entries", ctypes.c_uint64), ("n", ctypes.c_uint32), ("frames", ctypes.c_uint32),
+                ("bin_entries", ctypes.c_uint64), ("tile_entries", ctypes.c_uint64), ("n", ctypes.c_uint32), ("frames", ctypes.c_uint32),
                 ("sum_ms_project_key", ctypes.c_double), ("sum_ms_sort", ctypes.c_double),
-                ("sum_ms_bin", ctypes.c_double), ("sum_ms_blend", ctypes.c_double), ("sum_ms_total", ctypes.c_double)]
+                ("sum_ms_bin", ctypes.c_double), ("sum_ms_blend", ctypes.c_double), ("sum_ms_total", ctypes.c_double),
+                ("sum_visible", ctypes.c_uint64), ("sum_bin_entries", ctypes.c_uint64),
+                ("sum_tile_entries", ctypes.c_uint64), ("sum_frames", ctypes.c_uint64)]
 
 
 class GsplatError(RuntimeError):
@@ -100,7 +102,8 @@ def load_library(path=None):
 # ---------------------------------------------------------------------------
 def _float_to_half(x64):
     """src/utils.ts:16-43 (truncating; JS `>>` shift count taken modulo 32)."""
-    f = np.asarray(x64, dtype=np.float64).astype(np.float32).view(np.int32).astype(np.int64)
+    with np.errstate(over="ignore", invalid="ignore"):
+        f = np.asarray(x64, dtype=np.float64).astype(np.float32).view(np.int32).astype(np.int64)
     sign = (f >> 31) & 1
     exp = (f >> 23) & 0xFF
     frac = f & 0x007FFFFF
@@ -233,6 +236,10 @@ class HIPRenderer:
         v, p, vp = camera.f32()
         self._check(self._L.gsr_set_camera(self._ctx, v.ctypes.data, p.ctypes.data, vp.ctypes.data, camera.fx, camera.fy))
         self._camera = camera
+
+    def set_camera_arrays(self, view, proj, view_proj, fx, fy):
+        """Pre-rounded float32[16] matrices (what `new Float32Array(m.buffer)` yields)."""
+        self._check(self._L.gsr_set_camera(self._ctx, view.ctypes.data, proj.ctypes.data, view_proj.ctypes.data, fx, fy))
 
     def render(self, scene, camera, sync=True):
         if scene is not None and scene is not self._scene:

@@ -130,7 +130,7 @@ def test_image_parity_exact_mode(gh, oracle, scenes, name, k):
     cam = _camera(gh, k, cfg)
     img, img8, di, st, oimg, odi, V, D = _render_pair(gh, oracle, data, pos, cam, cfg["width"], cfg["height"])
     assert np.array_equal(di, odi)
-    assert st["visible"] == V
+    assert st["visible"] == V and st["tile_entries"] == D   # the bench's byte model uses these device counters
     err = np.abs(img.astype(np.float64) - oimg.astype(np.float64)).max()
     assert err <= TOL_EXACT, err
     o8 = np.floor(np.clip(oimg.astype(np.float64), 0, 1) * 255.0 + 0.5).astype(np.int32)
