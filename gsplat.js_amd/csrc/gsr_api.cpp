@@ -53,7 +53,11 @@ struct gsr_ctx {
     uint32_t sort_blocks = 0, sort_kpb = 0;
     // binning
     uint32_t *bin_table = nullptr, *bin_total = nullptr, *bin_start = nullptr, *bin_list = nullptr;
-    uint32_t bin_blocks = 0, bin_capacity = 0, bin_table_elems = 0, bin_nbins_alloc = 0;
+    uint32_t *seg_start = nullptr, *items = nullptr;
+    uint2* blk_counts = nullptr;
+    float4* partial = nullptr;
+    uint32_t bin_blocks = 0, bin_capacity = 0, bin_table_elems = 0, bin_nbins_alloc = 0, blk_counts_alloc = 0;
+    uint32_t max_items = 0, seg_len = 0;
     // frame words
     FrameState* fstate = nullptr;       // device
     FrameState* fstate_init = nullptr;  // device, constant image copied into fstate every frame
@@ -128,25 +132,47 @@ BinGrid make_grid(const gsr_ctx* c)
     return g;
 }
 
+// Compositor work-item granularity: list entries per (bin, segment) item.  0x7fffff00 = one item per
+// bin, which early termination needs (a segment cannot see whether earlier ones saturated the bin).
+constexpr uint32_t SEG_LEN_EXACT = 512;
+constexpr uint32_t SEG_LEN_WHOLE_BIN = 0x7fffff00u;
+
 int alloc_bins(gsr_ctx* c)
 {
-    if (!c->n || !c->W) return GSR_OK;
+    if (!c->W) return GSR_OK;
     const BinGrid g = make_grid(c);
     const uint32_t nbins = (uint32_t)((g.bx_hi - g.bx_lo) * g.nby);
     c->bin_blocks = (c->n + 2047) / 2048;
-    const size_t table = (size_t)c->bin_blocks * nbins;
+    const size_t table = (size_t)std::max(c->bin_blocks, 1u) * nbins;
     if (table > c->bin_table_elems) {
         if (int r = dev_alloc(c, &c->bin_table, table)) return r;
         c->bin_table_elems = (uint32_t)table;
     }
+    if (c->bin_blocks > c->blk_counts_alloc || !c->blk_counts) {
+        if (int r = dev_alloc(c, &c->blk_counts, std::max(c->bin_blocks, 1u))) return r;
+        c->blk_counts_alloc = c->bin_blocks;
+    }
+    bool items_dirty = false;
     if (nbins > c->bin_nbins_alloc) {
         if (int r = dev_alloc(c, &c->bin_total, nbins)) return r;
         if (int r = dev_alloc(c, &c->bin_start, nbins + 1)) return r;
+        if (int r = dev_alloc(c, &c->seg_start, nbins + 1)) return r;
         c->bin_nbins_alloc = nbins;
+        items_dirty = true;
     }
     if (!c->bin_capacity) {
         c->bin_capacity = std::max<uint32_t>(4u * c->n + (1u << 20), 1u << 22);
         if (int r = dev_alloc(c, &c->bin_list, c->bin_capacity)) return r;
+        items_dirty = true;
+    }
+    c->seg_len = c->opt.early_out_eps > 0.0f ? SEG_LEN_WHOLE_BIN : SEG_LEN_EXACT;
+    const uint32_t want_items = nbins + c->bin_capacity / c->seg_len + 16;
+    if (items_dirty || want_items > c->max_items) {
+        c->max_items = want_items;
+        if (int r = dev_alloc(c, &c->items, c->max_items)) return r;
+        if (c->seg_len != SEG_LEN_WHOLE_BIN) {
+            if (int r = dev_alloc(c, &c->partial, (size_t)c->max_items * BIN_PX * BIN_PX)) return r;
+        }
     }
     return GSR_OK;
 }
@@ -195,15 +221,15 @@ int enqueue_frame(gsr_ctx* c, bool render)
     if (render) {
         const BinGrid g = make_grid(c);
         const int nbins = (g.bx_hi - g.bx_lo) * g.nby;
-        HIP_TRY(c, hipMemsetAsync(c->bin_total, 0, sizeof(uint32_t) * nbins, s));
-        HIP_TRY(c, hipMemsetAsync(c->bin_start, 0, sizeof(uint32_t) * (nbins + 1), s));
-        if (c->n) {
-            BinBuffers bb{c->depth_index, c->bbox, c->bin_table, c->bin_total, c->bin_start, c->bin_list,
-                          &c->fstate->overflow, &c->fstate->visible, &c->fstate->tile_entries, c->accum, c->bin_capacity, 2048, c->bin_blocks};
-            launch_bin(bb, g, c->n, s);
-        }
+        if (!c->n) HIP_TRY(c, hipMemsetAsync(c->bin_total, 0, sizeof(uint32_t) * nbins, s));
+        BinBuffers bb{c->depth_index, c->bbox, c->bin_table, c->blk_counts, c->bin_total, c->bin_start, c->seg_start,
+                      c->items, c->bin_list, &c->fstate->overflow, &c->fstate->visible, &c->fstate->tile_entries,
+                      c->accum, c->bin_capacity, c->max_items, c->seg_len, c->bin_blocks};
+        launch_bin(bb, g, c->n, s);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BIN], s));
-        launch_blend(c->bin_start, c->bin_list, c->rec, c->bbox, c->fb, g, c->opt.early_out_eps, s);
+        BlendBuffers bl{c->items, c->seg_start, c->bin_start, c->bin_list, c->rec, c->bbox, c->fb, c->partial,
+                        c->seg_len, std::min<uint32_t>(c->max_items, 2048u)};
+        launch_blend(bl, g, c->opt.early_out_eps, s);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BLEND], s));
     }
     HIP_TRY(c, hipGetLastError());
@@ -263,6 +289,8 @@ int check_frame_words(gsr_ctx* c, bool* overflowed)
         if (want > 0xfffffff0ull) return fail(c, GSR_ERR_OVERFLOW, "bin list would need %llu entries", (unsigned long long)want);
         c->bin_capacity = (uint32_t)want;
         if (int r = dev_alloc(c, &c->bin_list, c->bin_capacity)) return r;
+        c->max_items = 0;
+        if (int r = alloc_bins(c)) return r;
     }
     return GSR_OK;
 }
@@ -338,6 +366,7 @@ int gsr_destroy(gsr_ctx* c)
     dev_free(&c->depth); dev_free(&c->keys); dev_free(&c->keys_tmp); dev_free(&c->idx_tmp); dev_free(&c->depth_index);
     dev_free(&c->block_hist); dev_free(&c->rec); dev_free(&c->bbox);
     dev_free(&c->bin_table); dev_free(&c->bin_total); dev_free(&c->bin_start); dev_free(&c->bin_list);
+    dev_free(&c->seg_start); dev_free(&c->items); dev_free(&c->blk_counts); dev_free(&c->partial);
     dev_free(&c->fstate); dev_free(&c->fstate_init); dev_free(&c->accum); dev_free(&c->fb); dev_free(&c->fb8);
     if (c->fstate_host) (void)hipHostFree(c->fstate_host);
     for (auto& set : c->evring)

@@ -75,22 +75,37 @@ struct BinGrid {
 struct BinBuffers {
     const uint32_t* depth_index; // n
     const uint2* bbox;           // n
-    uint32_t* table;             // nblocks * nbins  (counts, then per-block bases)
-    uint32_t* bin_total;         // nbins
+    uint32_t* table;             // nblocks * nbins  (counts, then per-workgroup offsets inside each bin)
+    uint2* blk_counts;           // nblocks: (visible splats, 16x16 tile overlaps) per counting workgroup
+    uint32_t* bin_total;         // nbins (zeroed by the caller when n == 0)
     uint32_t* bin_start;         // nbins + 1
+    uint32_t* seg_start;         // nbins + 1: first compositor work item of each bin; [nbins] = item count
+    uint32_t* items;             // max_items: bin | segment << 16
     uint32_t* list;              // capacity entries (splat indices, depth order inside each bin)
-    uint32_t* overflow;          // set to 1 if an entry did not fit
+    uint32_t* overflow;          // bit 0: list too small, bit 1: item table too small
     uint64_t* visible;           // V counter
     uint64_t* tile_entries;      // D counter (16x16 tiles overlapped by visible bboxes)
     uint64_t* accum;             // [4] running sums over frames: visible, bin entries, tile entries, frames
     uint32_t capacity;
-    uint32_t ranks_per_block;
+    uint32_t max_items;
+    uint32_t seg_len;            // list entries per compositor work item (multiple of 256)
     uint32_t nblocks;
 };
 void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s);
 
-void launch_blend(const uint32_t* bin_start, const uint32_t* list, const Record* rec, const uint2* bbox,
-                  float4* fb, const BinGrid& g, float early_out_eps, hipStream_t s);
+struct BlendBuffers {
+    const uint32_t* items;      // work items: bin | segment << 16
+    const uint32_t* seg_start;  // nbins + 1
+    const uint32_t* bin_start;  // nbins + 1
+    const uint32_t* list;
+    const Record* rec;
+    const uint2* bbox;
+    float4* fb;
+    float4* partial;            // max_items * 1024 float4: per-segment (colour, transmittance)
+    uint32_t seg_len;           // >= 0x40000000: one item per bin (early termination mode)
+    uint32_t grid;              // workgroups launched; items are dealt round-robin
+};
+void launch_blend(const BlendBuffers& b, const BinGrid& g, float early_out_eps, hipStream_t s);
 void launch_clear_fb(float4* fb, int32_t W, int32_t H, hipStream_t s);
 void launch_to_rgba8(const float4* fb, uint32_t* out, uint32_t npix, hipStream_t s);
 

@@ -13,6 +13,8 @@
 // lane: wavefront ballot arithmetic, no atomics with ordering requirements.
 #include "gsr_internal.h"
 
+#include <algorithm>
+
 namespace gsr {
 
 constexpr int BIN_THREADS = 256;
@@ -40,82 +42,71 @@ __device__ __forceinline__ uint32_t lanes_below64(uint64_t mask)
 }
 
 // ---------------------------------------------------------------------------
-// count: table[block][bin] = entries block contributes to bin; bin_total[bin] += same
+// count: table[block][bin] = entries this workgroup contributes to bin;
+// blk_counts[block] = (visible splats, 16x16 tiles their boxes overlap).
+// No global atomics: hundreds of workgroups hitting the same few words cost
+// more than the whole pass.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __restrict__ depth_index,
                                                            const uint2* __restrict__ bbox, uint32_t n, BinGrid g,
-                                                           uint32_t* __restrict__ table, uint32_t* __restrict__ bin_total,
-                                                           uint64_t* __restrict__ visible, uint64_t* __restrict__ tile_entries,
-                                                           uint64_t* __restrict__ accum)
+                                                           uint32_t* __restrict__ table, uint2* __restrict__ blk_counts)
 {
     extern __shared__ uint32_t s_cnt[];  // nbins
+    __shared__ uint32_t s_red[2 * BIN_WAVES];
     const int nbxb = g.bx_hi - g.bx_lo, nbins = nbxb * g.nby;
     for (int b = threadIdx.x; b < nbins; b += BIN_THREADS) s_cnt[b] = 0;
     __syncthreads();
     const uint32_t begin = blockIdx.x * BIN_RANKS_PER_BLOCK;
     uint32_t vis = 0, tiles = 0;
+    uint32_t idx[BIN_STEPS];
 #pragma unroll
     for (int st = 0; st < BIN_STEPS; st++) {
         const uint32_t r = begin + st * BIN_THREADS + threadIdx.x;
-        if (r < n) {
-            const uint2 bb = bbox[depth_index[r]];
-            const BinRect br = bin_rect(bb, g);
-            if (br.x0 <= br.x1) {
-                vis++;
-                const int tx0 = max((int)(bb.x & 0xffff) / TILE, g.bx_lo * BIN_TILES);
-                const int tx1 = min((int)(bb.x >> 16) / TILE, g.bx_hi * BIN_TILES - 1);
-                tiles += (uint32_t)((tx1 - tx0 + 1) * ((int)(bb.y >> 16) / TILE - (int)(bb.y & 0xffff) / TILE + 1));
-            }
+        idx[st] = (r < n) ? depth_index[r] : 0xffffffffu;
+    }
+    uint2 bbs[BIN_STEPS];
+#pragma unroll
+    for (int st = 0; st < BIN_STEPS; st++)
+        bbs[st] = (idx[st] != 0xffffffffu) ? bbox[idx[st]] : make_uint2(BBOX_INVISIBLE_X, BBOX_INVISIBLE_Y);
+#pragma unroll
+    for (int st = 0; st < BIN_STEPS; st++) {
+        const uint2 bb = bbs[st];
+        const BinRect br = bin_rect(bb, g);
+        if (br.x0 <= br.x1) {
+            vis++;
+            const int tx0 = max((int)(bb.x & 0xffff) / TILE, g.bx_lo * BIN_TILES);
+            const int tx1 = min((int)(bb.x >> 16) / TILE, g.bx_hi * BIN_TILES - 1);
+            tiles += (uint32_t)((tx1 - tx0 + 1) * ((int)(bb.y >> 16) / TILE - (int)(bb.y & 0xffff) / TILE + 1));
             for (int y = br.y0; y <= br.y1; y++)
                 for (int x = br.x0; x <= br.x1; x++) atomicAdd(&s_cnt[y * nbxb + x], 1u);
         }
-    }
-    __syncthreads();
-    for (int b = threadIdx.x; b < nbins; b += BIN_THREADS) {
-        const uint32_t c = s_cnt[b];
-        table[(size_t)blockIdx.x * nbins + b] = c;
-        if (c) atomicAdd(&bin_total[b], c);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         vis += __shfl_xor(vis, off);
         tiles += __shfl_xor(tiles, off);
     }
-    if ((threadIdx.x & 63) == 0 && vis) {
-        atomicAdd((unsigned long long*)visible, (unsigned long long)vis);
-        atomicAdd((unsigned long long*)tile_entries, (unsigned long long)tiles);
-        atomicAdd((unsigned long long*)&accum[0], (unsigned long long)vis);
-        atomicAdd((unsigned long long*)&accum[2], (unsigned long long)tiles);
+    if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6] = vis; s_red[BIN_WAVES + (threadIdx.x >> 6)] = tiles; }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nbins; b += BIN_THREADS) table[(size_t)blockIdx.x * nbins + b] = s_cnt[b];
+    if (threadIdx.x == 0) {
+        uint32_t v = 0, t = 0;
+        for (int w = 0; w < BIN_WAVES; w++) { v += s_red[w]; t += s_red[BIN_WAVES + w]; }
+        blk_counts[blockIdx.x] = make_uint2(v, t);
     }
 }
 
 // ---------------------------------------------------------------------------
-// scan: one wave per bin.  bin_start[bin] = entries of all earlier bins;
-// table[block][bin] <- bin_start[bin] + entries of earlier blocks in this bin.
-// The wave handling the last bin also writes bin_start[nbins].
+// scan: one wave per bin: table[block][bin] <- entries of earlier workgroups in this bin;
+// bin_total[bin] = the bin's entry count.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(BIN_THREADS) void k_bin_scan(uint32_t* __restrict__ table,
-                                                          const uint32_t* __restrict__ bin_total, int nbins,
-                                                          uint32_t nblocks, uint32_t* __restrict__ bin_start,
-                                                          uint64_t* __restrict__ accum)
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_scan(uint32_t* __restrict__ table, uint32_t* __restrict__ bin_total,
+                                                          int nbins, uint32_t nblocks)
 {
     const int lane = threadIdx.x & 63;
     const int bin = blockIdx.x * BIN_WAVES + (threadIdx.x >> 6);
     if (bin >= nbins) return;
-    uint32_t acc = 0;
-    for (int j = lane; j < bin; j += WAVE) acc += bin_total[j];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-    if (lane == 0) {
-        bin_start[bin] = acc;
-        if (bin == nbins - 1) {
-            const uint32_t total = acc + bin_total[bin];
-            bin_start[nbins] = total;
-            atomicAdd((unsigned long long*)&accum[1], (unsigned long long)total);
-            atomicAdd((unsigned long long*)&accum[3], 1ull);
-        }
-    }
-    uint32_t run = acc;
+    uint32_t run = 0;
     for (uint32_t b0 = 0; b0 < nblocks; b0 += WAVE) {
         const uint32_t b = b0 + lane;
         const uint32_t v = (b < nblocks) ? table[(size_t)b * nbins + bin] : 0u;
@@ -128,6 +119,79 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_scan(uint32_t* __restrict__
         if (b < nblocks) table[(size_t)b * nbins + bin] = run + incl - v;
         run += __shfl(incl, WAVE - 1);
     }
+    if (lane == 0) bin_total[bin] = run;
+}
+
+// ---------------------------------------------------------------------------
+// finalize (one workgroup): bin_start = exclusive scan of bin_total; the compositor's work items
+// (bin, segment of seg_len list entries), one per segment, at least one per bin; frame counters.
+// ---------------------------------------------------------------------------
+constexpr int FIN_THREADS = 1024;
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_scan, uint32_t* total)
+{
+    // Hillis-Steele over FIN_THREADS values in LDS
+    s_scan[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < FIN_THREADS; off <<= 1) {
+        const uint32_t t = (threadIdx.x >= (unsigned)off) ? s_scan[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_scan[threadIdx.x] += t;
+        __syncthreads();
+    }
+    const uint32_t incl = s_scan[threadIdx.x];
+    *total = s_scan[FIN_THREADS - 1];
+    __syncthreads();
+    return incl - v;
+}
+
+__global__ __launch_bounds__(FIN_THREADS) void k_bin_finalize(const uint32_t* __restrict__ bin_total, int nbins,
+                                                              uint32_t seg_len, uint32_t max_items,
+                                                              const uint2* __restrict__ blk_counts, uint32_t nblocks,
+                                                              uint32_t* __restrict__ bin_start,
+                                                              uint32_t* __restrict__ seg_start, uint32_t* __restrict__ items,
+                                                              uint32_t* __restrict__ overflow, uint64_t* __restrict__ visible,
+                                                              uint64_t* __restrict__ tile_entries, uint64_t* __restrict__ accum)
+{
+    __shared__ uint32_t s_scan[FIN_THREADS];
+    const int per = (nbins + FIN_THREADS - 1) / FIN_THREADS;
+    const int b0 = threadIdx.x * per, b1 = min(b0 + per, nbins);
+    uint32_t sum = 0, segs = 0;
+    for (int b = b0; b < b1; b++) {
+        const uint32_t c = bin_total[b];
+        sum += c;
+        segs += max(1u, (c + seg_len - 1) / seg_len);
+    }
+    uint32_t total_entries, total_items;
+    uint32_t ex = block_exclusive_scan(sum, s_scan, &total_entries);
+    uint32_t sx = block_exclusive_scan(segs, s_scan, &total_items);
+    for (int b = b0; b < b1; b++) {
+        const uint32_t c = bin_total[b];
+        const uint32_t ns = max(1u, (c + seg_len - 1) / seg_len);
+        bin_start[b] = ex;
+        seg_start[b] = sx;
+        for (uint32_t k = 0; k < ns; k++) {
+            if (sx + k < max_items) items[sx + k] = (uint32_t)b | (k << 16);
+            else atomicOr(overflow, 2u);
+        }
+        ex += c;
+        sx += ns;
+    }
+    if (threadIdx.x == 0) {
+        bin_start[nbins] = total_entries;
+        seg_start[nbins] = min(total_items, max_items);
+    }
+    // frame counters
+    uint32_t v = 0, t = 0;
+    for (uint32_t b = threadIdx.x; b < nblocks; b += FIN_THREADS) { v += blk_counts[b].x; t += blk_counts[b].y; }
+    uint32_t tv, tt;
+    block_exclusive_scan(v, s_scan, &tv);
+    block_exclusive_scan(t, s_scan, &tt);
+    if (threadIdx.x == 0) {
+        *visible = tv;
+        *tile_entries = tt;
+        accum[0] += tv; accum[1] += total_entries; accum[2] += tt; accum[3] += 1;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -138,6 +202,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_scan(uint32_t* __restrict__
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_scatter(const uint32_t* __restrict__ depth_index,
                                                              const uint2* __restrict__ bbox, uint32_t n, BinGrid g,
                                                              const uint32_t* __restrict__ table,
+                                                             const uint32_t* __restrict__ bin_start,
                                                              uint32_t* __restrict__ list, uint32_t capacity,
                                                              uint32_t* __restrict__ overflow)
 {
@@ -179,7 +244,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_scatter(const uint32_t* __r
     __syncthreads();
     // phase 2: running destinations: workgroup base + earlier waves
     for (int b = threadIdx.x; b < nbins; b += BIN_THREADS) {
-        uint32_t run = table[(size_t)blockIdx.x * nbins + b];
+        uint32_t run = bin_start[b] + table[(size_t)blockIdx.x * nbins + b];
 #pragma unroll
         for (int w = 0; w < BIN_WAVES; w++) {
             const uint32_t c = cnt[(size_t)w * nbins + b];
@@ -228,22 +293,31 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_scatter(const uint32_t* __r
 
 void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s)
 {
-    if (!n) return;
     const int nbxb = g.bx_hi - g.bx_lo, nbins = nbxb * g.nby;
+    if (nbins <= 0) return;
     const dim3 grid(b.nblocks), block(BIN_THREADS);
-    hipLaunchKernelGGL(k_bin_count, grid, block, nbins * sizeof(uint32_t), s, b.depth_index, b.bbox, n, g, b.table,
-                       b.bin_total, b.visible, b.tile_entries, b.accum);
-    hipLaunchKernelGGL(k_bin_scan, dim3((nbins + BIN_WAVES - 1) / BIN_WAVES), block, 0, s, b.table,
-                       (const uint32_t*)b.bin_total, nbins, b.nblocks, b.bin_start, b.accum);
     const size_t lds = (size_t)((BIN_WAVES * nbins + 1) & ~1) * 4 + (size_t)BIN_WAVES * (nbxb + g.nby) * 8;
-    static bool lds_raised = false;  // allow up to the CU's full 160 KiB of dynamic LDS (4K: 8160 bins)
-    if (!lds_raised) {
-        (void)hipFuncSetAttribute((const void*)k_bin_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_bin_count, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        lds_raised = true;
+    // dynamic LDS above the 64 KiB default needs the attribute raised (4K: 8160 bins -> 130 KiB)
+    static size_t lds_allowed = 64 * 1024;
+    if (lds > lds_allowed) {
+        const int want = (int)std::min<size_t>(lds + 1024, 160 * 1024 - 256);
+        if (hipFuncSetAttribute((const void*)k_bin_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_bin_count, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess)
+            (void)hipGetLastError();  // the launch below then reports the real failure
+        lds_allowed = (size_t)want;
     }
-    hipLaunchKernelGGL(k_bin_scatter, grid, block, lds, s, b.depth_index, b.bbox, n, g, (const uint32_t*)b.table, b.list,
-                       b.capacity, b.overflow);
+    if (n) {
+        hipLaunchKernelGGL(k_bin_count, grid, block, nbins * sizeof(uint32_t), s, b.depth_index, b.bbox, n, g, b.table,
+                           b.blk_counts);
+        hipLaunchKernelGGL(k_bin_scan, dim3((nbins + BIN_WAVES - 1) / BIN_WAVES), block, 0, s, b.table, b.bin_total, nbins,
+                           b.nblocks);
+    }
+    hipLaunchKernelGGL(k_bin_finalize, dim3(1), dim3(FIN_THREADS), 0, s, (const uint32_t*)b.bin_total, nbins, b.seg_len,
+                       b.max_items, (const uint2*)b.blk_counts, n ? b.nblocks : 0u, b.bin_start, b.seg_start, b.items,
+                       b.overflow, b.visible, b.tile_entries, b.accum);
+    if (n)
+        hipLaunchKernelGGL(k_bin_scatter, grid, block, lds, s, b.depth_index, b.bbox, n, g, (const uint32_t*)b.table,
+                           (const uint32_t*)b.bin_start, b.list, b.capacity, b.overflow);
 }
 
 }  // namespace gsr

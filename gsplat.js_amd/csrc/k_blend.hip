@@ -1,14 +1,24 @@
 // Front-to-back tile compositor: frag.glsl.ts:13-21 plus the blend state of
 // WebGLRenderer.ts:139-142,279-285, evaluated per pixel centre in f32.
 //
-// One workgroup (4 waves) per 32x32 screen bin, one wave per 16x16 tile, four
-// pixels per lane.  The bin's depth-ordered splat list is streamed through LDS
-// in chunks of 256 entries: every thread stages one 32-byte record plus a 4-bit
-// "which of the bin's tiles does my box touch" mask; then every wave picks its
-// tile's entries out of the chunk with a wave64 ballot on its mask bit (order
-// preserving) and walks the set bits, reading each record as an LDS broadcast.
-// No per-tile list is ever materialised in HBM and nothing spills: the LDS
-// footprint is fixed (9 KiB) however long the list is.
+// One workgroup (4 waves) per work item = (32x32 screen bin, segment of the
+// bin's depth-ordered splat list); one wave per 16x16 tile, four pixels per
+// lane.  The segment is streamed through LDS in chunks of 256 entries: every
+// thread stages one 32-byte record plus a 4-bit "which of the bin's tiles does
+// my box touch" mask; then every wave picks its tile's entries out of the chunk
+// with a wave64 ballot on its mask bit (order preserving) and walks the set
+// bits, reading each record as an LDS broadcast.  No per-tile list is ever
+// materialised in HBM and nothing spills: the LDS footprint is fixed (9 KiB)
+// however long the list is.
+//
+// Long lists (screen centre) are cut into segments that are composited
+// concurrently by different workgroups, each from (colour 0, transmittance 1);
+// "under" compositing is associative, so k_combine folds the partial
+// (colour, transmittance) pairs of a bin front to back:
+//     C = C0 + T0*C1 + T0*T1*C2 + ...,  T = T0*T1*T2*...
+// This removes the serial critical path of the heaviest tiles.  With early
+// termination enabled a bin is one item (segments could not see each other's
+// saturation), processed front to back until every pixel is opaque.
 //
 // Compiled with -ffp-contract=off; the fused multiply-adds below are explicit,
 // so the coverage test (|vPosition|^2 <= 4) is bit-identical to the oracle's.
@@ -18,136 +28,187 @@ namespace gsr {
 
 constexpr int BLEND_THREADS = 256;
 constexpr int CHUNK = BLEND_THREADS;
+constexpr int BIN_PIXELS = BIN_PX * BIN_PX;
 constexpr float LOG2E = 1.4426950408889634f;
 
-struct Px4 { float T[4], r[4], g[4], b[4]; };
-
-__global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t* __restrict__ bin_start,
+__global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t* __restrict__ items,
+                                                         const uint32_t* __restrict__ seg_start,
+                                                         const uint32_t* __restrict__ bin_start,
                                                          const uint32_t* __restrict__ list,
                                                          const Record* __restrict__ rec,
                                                          const uint2* __restrict__ bbox, float4* __restrict__ fb,
-                                                         BinGrid g, float eps)
+                                                         float4* __restrict__ partial, BinGrid g, float eps,
+                                                         uint32_t seg_len)
 {
     __shared__ float4 s_rec[CHUNK][2];
     __shared__ uint32_t s_mask[CHUNK];
     __shared__ uint32_t s_done;
 
-    const int nbxb = g.bx_hi - g.bx_lo;
-    const int bin = blockIdx.x;
-    const int by = bin / nbxb, bxl = bin - by * nbxb;
+    const int nbxb = g.bx_hi - g.bx_lo, nbins = nbxb * g.nby;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int binX0 = (g.bx_lo + bxl) * BIN_PX, binY0 = by * BIN_PX;
-    const int X0 = binX0 + (wave & 1) * TILE, Y0 = binY0 + (wave >> 1) * TILE;
     const int lx = lane & 7, ly = lane >> 3;
-    const float pxf0 = (float)(X0 + lx) + 0.5f, pxf1 = (float)(X0 + lx + 8) + 0.5f;
-    const float pyf0 = (float)(Y0 + ly) + 0.5f, pyf1 = (float)(Y0 + ly + 8) + 0.5f;
+    const uint32_t total_items = seg_start[nbins];
 
-    float T00 = 1.f, T10 = 1.f, T01 = 1.f, T11 = 1.f;  // T[i][j]: pixel (x+8i, y+8j); 1 - alpha
-    float r00 = 0.f, r10 = 0.f, r01 = 0.f, r11 = 0.f;
-    float g00 = 0.f, g10 = 0.f, g01 = 0.f, g11 = 0.f;
-    float b00 = 0.f, b10 = 0.f, b01 = 0.f, b11 = 0.f;
+    for (uint32_t item = blockIdx.x; item < total_items; item += gridDim.x) {
+        const uint32_t it = items[item];
+        const int bin = (int)(it & 0xffffu);
+        const uint32_t seg = it >> 16;
+        const uint32_t nseg = seg_start[bin + 1] - seg_start[bin];
+        const int by = bin / nbxb, bxl = bin - by * nbxb;
+        const int binX0 = (g.bx_lo + bxl) * BIN_PX, binY0 = by * BIN_PX;
+        const int X0 = binX0 + (wave & 1) * TILE, Y0 = binY0 + (wave >> 1) * TILE;
+        const float pxf0 = (float)(X0 + lx) + 0.5f, pxf1 = (float)(X0 + lx + 8) + 0.5f;
+        const float pyf0 = (float)(Y0 + ly) + 0.5f, pyf1 = (float)(Y0 + ly + 8) + 0.5f;
 
-    const uint32_t begin = bin_start[bin], end = bin_start[bin + 1];
-    if (threadIdx.x == 0) s_done = 0;
-    bool done = false;
+        float T00 = 1.f, T10 = 1.f, T01 = 1.f, T11 = 1.f;  // Tij: pixel (x+8i, y+8j); 1 - alpha
+        float r00 = 0.f, r10 = 0.f, r01 = 0.f, r11 = 0.f;
+        float g00 = 0.f, g10 = 0.f, g01 = 0.f, g11 = 0.f;
+        float b00 = 0.f, b10 = 0.f, b01 = 0.f, b11 = 0.f;
 
-    for (uint32_t base = begin; base < end; base += CHUNK) {
-        __syncthreads();  // previous chunk fully consumed (and s_done visible)
-        if (s_done == BLEND_THREADS / WAVE) break;  // every tile of the bin is saturated
-        // ---- stage one entry per thread ----
-        const uint32_t e = base + threadIdx.x;
-        uint32_t mask = 0;
-        if (e < end) {
-            const uint32_t i = list[e];
-            const float4* rp = reinterpret_cast<const float4*>(rec + i);
-            const float4 ra = rp[0], rb = rp[1];
-            const uint2 bb = bbox[i];
-            const int px0 = bb.x & 0xffff, px1 = bb.x >> 16, py0 = bb.y & 0xffff, py1 = bb.y >> 16;
-            const uint32_t mx = (px0 <= binX0 + TILE - 1 ? 1u : 0u) | (px1 >= binX0 + TILE ? 2u : 0u);
-            const uint32_t my = (py0 <= binY0 + TILE - 1 ? 1u : 0u) | (py1 >= binY0 + TILE ? 2u : 0u);
-            // bit (ty*2 + tx)
-            mask = ((my & 1u) ? mx : 0u) | ((my & 2u) ? (mx << 2) : 0u);
-            s_rec[threadIdx.x][0] = ra;
-            s_rec[threadIdx.x][1] = rb;
-        }
-        s_mask[threadIdx.x] = mask;
-        __syncthreads();
+        const uint32_t bin_end = bin_start[bin + 1];
+        const uint32_t begin = min(bin_start[bin] + seg * seg_len, bin_end);
+        const uint32_t end = min(begin + seg_len, bin_end);
+        __syncthreads();  // the previous item no longer uses the LDS words
+        if (threadIdx.x == 0) s_done = 0;
+        bool done = false;
 
-        if (!done) {
-            const uint32_t cnt = min((uint32_t)CHUNK, end - base);
-            for (uint32_t c0 = 0; c0 < cnt; c0 += WAVE) {
-                uint64_t bal = __ballot((s_mask[c0 + lane] >> wave) & 1u);
-                while (bal) {
-                    const int j = __builtin_ctzll(bal);
-                    bal &= bal - 1;
-                    const float4 ra = s_rec[c0 + j][0];
-                    const float4 rb = s_rec[c0 + j][1];
-                    const float dx0 = pxf0 - ra.x, dx1 = pxf1 - ra.x;
-                    const float dy0 = pyf0 - ra.y, dy1 = pyf1 - ra.y;
-                    const float uy0 = ra.w * dy0, uy1 = ra.w * dy1;
-                    const float wy0 = rb.y * dy0, wy1 = rb.y * dy1;
-                    const float vx00 = __builtin_fmaf(ra.z, dx0, uy0), vy00 = __builtin_fmaf(rb.x, dx0, wy0);
-                    const float vx10 = __builtin_fmaf(ra.z, dx1, uy0), vy10 = __builtin_fmaf(rb.x, dx1, wy0);
-                    const float vx01 = __builtin_fmaf(ra.z, dx0, uy1), vy01 = __builtin_fmaf(rb.x, dx0, wy1);
-                    const float vx11 = __builtin_fmaf(ra.z, dx1, uy1), vy11 = __builtin_fmaf(rb.x, dx1, wy1);
-                    const float q00 = __builtin_fmaf(vy00, vy00, vx00 * vx00);
-                    const float q10 = __builtin_fmaf(vy10, vy10, vx10 * vx10);
-                    const float q01 = __builtin_fmaf(vy01, vy01, vx01 * vx01);
-                    const float q11 = __builtin_fmaf(vy11, vy11, vx11 * vx11);
-                    // frag.glsl.ts:15  if (A < -4.0) discard;   (A = -q)
-                    const bool in00 = q00 <= 4.0f, in10 = q10 <= 4.0f, in01 = q01 <= 4.0f, in11 = q11 <= 4.0f;
-                    if (__ballot(in00 || in10 || in01 || in11) == 0ull) continue;  // wave-uniform
-                    const uint32_t rgb8 = __float_as_uint(rb.w);
-                    const float cr = (float)(rgb8 & 0xffu) * (1.0f / 255.0f);
-                    const float cg = (float)((rgb8 >> 8) & 0xffu) * (1.0f / 255.0f);
-                    const float cb = (float)((rgb8 >> 16) & 0xffu) * (1.0f / 255.0f);
-                    // frag.glsl.ts:16-20  B = clamp(exp(A) * opacity, 0, 1)  (never clamps: exp(A) <= 1, opacity <= 1)
-                    // blend: dst += (1 - dst.a) * (B*rgb, B)
-#define GSR_BLEND_PX(IN, Q, T, R, G, B_)                                                   \
-    {                                                                                      \
-        const float e = (IN) ? __builtin_amdgcn_exp2f(__builtin_fmaf((Q), -LOG2E, rb.z)) : 0.0f; \
-        const float w = (T) * e;                                                           \
-        (T) = (T) - w;                                                                     \
-        (R) = __builtin_fmaf(w, cr, (R));                                                  \
-        (G) = __builtin_fmaf(w, cg, (G));                                                  \
-        (B_) = __builtin_fmaf(w, cb, (B_));                                                \
+        for (uint32_t base = begin; base < end; base += CHUNK) {
+            __syncthreads();  // previous chunk fully consumed (and s_done visible)
+            if (s_done == BLEND_THREADS / WAVE) break;  // every tile of the bin is saturated
+            // ---- stage one entry per thread ----
+            const uint32_t e = base + threadIdx.x;
+            uint32_t mask = 0;
+            if (e < end) {
+                const uint32_t i = list[e];
+                const float4* rp = reinterpret_cast<const float4*>(rec + i);
+                const float4 ra = rp[0], rb = rp[1];
+                const uint2 bb = bbox[i];
+                const int px0 = bb.x & 0xffff, px1 = bb.x >> 16, py0 = bb.y & 0xffff, py1 = bb.y >> 16;
+                const uint32_t mx = (px0 <= binX0 + TILE - 1 ? 1u : 0u) | (px1 >= binX0 + TILE ? 2u : 0u);
+                const uint32_t my = (py0 <= binY0 + TILE - 1 ? 1u : 0u) | (py1 >= binY0 + TILE ? 2u : 0u);
+                mask = ((my & 1u) ? mx : 0u) | ((my & 2u) ? (mx << 2) : 0u);  // bit (ty*2 + tx)
+                s_rec[threadIdx.x][0] = ra;
+                s_rec[threadIdx.x][1] = rb;
+            }
+            s_mask[threadIdx.x] = mask;
+            __syncthreads();
+
+            if (!done) {
+                const uint32_t cnt = min((uint32_t)CHUNK, end - base);
+                for (uint32_t c0 = 0; c0 < cnt; c0 += WAVE) {
+                    uint64_t bal = __ballot((s_mask[c0 + lane] >> wave) & 1u);
+                    while (bal) {
+                        const int j = __builtin_ctzll(bal);
+                        bal &= bal - 1;
+                        const float4 ra = s_rec[c0 + j][0];
+                        const float4 rb = s_rec[c0 + j][1];
+                        const float dx0 = pxf0 - ra.x, dx1 = pxf1 - ra.x;
+                        const float dy0 = pyf0 - ra.y, dy1 = pyf1 - ra.y;
+                        const float uy0 = ra.w * dy0, uy1 = ra.w * dy1;
+                        const float wy0 = rb.y * dy0, wy1 = rb.y * dy1;
+                        const float vx00 = __builtin_fmaf(ra.z, dx0, uy0), vy00 = __builtin_fmaf(rb.x, dx0, wy0);
+                        const float vx10 = __builtin_fmaf(ra.z, dx1, uy0), vy10 = __builtin_fmaf(rb.x, dx1, wy0);
+                        const float vx01 = __builtin_fmaf(ra.z, dx0, uy1), vy01 = __builtin_fmaf(rb.x, dx0, wy1);
+                        const float vx11 = __builtin_fmaf(ra.z, dx1, uy1), vy11 = __builtin_fmaf(rb.x, dx1, wy1);
+                        const float q00 = __builtin_fmaf(vy00, vy00, vx00 * vx00);
+                        const float q10 = __builtin_fmaf(vy10, vy10, vx10 * vx10);
+                        const float q01 = __builtin_fmaf(vy01, vy01, vx01 * vx01);
+                        const float q11 = __builtin_fmaf(vy11, vy11, vx11 * vx11);
+                        // frag.glsl.ts:15  if (A < -4.0) discard;   (A = -q)
+                        const bool in00 = q00 <= 4.0f, in10 = q10 <= 4.0f, in01 = q01 <= 4.0f, in11 = q11 <= 4.0f;
+                        if (__ballot(in00 || in10 || in01 || in11) == 0ull) continue;  // wave-uniform
+                        const uint32_t rgb8 = __float_as_uint(rb.w);
+                        const float cr = (float)(rgb8 & 0xffu) * (1.0f / 255.0f);
+                        const float cg = (float)((rgb8 >> 8) & 0xffu) * (1.0f / 255.0f);
+                        const float cb = (float)((rgb8 >> 16) & 0xffu) * (1.0f / 255.0f);
+                        // frag.glsl.ts:16-20  B = clamp(exp(A) * opacity, 0, 1)  (never clamps: exp(A) <= 1, opacity <= 1)
+                        // blend: dst += (1 - dst.a) * (B*rgb, B)
+#define GSR_BLEND_PX(IN, Q, T, R, G, B_)                                                         \
+    {                                                                                            \
+        const float e_ = (IN) ? __builtin_amdgcn_exp2f(__builtin_fmaf((Q), -LOG2E, rb.z)) : 0.0f; \
+        const float w_ = (T) * e_;                                                               \
+        (T) = (T) - w_;                                                                          \
+        (R) = __builtin_fmaf(w_, cr, (R));                                                       \
+        (G) = __builtin_fmaf(w_, cg, (G));                                                       \
+        (B_) = __builtin_fmaf(w_, cb, (B_));                                                     \
     }
-                    GSR_BLEND_PX(in00, q00, T00, r00, g00, b00)
-                    GSR_BLEND_PX(in10, q10, T10, r10, g10, b10)
-                    GSR_BLEND_PX(in01, q01, T01, r01, g01, b01)
-                    GSR_BLEND_PX(in11, q11, T11, r11, g11, b11)
+                        GSR_BLEND_PX(in00, q00, T00, r00, g00, b00)
+                        GSR_BLEND_PX(in10, q10, T10, r10, g10, b10)
+                        GSR_BLEND_PX(in01, q01, T01, r01, g01, b01)
+                        GSR_BLEND_PX(in11, q11, T11, r11, g11, b11)
 #undef GSR_BLEND_PX
-                }
-                if (eps > 0.0f) {
-                    const float tmax = fmaxf(fmaxf(T00, T10), fmaxf(T01, T11));
-                    if (__ballot(tmax >= eps) == 0ull) {
-                        done = true;
-                        if (lane == 0) atomicAdd(&s_done, 1u);
-                        break;
+                    }
+                    if (eps > 0.0f) {
+                        const float tmax = fmaxf(fmaxf(T00, T10), fmaxf(T01, T11));
+                        if (__ballot(tmax >= eps) == 0ull) {
+                            done = true;
+                            if (lane == 0) atomicAdd(&s_done, 1u);
+                            break;
+                        }
                     }
                 }
             }
         }
-    }
 
-    // ---- write the tile: premultiplied RGBA, alpha = 1 - T ----
-    const int x0 = X0 + lx, x1 = x0 + 8, y0 = Y0 + ly, y1 = y0 + 8;
-    if (y0 < g.H) {
-        if (x0 < g.W) fb[(size_t)y0 * g.W + x0] = make_float4(r00, g00, b00, 1.0f - T00);
-        if (x1 < g.W) fb[(size_t)y0 * g.W + x1] = make_float4(r10, g10, b10, 1.0f - T10);
-    }
-    if (y1 < g.H) {
-        if (x0 < g.W) fb[(size_t)y1 * g.W + x0] = make_float4(r01, g01, b01, 1.0f - T01);
-        if (x1 < g.W) fb[(size_t)y1 * g.W + x1] = make_float4(r11, g11, b11, 1.0f - T11);
+        if (nseg == 1) {
+            // ---- the only segment: write the tile, premultiplied RGBA, alpha = 1 - T ----
+            const int x0 = X0 + lx, x1 = x0 + 8, y0 = Y0 + ly, y1 = y0 + 8;
+            if (y0 < g.H) {
+                if (x0 < g.W) fb[(size_t)y0 * g.W + x0] = make_float4(r00, g00, b00, 1.0f - T00);
+                if (x1 < g.W) fb[(size_t)y0 * g.W + x1] = make_float4(r10, g10, b10, 1.0f - T10);
+            }
+            if (y1 < g.H) {
+                if (x0 < g.W) fb[(size_t)y1 * g.W + x0] = make_float4(r01, g01, b01, 1.0f - T01);
+                if (x1 < g.W) fb[(size_t)y1 * g.W + x1] = make_float4(r11, g11, b11, 1.0f - T11);
+            }
+        } else {
+            // ---- partial (colour, transmittance) of this segment, slot-major: fully coalesced ----
+            float4* p = partial + (size_t)item * BIN_PIXELS + wave * (TILE * TILE) + lane;
+            p[0] = make_float4(r00, g00, b00, T00);
+            p[64] = make_float4(r10, g10, b10, T10);
+            p[128] = make_float4(r01, g01, b01, T01);
+            p[192] = make_float4(r11, g11, b11, T11);
+        }
     }
 }
 
-void launch_blend(const uint32_t* bin_start, const uint32_t* list, const Record* rec, const uint2* bbox, float4* fb,
-                  const BinGrid& g, float early_out_eps, hipStream_t s)
+// Fold the per-segment partials of every multi-segment bin, front to back.
+__global__ __launch_bounds__(BLEND_THREADS) void k_combine(const uint32_t* __restrict__ seg_start,
+                                                           const float4* __restrict__ partial, float4* __restrict__ fb,
+                                                           BinGrid g)
+{
+    const int nbxb = g.bx_hi - g.bx_lo;
+    const int bin = blockIdx.x;
+    const uint32_t s0 = seg_start[bin], nseg = seg_start[bin + 1] - s0;
+    if (nseg <= 1) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int by = bin / nbxb, bxl = bin - by * nbxb;
+    const int X0 = (g.bx_lo + bxl) * BIN_PX + (wave & 1) * TILE, Y0 = by * BIN_PX + (wave >> 1) * TILE;
+    const int lx = lane & 7, ly = lane >> 3;
+#pragma unroll
+    for (int slot = 0; slot < 4; slot++) {
+        const float4* p = partial + (size_t)s0 * BIN_PIXELS + wave * (TILE * TILE) + slot * 64 + lane;
+        float r = 0.f, gg = 0.f, b = 0.f, T = 1.f;
+        for (uint32_t k = 0; k < nseg; k++) {
+            const float4 v = p[(size_t)k * BIN_PIXELS];
+            r = __builtin_fmaf(T, v.x, r);
+            gg = __builtin_fmaf(T, v.y, gg);
+            b = __builtin_fmaf(T, v.z, b);
+            T = T * v.w;
+        }
+        const int x = X0 + lx + 8 * (slot & 1), y = Y0 + ly + 8 * (slot >> 1);
+        if (x < g.W && y < g.H) fb[(size_t)y * g.W + x] = make_float4(r, gg, b, 1.0f - T);
+    }
+}
+
+void launch_blend(const BlendBuffers& b, const BinGrid& g, float early_out_eps, hipStream_t s)
 {
     const int nbins = (g.bx_hi - g.bx_lo) * g.nby;
     if (nbins <= 0) return;
-    hipLaunchKernelGGL(k_blend, dim3(nbins), dim3(BLEND_THREADS), 0, s, bin_start, list, rec, bbox, fb, g, early_out_eps);
+    hipLaunchKernelGGL(k_blend, dim3(b.grid), dim3(BLEND_THREADS), 0, s, b.items, b.seg_start, b.bin_start, b.list, b.rec,
+                       b.bbox, b.fb, b.partial, g, early_out_eps, b.seg_len);
+    if (b.seg_len < 0x40000000u)
+        hipLaunchKernelGGL(k_combine, dim3(nbins), dim3(BLEND_THREADS), 0, s, b.seg_start, (const float4*)b.partial, b.fb, g);
 }
 
 __global__ void k_clear_fb(float4* fb, uint32_t npix)

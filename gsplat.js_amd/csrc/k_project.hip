@@ -205,8 +205,10 @@ __global__ __launch_bounds__(256) void k_project_key(SceneSoA sc, uint32_t n, Ca
     if (threadIdx.x == 0) {
         dmin = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
         dmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-        atomicMin(&minmax[0], dmin);
-        atomicMax(&minmax[1], dmax);
+        // ~4000 workgroups on two words: only those that would move the bound issue the atomic.  The plain
+        // (agent-scope, L1-bypassing) read may be stale, which can only cost a redundant atomic, never lose one.
+        if (dmin < __hip_atomic_load(&minmax[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&minmax[0], dmin);
+        if (dmax > __hip_atomic_load(&minmax[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&minmax[1], dmax);
     }
 }
 
