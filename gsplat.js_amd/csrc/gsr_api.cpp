@@ -24,7 +24,7 @@ enum Stage { EV_BEGIN = 0, EV_PROJECT, EV_SORT, EV_BIN, EV_BLEND, EV_COUNT };
 struct FrameState {  // small per-frame device words, (re)initialised by one memcpy per frame
     int32_t minmax[2];
     uint32_t overflow;
-    uint32_t pad;
+    uint32_t queue;   // compositor work-item counter
     uint64_t visible;
     uint64_t tile_entries;
     uint32_t digit_total[RADIX_LO_BINS + RADIX_HI_BINS];
@@ -228,7 +228,7 @@ int enqueue_frame(gsr_ctx* c, bool render)
         launch_bin(bb, g, c->n, s);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BIN], s));
         BlendBuffers bl{c->items, c->seg_start, c->bin_start, c->bin_list, c->rec, c->bbox, c->fb, c->partial,
-                        c->seg_len, std::min<uint32_t>(c->max_items, 2048u)};
+                        &c->fstate->queue, c->seg_len, std::min<uint32_t>(c->max_items, 2048u)};
         launch_blend(bl, g, c->opt.early_out_eps, s);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BLEND], s));
     }

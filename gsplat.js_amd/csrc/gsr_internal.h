@@ -101,9 +101,10 @@ struct BlendBuffers {
     const Record* rec;
     const uint2* bbox;
     float4* fb;
-    float4* partial;            // max_items * 1024 float4: per-segment (colour, transmittance)
+    float4* partial;            // max_items * 1024 float4: per-segment (colour, transmittance), slot = seg_start[bin] + segment
+    uint32_t* queue;            // device-wide work-item counter, zero at frame start
     uint32_t seg_len;           // >= 0x40000000: one item per bin (early termination mode)
-    uint32_t grid;              // workgroups launched; items are dealt round-robin
+    uint32_t grid;              // persistent workgroups launched
 };
 void launch_blend(const BlendBuffers& b, const BinGrid& g, float early_out_eps, hipStream_t s);
 void launch_clear_fb(float4* fb, int32_t W, int32_t H, hipStream_t s);

@@ -156,26 +156,35 @@ __global__ __launch_bounds__(FIN_THREADS) void k_bin_finalize(const uint32_t* __
     __shared__ uint32_t s_scan[FIN_THREADS];
     const int per = (nbins + FIN_THREADS - 1) / FIN_THREADS;
     const int b0 = threadIdx.x * per, b1 = min(b0 + per, nbins);
-    uint32_t sum = 0, segs = 0;
+    // Items are emitted heaviest first: every full segment (seg_len entries) before every partial or
+    // empty one, so the compositor's queue hands out the long items while the chip is still full.
+    uint32_t sum = 0, segs = 0, fulls = 0;
     for (int b = b0; b < b1; b++) {
         const uint32_t c = bin_total[b];
         sum += c;
         segs += max(1u, (c + seg_len - 1) / seg_len);
+        fulls += c / seg_len;
     }
-    uint32_t total_entries, total_items;
+    uint32_t total_entries, total_items, total_full;
     uint32_t ex = block_exclusive_scan(sum, s_scan, &total_entries);
     uint32_t sx = block_exclusive_scan(segs, s_scan, &total_items);
+    uint32_t fx = block_exclusive_scan(fulls, s_scan, &total_full);
+    uint32_t px = total_full + (sx - fx);  // partial/empty items follow all full ones
     for (int b = b0; b < b1; b++) {
         const uint32_t c = bin_total[b];
         const uint32_t ns = max(1u, (c + seg_len - 1) / seg_len);
+        const uint32_t nf = c / seg_len;
         bin_start[b] = ex;
         seg_start[b] = sx;
+        if (sx + ns > max_items) atomicOr(overflow, 2u);
         for (uint32_t k = 0; k < ns; k++) {
-            if (sx + k < max_items) items[sx + k] = (uint32_t)b | (k << 16);
-            else atomicOr(overflow, 2u);
+            const uint32_t slot = (k < nf) ? fx + k : px;
+            if (slot < max_items) items[slot] = (uint32_t)b | (k << 16);
         }
         ex += c;
         sx += ns;
+        fx += nf;
+        px += ns - nf;
     }
     if (threadIdx.x == 0) {
         bin_start[nbins] = total_entries;
@@ -253,8 +262,14 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_scatter(const uint32_t* __r
         }
     }
     __syncthreads();
-    // phase 3: per step, build the lane sets, rank, write, advance the running destinations
-    volatile uint32_t* vcnt = mycnt;
+    // phase 3: per step, build the lane sets, rank, write, advance the running destinations.
+    // Everything below is one wave talking to its own LDS words; LDS executes a wave's operations in
+    // order, and the wavefront-scope fences keep the compiler from moving accesses across the sweeps.
+#define GSR_WAVE_SYNC()                                      \
+    do {                                                     \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                     \
+    } while (0)
     const unsigned long long mybit = 1ull << lane;
 #pragma unroll
     for (int st = 0; st < BIN_STEPS; st++) {
@@ -263,32 +278,33 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_scatter(const uint32_t* __r
         if (!any) continue;  // wave-uniform
         for (int x = b.x0; x <= b.x1; x++) atomicOr(&colm[x], mybit);
         for (int y = b.y0; y <= b.y1 && b.x0 <= b.x1; y++) atomicOr(&rowm[y], mybit);
-        __builtin_amdgcn_wave_barrier();
+        GSR_WAVE_SYNC();
         // sweep 1: read running destination + rank for every covered bin, write the entries
         for (int y = b.y0; y <= b.y1; y++) {
-            const uint64_t rm = ((volatile unsigned long long*)rowm)[y];
+            const uint64_t rm = rowm[y];
             for (int x = b.x0; x <= b.x1; x++) {
-                const uint64_t m = rm & ((volatile unsigned long long*)colm)[x];
-                const uint32_t dst = vcnt[y * nbxb + x] + lanes_below64(m);
+                const uint64_t m = rm & colm[x];
+                const uint32_t dst = mycnt[y * nbxb + x] + lanes_below64(m);
                 if (dst < capacity) list[dst] = idx[st];
                 else atomicOr(overflow, 1u);
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        GSR_WAVE_SYNC();
         // sweep 2: the lowest lane of every bin's set advances that bin's running destination
         for (int y = b.y0; y <= b.y1; y++) {
-            const uint64_t rm = ((volatile unsigned long long*)rowm)[y];
+            const uint64_t rm = rowm[y];
             for (int x = b.x0; x <= b.x1; x++) {
-                const uint64_t m = rm & ((volatile unsigned long long*)colm)[x];
-                if ((m & (mybit - 1)) == 0ull) vcnt[y * nbxb + x] += (uint32_t)__popcll(m);
+                const uint64_t m = rm & colm[x];
+                if ((m & (mybit - 1)) == 0ull) mycnt[y * nbxb + x] += (uint32_t)__popcll(m);
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        GSR_WAVE_SYNC();
         // clear the words this lane set
-        for (int x = b.x0; x <= b.x1; x++) ((volatile unsigned long long*)colm)[x] = 0ull;
-        for (int y = b.y0; y <= b.y1 && b.x0 <= b.x1; y++) ((volatile unsigned long long*)rowm)[y] = 0ull;
-        __builtin_amdgcn_wave_barrier();
+        for (int x = b.x0; x <= b.x1; x++) colm[x] = 0ull;
+        for (int y = b.y0; y <= b.y1 && b.x0 <= b.x1; y++) rowm[y] = 0ull;
+        GSR_WAVE_SYNC();
     }
+#undef GSR_WAVE_SYNC
 }
 
 void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s)

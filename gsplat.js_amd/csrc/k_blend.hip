@@ -4,11 +4,12 @@
 // One workgroup (4 waves) per work item = (32x32 screen bin, segment of the
 // bin's depth-ordered splat list); one wave per 16x16 tile, four pixels per
 // lane.  The segment is streamed through LDS in chunks of 256 entries: every
-// thread stages one 32-byte record plus a 4-bit "which of the bin's tiles does
-// my box touch" mask; then every wave picks its tile's entries out of the chunk
-// with a wave64 ballot on its mask bit (order preserving) and walks the set
-// bits, reading each record as an LDS broadcast.  No per-tile list is ever
-// materialised in HBM and nothing spills: the LDS footprint is fixed (9 KiB)
+// thread stages one record plus a 16-bit mask of the bin's 8x8-pixel quadrants
+// its splat can touch; then every wave picks its tile's entries out of the chunk
+// with a wave64 ballot on its mask nibble (order preserving) and walks the set
+// bits, reading each record as an LDS broadcast and visiting only the flagged
+// quadrants.  No per-tile list is ever
+// materialised in HBM and nothing spills: the LDS footprint is fixed (11 KiB)
 // however long the list is.
 //
 // Long lists (screen centre) are cut into segments that are composited
@@ -37,20 +38,33 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t* __restr
                                                          const uint32_t* __restrict__ list,
                                                          const Record* __restrict__ rec,
                                                          const uint2* __restrict__ bbox, float4* __restrict__ fb,
-                                                         float4* __restrict__ partial, BinGrid g, float eps,
-                                                         uint32_t seg_len)
+                                                         float4* __restrict__ partial, uint32_t* __restrict__ queue,
+                                                         BinGrid g, float eps, uint32_t seg_len)
 {
-    __shared__ float4 s_rec[CHUNK][2];
+    __shared__ float4 s_ra[CHUNK];   // cx, cy, ux, uy
+    __shared__ float4 s_rb[CHUNK];   // wx, wy, log2(opacity), red
+    __shared__ float2 s_rc[CHUNK];   // green, blue
     __shared__ uint32_t s_mask[CHUNK];
     __shared__ uint32_t s_done;
+    __shared__ uint32_t s_item;
 
     const int nbxb = g.bx_hi - g.bx_lo, nbins = nbxb * g.nby;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lx = lane & 7, ly = lane >> 3;
     const uint32_t total_items = seg_start[nbins];
 
-    for (uint32_t item = blockIdx.x; item < total_items; item += gridDim.x) {
-        const uint32_t it = items[item];
+    // Work items come from one device-wide queue (items are ordered heaviest first), so a workgroup
+    // that drew light items simply draws more: no static assignment, no long pole.
+    for (;;) {
+        __syncthreads();  // the previous item no longer uses the LDS words
+        if (threadIdx.x == 0) {
+            s_item = atomicAdd(queue, 1u);
+            s_done = 0;
+        }
+        __syncthreads();
+        const uint32_t qi = s_item;
+        if (qi >= total_items) break;
+        const uint32_t it = items[qi];
         const int bin = (int)(it & 0xffffu);
         const uint32_t seg = it >> 16;
         const uint32_t nseg = seg_start[bin + 1] - seg_start[bin];
@@ -68,14 +82,17 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t* __restr
         const uint32_t bin_end = bin_start[bin + 1];
         const uint32_t begin = min(bin_start[bin] + seg * seg_len, bin_end);
         const uint32_t end = min(begin + seg_len, bin_end);
-        __syncthreads();  // the previous item no longer uses the LDS words
-        if (threadIdx.x == 0) s_done = 0;
         bool done = false;
 
         for (uint32_t base = begin; base < end; base += CHUNK) {
             __syncthreads();  // previous chunk fully consumed (and s_done visible)
             if (s_done == BLEND_THREADS / WAVE) break;  // every tile of the bin is saturated
-            // ---- stage one entry per thread ----
+            // ---- stage one entry per thread: record, unpacked colour, and a 16-bit mask of the bin's
+            //      8x8-pixel quadrants the splat can touch (bit = tile*4 + quadrant).  The mask is a
+            //      conservative cull only: a quadrant is dropped when the splat's pixel box misses it, when
+            //      it lies outside the oriented box |vPosition.x|,|vPosition.y| <= 2 (separating axes u, w),
+            //      or farther from the centre than the longer semi-axis.  Pixels that pass are still
+            //      tested exactly (q <= 4) below. ----
             const uint32_t e = base + threadIdx.x;
             uint32_t mask = 0;
             if (e < end) {
@@ -84,11 +101,41 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t* __restr
                 const float4 ra = rp[0], rb = rp[1];
                 const uint2 bb = bbox[i];
                 const int px0 = bb.x & 0xffff, px1 = bb.x >> 16, py0 = bb.y & 0xffff, py1 = bb.y >> 16;
-                const uint32_t mx = (px0 <= binX0 + TILE - 1 ? 1u : 0u) | (px1 >= binX0 + TILE ? 2u : 0u);
-                const uint32_t my = (py0 <= binY0 + TILE - 1 ? 1u : 0u) | (py1 >= binY0 + TILE ? 2u : 0u);
-                mask = ((my & 1u) ? mx : 0u) | ((my & 2u) ? (mx << 2) : 0u);  // bit (ty*2 + tx)
-                s_rec[threadIdx.x][0] = ra;
-                s_rec[threadIdx.x][1] = rb;
+                const float aux = fabsf(ra.z), auy = fabsf(ra.w), awx = fabsf(rb.x), awy = fabsf(rb.y);
+                const float eu = 3.5f * (aux + auy) + 2.0005f, ew = 3.5f * (awx + awy) + 2.0005f;
+                const float minlen2 = fminf(ra.z * ra.z + ra.w * ra.w, rb.x * rb.x + rb.y * rb.y);
+                float ucol[4], wcol[4], dcol[4];
+                uint32_t colok = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int qx = binX0 + 8 * k;
+                    const float dc = (float)(qx + 4) - ra.x;
+                    ucol[k] = ra.z * dc; wcol[k] = rb.x * dc;
+                    const float dd = fmaxf(fabsf(dc) - 3.5f, 0.0f);
+                    dcol[k] = dd * dd;
+                    if (px0 <= qx + 7 && px1 >= qx) colok |= 1u << k;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int qy = binY0 + 8 * r;
+                    if (!(py0 <= qy + 7 && py1 >= qy)) continue;
+                    const float dc = (float)(qy + 4) - ra.y;
+                    const float ur = ra.w * dc, wr = rb.y * dc;
+                    const float dd = fmaxf(fabsf(dc) - 3.5f, 0.0f);
+                    const float d2 = dd * dd;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const bool hit = ((colok >> k) & 1u) && fabsf(ucol[k] + ur) <= eu && fabsf(wcol[k] + wr) <= ew &&
+                                         (dcol[k] + d2) * minlen2 <= 4.002f;
+                        // quadrant (k, r) of the bin -> tile (k>>1, r>>1), quadrant (k&1, r&1)
+                        if (hit) mask |= 1u << ((((r >> 1) * 2 + (k >> 1)) << 2) + ((r & 1) * 2 + (k & 1)));
+                    }
+                }
+                const uint32_t rgb8 = __float_as_uint(rb.w);
+                s_ra[threadIdx.x] = ra;
+                s_rb[threadIdx.x] = make_float4(rb.x, rb.y, rb.z, (float)(rgb8 & 0xffu) * (1.0f / 255.0f));
+                s_rc[threadIdx.x] = make_float2((float)((rgb8 >> 8) & 0xffu) * (1.0f / 255.0f),
+                                                (float)((rgb8 >> 16) & 0xffu) * (1.0f / 255.0f));
             }
             s_mask[threadIdx.x] = mask;
             __syncthreads();
@@ -96,47 +143,42 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t* __restr
             if (!done) {
                 const uint32_t cnt = min((uint32_t)CHUNK, end - base);
                 for (uint32_t c0 = 0; c0 < cnt; c0 += WAVE) {
-                    uint64_t bal = __ballot((s_mask[c0 + lane] >> wave) & 1u);
+                    const uint32_t mine = (s_mask[c0 + lane] >> (wave * 4)) & 15u;  // entry (c0+lane) vs my tile
+                    uint64_t bal = __ballot(mine != 0u);
                     while (bal) {
                         const int j = __builtin_ctzll(bal);
                         bal &= bal - 1;
-                        const float4 ra = s_rec[c0 + j][0];
-                        const float4 rb = s_rec[c0 + j][1];
+                        const uint32_t qm = __builtin_amdgcn_readlane(mine, j);  // wave-uniform quadrant mask
+                        const float4 ra = s_ra[c0 + j];
+                        const float4 rb = s_rb[c0 + j];
+                        const float2 rc = s_rc[c0 + j];
+                        const float cr = rb.w, cg = rc.x, cb = rc.y;
                         const float dx0 = pxf0 - ra.x, dx1 = pxf1 - ra.x;
                         const float dy0 = pyf0 - ra.y, dy1 = pyf1 - ra.y;
                         const float uy0 = ra.w * dy0, uy1 = ra.w * dy1;
                         const float wy0 = rb.y * dy0, wy1 = rb.y * dy1;
-                        const float vx00 = __builtin_fmaf(ra.z, dx0, uy0), vy00 = __builtin_fmaf(rb.x, dx0, wy0);
-                        const float vx10 = __builtin_fmaf(ra.z, dx1, uy0), vy10 = __builtin_fmaf(rb.x, dx1, wy0);
-                        const float vx01 = __builtin_fmaf(ra.z, dx0, uy1), vy01 = __builtin_fmaf(rb.x, dx0, wy1);
-                        const float vx11 = __builtin_fmaf(ra.z, dx1, uy1), vy11 = __builtin_fmaf(rb.x, dx1, wy1);
-                        const float q00 = __builtin_fmaf(vy00, vy00, vx00 * vx00);
-                        const float q10 = __builtin_fmaf(vy10, vy10, vx10 * vx10);
-                        const float q01 = __builtin_fmaf(vy01, vy01, vx01 * vx01);
-                        const float q11 = __builtin_fmaf(vy11, vy11, vx11 * vx11);
                         // frag.glsl.ts:15  if (A < -4.0) discard;   (A = -q)
-                        const bool in00 = q00 <= 4.0f, in10 = q10 <= 4.0f, in01 = q01 <= 4.0f, in11 = q11 <= 4.0f;
-                        if (__ballot(in00 || in10 || in01 || in11) == 0ull) continue;  // wave-uniform
-                        const uint32_t rgb8 = __float_as_uint(rb.w);
-                        const float cr = (float)(rgb8 & 0xffu) * (1.0f / 255.0f);
-                        const float cg = (float)((rgb8 >> 8) & 0xffu) * (1.0f / 255.0f);
-                        const float cb = (float)((rgb8 >> 16) & 0xffu) * (1.0f / 255.0f);
                         // frag.glsl.ts:16-20  B = clamp(exp(A) * opacity, 0, 1)  (never clamps: exp(A) <= 1, opacity <= 1)
                         // blend: dst += (1 - dst.a) * (B*rgb, B)
-#define GSR_BLEND_PX(IN, Q, T, R, G, B_)                                                         \
-    {                                                                                            \
-        const float e_ = (IN) ? __builtin_amdgcn_exp2f(__builtin_fmaf((Q), -LOG2E, rb.z)) : 0.0f; \
-        const float w_ = (T) * e_;                                                               \
-        (T) = (T) - w_;                                                                          \
-        (R) = __builtin_fmaf(w_, cr, (R));                                                       \
-        (G) = __builtin_fmaf(w_, cg, (G));                                                       \
-        (B_) = __builtin_fmaf(w_, cb, (B_));                                                     \
+#define GSR_QUAD(BIT, DX, UY, WY, T, R, G, B_)                                                        \
+    if (qm & (BIT)) {                                                                                 \
+        const float vx_ = __builtin_fmaf(ra.z, (DX), (UY)), vy_ = __builtin_fmaf(rb.x, (DX), (WY));   \
+        const float q_ = __builtin_fmaf(vy_, vy_, vx_ * vx_);                                         \
+        const bool in_ = q_ <= 4.0f;                                                                  \
+        if (__ballot(in_) != 0ull) {                                                                  \
+            const float e_ = in_ ? __builtin_amdgcn_exp2f(__builtin_fmaf(q_, -LOG2E, rb.z)) : 0.0f;   \
+            const float w_ = (T) * e_;                                                                \
+            (T) = (T) - w_;                                                                           \
+            (R) = __builtin_fmaf(w_, cr, (R));                                                        \
+            (G) = __builtin_fmaf(w_, cg, (G));                                                        \
+            (B_) = __builtin_fmaf(w_, cb, (B_));                                                      \
+        }                                                                                             \
     }
-                        GSR_BLEND_PX(in00, q00, T00, r00, g00, b00)
-                        GSR_BLEND_PX(in10, q10, T10, r10, g10, b10)
-                        GSR_BLEND_PX(in01, q01, T01, r01, g01, b01)
-                        GSR_BLEND_PX(in11, q11, T11, r11, g11, b11)
-#undef GSR_BLEND_PX
+                        GSR_QUAD(1u, dx0, uy0, wy0, T00, r00, g00, b00)
+                        GSR_QUAD(2u, dx1, uy0, wy0, T10, r10, g10, b10)
+                        GSR_QUAD(4u, dx0, uy1, wy1, T01, r01, g01, b01)
+                        GSR_QUAD(8u, dx1, uy1, wy1, T11, r11, g11, b11)
+#undef GSR_QUAD
                     }
                     if (eps > 0.0f) {
                         const float tmax = fmaxf(fmaxf(T00, T10), fmaxf(T01, T11));
@@ -163,7 +205,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t* __restr
             }
         } else {
             // ---- partial (colour, transmittance) of this segment, slot-major: fully coalesced ----
-            float4* p = partial + (size_t)item * BIN_PIXELS + wave * (TILE * TILE) + lane;
+            float4* p = partial + (size_t)(seg_start[bin] + seg) * BIN_PIXELS + wave * (TILE * TILE) + lane;
             p[0] = make_float4(r00, g00, b00, T00);
             p[64] = make_float4(r10, g10, b10, T10);
             p[128] = make_float4(r01, g01, b01, T01);
@@ -206,7 +248,7 @@ void launch_blend(const BlendBuffers& b, const BinGrid& g, float early_out_eps, 
     const int nbins = (g.bx_hi - g.bx_lo) * g.nby;
     if (nbins <= 0) return;
     hipLaunchKernelGGL(k_blend, dim3(b.grid), dim3(BLEND_THREADS), 0, s, b.items, b.seg_start, b.bin_start, b.list, b.rec,
-                       b.bbox, b.fb, b.partial, g, early_out_eps, b.seg_len);
+                       b.bbox, b.fb, b.partial, b.queue, g, early_out_eps, b.seg_len);
     if (b.seg_len < 0x40000000u)
         hipLaunchKernelGGL(k_combine, dim3(nbins), dim3(BLEND_THREADS), 0, s, b.seg_start, (const float4*)b.partial, b.fb, g);
 }

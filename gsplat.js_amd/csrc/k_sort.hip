@@ -177,13 +177,15 @@ __global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint32_t* __rest
         const uint32_t digit = (key >> SHIFT) & (BINS - 1);
         const uint64_t m = match_digit<BITS>(digit, valid);
         const uint32_t rank = lanes_below(m);
-        // All lanes read their digit's running destination, THEN the lowest lane of every
-        // group of equal digits advances it.  One wave, LDS is in order; the volatile
-        // accesses and wave barriers keep the compiler from sinking the read below the write.
-        volatile uint32_t* wc = cnt[wave];
+        // All lanes read their digit's running destination, THEN the lowest lane of every group of
+        // equal digits advances it.  One wave, its own LDS words: LDS executes in order, and the
+        // wavefront-scope fences keep the compiler from moving the read below the write.
+        uint32_t* wc = cnt[wave];
         const uint32_t start = wc[digit];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (valid && rank == 0) wc[digit] = start + (uint32_t)__popcll(m);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (valid) {
             const uint32_t dst = start + rank;
