@@ -1,0 +1,106 @@
+"use strict";
+// HIPRenderer: drop-in for the render path of src/renderers/WebGLRenderer.ts on an AMD MI355X.
+//   renderer.render(scene, camera) = camera.update + depth sort + projection + front-to-back composite,
+// all on one HIP stream through libgsplat_hip.so (see include/gsplat_hip.h).  Differences from the WebGL
+// renderer, all forced by the missing browser: no `domElement`/`gl`; the image is read back with readPixels() /
+// readPixelsFloat(); the sort is synchronous with the frame (the reference sorts in a worker and draws with a
+// stale order until it finishes, WebGLRenderer.ts:105-110,223-229), so every frame is deterministic.
+// There is no CPU fallback: the constructor throws if the addon or a GPU is missing.
+const path = require("path");
+const { FadeInPass } = require("./FadeInPass");
+
+let native = null;
+function loadNative() {
+    if (!native) {
+        try {
+            native = require(path.join(__dirname, "..", "native", "gsplat_hip.node"));
+        } catch (e) {
+            throw new Error("gsplat_hip.node is not built or libgsplat_hip.so cannot be loaded (" + e.message +
+                            "); run `python -c \"import __graft_entry__ as g; g.build()\"`");
+        }
+    }
+    return native;
+}
+
+class HIPRenderer {
+    // new HIPRenderer(canvasLike | options | null, shaderPasses | null)
+    //   canvasLike: anything with numeric width/height (stands in for the HTMLCanvasElement of WebGLRenderer.ts:23)
+    //   options: { width, height, device, earlyOutEps, band: [x0, x1], timing }
+    constructor(target, optionalShaderPasses) {
+        const o = target || {};
+        this._n = loadNative();
+        this.width = o.width || 1920;
+        this.height = o.height || 1080;
+        const band = o.band || [0, 0];
+        this._h = this._n.create({ device: o.device || 0, width: this.width, height: this.height,
+                                   earlyOutEps: o.earlyOutEps || 0, bandX0: band[0], bandX1: band[1], timing: o.timing ? 1 : 0 });
+        const passes = optionalShaderPasses || [];
+        if (!optionalShaderPasses) passes.push(new FadeInPass());
+        let activeScene = null, activeCamera = null, initialized = false, vertexCount = 0;
+        const f32 = { view: new Float32Array(16), proj: new Float32Array(16), vp: new Float32Array(16) };
+
+        const upload = () => {   // initWebGL's scene part: worker init + texImage2D (WebGLRenderer.ts:105-110,185-195)
+            vertexCount = activeScene.vertexCount;
+            this._n.setScene(this._h, activeScene.data, activeScene.positions, vertexCount);
+            for (const p of passes) p.init(this, null);
+            initialized = true;
+        };
+        const onSceneChange = () => upload();   // WebGLRenderer.ts:234-239
+
+        this.setSize = (width, height) => {     // WebGLRenderer.ts:85-102
+            this.width = width;
+            this.height = height;
+            this._n.resize(this._h, width, height);
+        };
+        this.resize = () => {};                  // no DOM: nothing to measure
+        this.setBand = (x0, x1) => this._n.setBand(this._h, x0, x1);
+
+        const pushCamera = () => {               // uniforms + postMessage({viewProj}) (WebGLRenderer.ts:144-159,268-269,275)
+            activeCamera.update(this.width, this.height);
+            f32.view.set(activeCamera.viewMatrix.buffer);         // f64 -> f32 exactly like new Float32Array(m.buffer)
+            f32.proj.set(activeCamera.projectionMatrix.buffer);
+            f32.vp.set(activeCamera.viewProj.buffer);
+            this._n.setCamera(this._h, f32.view, f32.proj, f32.vp, activeCamera.fx, activeCamera.fy);
+        };
+        this.setCameraBuffers = () => pushCamera();
+
+        // WebGLRenderer.ts:241-296
+        this.render = (scene, camera) => {
+            activeCamera = camera;
+            if (scene !== activeScene) {
+                if (activeScene) activeScene.removeEventListener("change", onSceneChange);
+                activeScene = scene;
+                activeScene.addEventListener("change", onSceneChange);
+                upload();
+            }
+            pushCamera();
+            for (const p of passes) p.render();
+            this._n.render(this._h);
+        };
+        this.sort = (camera) => {                // the worker's job alone (Worker.ts:36-43)
+            if (camera) { activeCamera = camera; pushCamera(); }
+            this._n.sort(this._h);
+        };
+        this.dispose = () => {                   // WebGLRenderer.ts:298-310
+            if (activeScene) activeScene.removeEventListener("change", onSceneChange);
+            activeScene = null;
+            if (this._h) { this._n.destroy(this._h); this._h = null; }
+            initialized = false;
+        };
+
+        // ---- results ----
+        this.lastDepthIndex = () => { const a = new Uint32Array(vertexCount); this._n.readDepthIndex(this._h, a); return a; };
+        this.readPixels = () => { const a = new Uint8Array(this.width * this.height * 4); this._n.readPixels(this._h, a, this.width, this.height); return a; };
+        this.readPixelsFloat = () => { const a = new Float32Array(this.width * this.height * 4); this._n.readPixels(this._h, a, this.width, this.height); return a; };
+        this.stats = () => this._n.getTimings(this._h);
+        this.deviceInfo = () => this._n.deviceInfo(this._h);
+        this.isInitialized = () => initialized;
+    }
+}
+
+// the wasm export's drop-in (wasm/wasm.cpp:8-13, call site Worker.ts:39)
+function sortHost(viewProj, vertexCount, fBuffer, depthBuffer, depthIndex) {
+    loadNative().sortHost(viewProj, vertexCount, fBuffer, depthBuffer || null, depthIndex);
+}
+
+module.exports = { HIPRenderer, sortHost };

@@ -1,0 +1,76 @@
+#!/usr/bin/env node
+// Driver used by tests/test_js_host.py: exercises the JavaScript host through its public API and dumps
+// binary results for the Python side to compare with the oracle.
+"use strict";
+const fs = require("fs");
+const path = require("path");
+const G = require(path.join(__dirname, "..", "..", "gsplat.js_amd", "js"));
+
+const [, , mode, ...a] = process.argv;
+const writeBin = (file, typed) => fs.writeFileSync(file, Buffer.from(typed.buffer, typed.byteOffset, typed.byteLength));
+
+function orbitCamera(k, frames, fx) {
+    const cam = new G.Camera(undefined, undefined, fx, fx);
+    G.OrbitControls.applyPose(cam, (2 * Math.PI * k) / frames, 0.3, 8, new G.Vector3(0, 0, 0));
+    return cam;
+}
+
+if (mode === "pack") {                     // pack <splat> <outprefix> <W> <H> <fx> <pose...>
+    const [file, out, W, H, fx, ...poses] = a;
+    const scene = new G.Scene();
+    let events = 0;
+    scene.addEventListener("change", () => events++);
+    G.Loader.LoadSync(file, scene);
+    writeBin(out + ".data.bin", scene.data);
+    writeBin(out + ".pos.bin", scene.positions);
+    const cams = poses.map((k) => {
+        const cam = orbitCamera(+k, 120, +fx);
+        cam.update(+W, +H);
+        return { pose: +k, position: cam.position.flat(), rotation: cam.rotation.flat(), view: cam.viewMatrix.buffer,
+                 proj: cam.projectionMatrix.buffer, viewProj: cam.viewProj.buffer };
+    });
+    // transforms: translate, rotate, scale, limitBox on a copy
+    const s2 = new G.Scene();
+    G.Loader.LoadSync(file, s2);
+    s2.translate(new G.Vector3(0.25, -0.5, 1));
+    s2.rotate(G.Quaternion.FromEuler(new G.Vector3(0.1, 0.2, 0.3)));
+    s2.scale(new G.Vector3(1.5, 1.5, 1.5));
+    s2.limitBox(-4, 4, -4, 4, -4, 4);
+    writeBin(out + ".xf.splat", s2.toSplatBytes());
+    writeBin(out + ".xf.data.bin", s2.data);
+    fs.writeFileSync(out + ".json", JSON.stringify({ events, vertexCount: scene.vertexCount, width: scene.width, height: scene.height,
+                                                     dataLength: scene.data.length, cams, xfCount: s2.vertexCount }));
+} else if (mode === "render") {            // render <splat> <outprefix> <W> <H> <fx> <pose> [eps]
+    const [file, out, W, H, fx, pose, eps] = a;
+    const scene = new G.Scene();
+    G.Loader.LoadSync(file, scene);
+    const r = new G.WebGLRenderer({ width: +W, height: +H, earlyOutEps: eps ? +eps : 0, timing: true });
+    const cam = orbitCamera(+pose, 120, +fx);
+    r.render(scene, cam);
+    writeBin(out + ".depthIndex.bin", r.lastDepthIndex());
+    writeBin(out + ".rgba32f.bin", r.readPixelsFloat());
+    writeBin(out + ".rgba8.bin", r.readPixels());
+    // scene mutation must trigger a re-upload through the "change" event (WebGLRenderer.ts:234-239)
+    scene.translate(new G.Vector3(0.5, 0, 0));
+    r.render(scene, cam);
+    writeBin(out + ".moved.depthIndex.bin", r.lastDepthIndex());
+    writeBin(out + ".moved.pos.bin", scene.positions);
+    // wasm drop-in
+    const di = new Uint32Array(scene.vertexCount), keys = new Uint32Array(scene.vertexCount);
+    G.sortHost(new Float32Array(cam.viewProj.buffer), scene.vertexCount, scene.positions, keys, di);
+    writeBin(out + ".sortHost.depthIndex.bin", di);
+    fs.writeFileSync(out + ".json", JSON.stringify({ stats: r.stats(), device: r.deviceInfo(), viewProj: cam.viewProj.buffer }));
+    r.dispose();
+} else if (mode === "nodevice") {
+    try {
+        new G.HIPRenderer({ width: 64, height: 64 });
+        console.log("CREATED");
+    } catch (e) {
+        console.log("THROWN:" + e.message);
+    }
+} else if (mode === "api") {
+    console.log(JSON.stringify(Object.keys(G).sort()));
+} else {
+    console.error("unknown mode");
+    process.exit(2);
+}

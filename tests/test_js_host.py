@@ -1,0 +1,105 @@
+"""The JavaScript host (gsplat.js_amd/js, the reference's own language) driven through Node.
+CPU part: Scene.setData / transforms / Camera.update bits against the oracle and the Python mirror, the
+export list of src/index.ts, and the loud failure without a GPU.  GPU part: renderer.render(scene, camera)
+through the N-API addon against the oracle."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "tests", "js", "host_check.js")
+NODE = shutil.which("node")
+ADDON = os.path.join(ROOT, "gsplat.js_amd", "js", "native", "gsplat_hip.node")
+
+pytestmark = pytest.mark.skipif(NODE is None, reason="node is not installed")
+
+
+def run(*args):
+    r = subprocess.run([NODE, DRIVER] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout
+
+
+def test_export_list_matches_reference_index():
+    names = json.loads(run("api"))
+    for n in ["Camera", "Scene", "Loader", "WebGLRenderer", "OrbitControls", "Quaternion", "Vector3", "Matrix4", "Matrix3",
+              "ShaderPass", "FadeInPass"]:   # src/index.ts:1-12 minus PLYLoader (out of scope)
+        assert n in names
+
+
+def test_scene_and_camera_bits(tmp_path, oracle):
+    import gsplat_hip as gh
+    rows = gh.synth.synth_rows(5000, 123)
+    f = tmp_path / "s.splat"
+    rows.tofile(f)
+    out = str(tmp_path / "o")
+    poses = (0, 31, 77)
+    run("pack", f, out, 1920, 1080, 1132, *poses)
+    meta = json.load(open(out + ".json"))
+    data, pos = oracle.scene_pack(rows)
+    jdata = np.fromfile(out + ".data.bin", dtype=np.uint32)
+    assert meta["events"] == 1 and meta["vertexCount"] == 5000 and meta["width"] == 2048
+    assert jdata.size == meta["dataLength"] == 2048 * meta["height"] * 4
+    assert np.array_equal(jdata[:data.size], data) and not jdata[data.size:].any()
+    assert np.array_equal(np.fromfile(out + ".pos.bin", dtype=np.float32), pos)
+    # Camera.update: JS f64 matrices equal the Python mirror's (same formulas, same order) to the last bit,
+    # except the trigonometric pose inputs, which may differ by an ulp between V8 and libm
+    for cam_js in meta["cams"]:
+        cam = gh.Camera(tuple(cam_js["position"]), tuple(cam_js["rotation"])).update(1920, 1080)
+        assert cam.viewMatrix == cam_js["view"]
+        assert cam.projectionMatrix == cam_js["proj"]
+        assert cam.viewProj == cam_js["viewProj"]
+        ref = gh.orbit_camera(cam_js["pose"])
+        assert np.allclose(ref.viewProj, cam_js["viewProj"], rtol=0, atol=1e-12)
+    # transforms: re-serialised rows re-pack (through the oracle) to what the JS scene holds
+    xf = np.fromfile(out + ".xf.splat", dtype=np.uint8)
+    assert xf.size == meta["xfCount"] * 32 and 0 < meta["xfCount"] < 5000
+    xdata = np.fromfile(out + ".xf.data.bin", dtype=np.uint32).reshape(-1, 8)[:meta["xfCount"]]
+    odata = oracle.scene_pack(xf)[0].reshape(-1, 8)
+    assert np.array_equal(xdata[:, [0, 1, 2, 7]], odata[:, [0, 1, 2, 7]])       # positions and colours survive exactly
+
+
+def test_js_renderer_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    if not os.path.exists(ADDON):
+        pytest.skip("addon not built")
+    out = run("nodevice")
+    assert out.startswith("THROWN:") and "no HIP device" in out
+
+
+@pytest.mark.gpu
+def test_js_render_matches_oracle(tmp_path, oracle):
+    import gsplat_hip as gh
+    cfg = gh.synth.CONFIGS["C1"]
+    rows = gh.synth.config_rows("C1")
+    f = tmp_path / "c1.splat"
+    rows.tofile(f)
+    out = str(tmp_path / "r")
+    run("render", f, out, cfg["width"], cfg["height"], cfg["fx"], 9)
+    meta = json.load(open(out + ".json"))
+    data, pos = oracle.scene_pack(rows)
+    # the exact camera the JS host used (its f64 viewProj), rounded to f32 like Float32Array(buffer)
+    vp = np.asarray(meta["viewProj"], dtype=np.float32)
+    odi, _, _ = oracle.sort(vp, pos)
+    assert np.array_equal(np.fromfile(out + ".depthIndex.bin", dtype=np.uint32), odi)
+    assert np.array_equal(np.fromfile(out + ".sortHost.depthIndex.bin", dtype=np.uint32), odi)
+    cam = gh.orbit_camera(9, width=cfg["width"], height=cfg["height"], fx=cfg["fx"])
+    v, p, vp2 = cam.f32()
+    oimg = oracle.render_scene(data, pos, v, p, vp2, cam.fx, cam.fy, cfg["width"], cfg["height"], mode=1)[0]
+    img = np.fromfile(out + ".rgba32f.bin", dtype=np.float32).reshape(cfg["height"], cfg["width"], 4)
+    # V8's and libm's sin/cos may differ by an ulp in the pose, hence a slightly wider bound than the 2e-4 of the
+    # Python-driven parity tests (which use bit-identical cameras on both sides)
+    assert np.abs(img.astype(np.float64) - oimg).max() <= 1e-3
+    img8 = np.fromfile(out + ".rgba8.bin", dtype=np.uint8).reshape(cfg["height"], cfg["width"], 4)
+    o8 = np.floor(np.clip(oimg.astype(np.float64), 0, 1) * 255.0 + 0.5).astype(np.int32)
+    assert np.abs(img8.astype(np.int32) - o8).max() <= 1
+    # scene.translate fired "change": the renderer re-uploaded and sorted the moved positions
+    moved = np.fromfile(out + ".moved.pos.bin", dtype=np.float32)
+    assert np.array_equal(np.fromfile(out + ".moved.depthIndex.bin", dtype=np.uint32), oracle.sort(vp, moved)[0])
+    assert meta["stats"]["n"] == cfg["n"] and meta["device"]["computeUnits"] > 0
