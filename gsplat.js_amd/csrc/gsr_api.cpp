@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -166,6 +167,10 @@ int alloc_bins(gsr_ctx* c)
         items_dirty = true;
     }
     c->seg_len = c->opt.early_out_eps > 0.0f ? SEG_LEN_WHOLE_BIN : SEG_LEN_EXACT;
+    if (const char* e = getenv("GSR_SEG_LEN")) {  // tuning knob: entries per compositor work item (multiple of 256)
+        const long v = atol(e);
+        if (v >= 256 && c->seg_len != SEG_LEN_WHOLE_BIN) c->seg_len = (uint32_t)(v / 256 * 256);
+    }
     const uint32_t want_items = nbins + c->bin_capacity / c->seg_len + 16;
     if (items_dirty || want_items > c->max_items) {
         c->max_items = want_items;

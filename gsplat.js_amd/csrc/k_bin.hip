@@ -127,22 +127,32 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_scan(uint32_t* __restrict__
 // (bin, segment of seg_len list entries), one per segment, at least one per bin; frame counters.
 // ---------------------------------------------------------------------------
 constexpr int FIN_THREADS = 1024;
+constexpr int FIN_WAVES = FIN_THREADS / WAVE;
 
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_scan, uint32_t* total)
+struct U3 { uint32_t a, b, c; };
+
+// exclusive scan of three independent u32 streams over the workgroup's FIN_THREADS threads; totals in *tot
+__device__ __forceinline__ U3 block_exclusive_scan3(U3 v, uint32_t (*s_w)[FIN_WAVES], U3* tot)
 {
-    // Hillis-Steele over FIN_THREADS values in LDS
-    s_scan[threadIdx.x] = v;
-    __syncthreads();
-    for (int off = 1; off < FIN_THREADS; off <<= 1) {
-        const uint32_t t = (threadIdx.x >= (unsigned)off) ? s_scan[threadIdx.x - off] : 0u;
-        __syncthreads();
-        s_scan[threadIdx.x] += t;
-        __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    U3 inc = v;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const uint32_t ta = __shfl_up(inc.a, off), tb = __shfl_up(inc.b, off), tc = __shfl_up(inc.c, off);
+        if (lane >= off) { inc.a += ta; inc.b += tb; inc.c += tc; }
     }
-    const uint32_t incl = s_scan[threadIdx.x];
-    *total = s_scan[FIN_THREADS - 1];
+    if (lane == WAVE - 1) { s_w[0][wave] = inc.a; s_w[1][wave] = inc.b; s_w[2][wave] = inc.c; }
     __syncthreads();
-    return incl - v;
+    U3 base = {0, 0, 0}, total = {0, 0, 0};
+#pragma unroll
+    for (int w = 0; w < FIN_WAVES; w++) {
+        const uint32_t xa = s_w[0][w], xb = s_w[1][w], xc = s_w[2][w];
+        if (w < wave) { base.a += xa; base.b += xb; base.c += xc; }
+        total.a += xa; total.b += xb; total.c += xc;
+    }
+    __syncthreads();
+    *tot = total;
+    return U3{base.a + inc.a - v.a, base.b + inc.b - v.b, base.c + inc.c - v.c};
 }
 
 __global__ __launch_bounds__(FIN_THREADS) void k_bin_finalize(const uint32_t* __restrict__ bin_total, int nbins,
@@ -153,23 +163,22 @@ __global__ __launch_bounds__(FIN_THREADS) void k_bin_finalize(const uint32_t* __
                                                               uint32_t* __restrict__ overflow, uint64_t* __restrict__ visible,
                                                               uint64_t* __restrict__ tile_entries, uint64_t* __restrict__ accum)
 {
-    __shared__ uint32_t s_scan[FIN_THREADS];
+    __shared__ uint32_t s_w[3][FIN_WAVES];
     const int per = (nbins + FIN_THREADS - 1) / FIN_THREADS;
     const int b0 = threadIdx.x * per, b1 = min(b0 + per, nbins);
     // Items are emitted heaviest first: every full segment (seg_len entries) before every partial or
     // empty one, so the compositor's queue hands out the long items while the chip is still full.
-    uint32_t sum = 0, segs = 0, fulls = 0;
+    U3 mine = {0, 0, 0};  // entries, segments, full segments of this thread's bins
     for (int b = b0; b < b1; b++) {
         const uint32_t c = bin_total[b];
-        sum += c;
-        segs += max(1u, (c + seg_len - 1) / seg_len);
-        fulls += c / seg_len;
+        mine.a += c;
+        mine.b += max(1u, (c + seg_len - 1) / seg_len);
+        mine.c += c / seg_len;
     }
-    uint32_t total_entries, total_items, total_full;
-    uint32_t ex = block_exclusive_scan(sum, s_scan, &total_entries);
-    uint32_t sx = block_exclusive_scan(segs, s_scan, &total_items);
-    uint32_t fx = block_exclusive_scan(fulls, s_scan, &total_full);
-    uint32_t px = total_full + (sx - fx);  // partial/empty items follow all full ones
+    U3 tot;
+    const U3 ex3 = block_exclusive_scan3(mine, s_w, &tot);
+    uint32_t ex = ex3.a, sx = ex3.b, fx = ex3.c;
+    uint32_t px = tot.c + (sx - fx);  // partial/empty items follow all full ones
     for (int b = b0; b < b1; b++) {
         const uint32_t c = bin_total[b];
         const uint32_t ns = max(1u, (c + seg_len - 1) / seg_len);
@@ -186,20 +195,17 @@ __global__ __launch_bounds__(FIN_THREADS) void k_bin_finalize(const uint32_t* __
         fx += nf;
         px += ns - nf;
     }
-    if (threadIdx.x == 0) {
-        bin_start[nbins] = total_entries;
-        seg_start[nbins] = min(total_items, max_items);
-    }
     // frame counters
-    uint32_t v = 0, t = 0;
-    for (uint32_t b = threadIdx.x; b < nblocks; b += FIN_THREADS) { v += blk_counts[b].x; t += blk_counts[b].y; }
-    uint32_t tv, tt;
-    block_exclusive_scan(v, s_scan, &tv);
-    block_exclusive_scan(t, s_scan, &tt);
+    U3 cnt = {0, 0, 0};
+    for (uint32_t b = threadIdx.x; b < nblocks; b += FIN_THREADS) { cnt.a += blk_counts[b].x; cnt.b += blk_counts[b].y; }
+    U3 ctot;
+    block_exclusive_scan3(cnt, s_w, &ctot);
     if (threadIdx.x == 0) {
-        *visible = tv;
-        *tile_entries = tt;
-        accum[0] += tv; accum[1] += total_entries; accum[2] += tt; accum[3] += 1;
+        bin_start[nbins] = tot.a;
+        seg_start[nbins] = min(tot.b, max_items);
+        *visible = ctot.a;
+        *tile_entries = ctot.b;
+        accum[0] += ctot.a; accum[1] += tot.a; accum[2] += ctot.b; accum[3] += 1;
     }
 }
 
@@ -262,13 +268,17 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_scatter(const uint32_t* __r
         }
     }
     __syncthreads();
-    // phase 3: per step, build the lane sets, rank, write, advance the running destinations.
-    // Everything below is one wave talking to its own LDS words; LDS executes a wave's operations in
-    // order, and the wavefront-scope fences keep the compiler from moving accesses across the sweeps.
-#define GSR_WAVE_SYNC()                                      \
-    do {                                                     \
+    // phase 3: per step of 64 ranks: (a) every lane ORs its bit into the column/row lane sets of its box and adds
+    // 1 to the running destination of every bin it covers; (b) it reads them back: the set of lanes covering bin
+    // (X,Y) is colmask[X] & rowmask[Y], the bin's first slot for this step is the advanced counter minus the
+    // set's size, and the lane's own slot adds the number of lower lanes in the set -- input order, no leader,
+    // no ordered atomics; (c) it clears the words it set.  One wave, its own LDS words: LDS executes a wave's
+    // operations in order, so (a) < (b) < (c) < next step's (a) needs no waiting, only the compiler kept from
+    // reordering (wavefront-scope fences).
+#define GSR_WAVE_ORDER()                                       \
+    do {                                                       \
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); \
-        __builtin_amdgcn_wave_barrier();                     \
+        __builtin_amdgcn_wave_barrier();                       \
     } while (0)
     const unsigned long long mybit = 1ull << lane;
 #pragma unroll
@@ -277,34 +287,26 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_scatter(const uint32_t* __r
         const bool any = __ballot(b.x0 <= b.x1) != 0ull;
         if (!any) continue;  // wave-uniform
         for (int x = b.x0; x <= b.x1; x++) atomicOr(&colm[x], mybit);
-        for (int y = b.y0; y <= b.y1 && b.x0 <= b.x1; y++) atomicOr(&rowm[y], mybit);
-        GSR_WAVE_SYNC();
-        // sweep 1: read running destination + rank for every covered bin, write the entries
+        for (int y = b.y0; y <= b.y1; y++) {
+            if (b.x0 <= b.x1) atomicOr(&rowm[y], mybit);
+            for (int x = b.x0; x <= b.x1; x++) atomicAdd(&mycnt[y * nbxb + x], 1u);
+        }
+        GSR_WAVE_ORDER();
         for (int y = b.y0; y <= b.y1; y++) {
             const uint64_t rm = rowm[y];
             for (int x = b.x0; x <= b.x1; x++) {
                 const uint64_t m = rm & colm[x];
-                const uint32_t dst = mycnt[y * nbxb + x] + lanes_below64(m);
+                const uint32_t dst = mycnt[y * nbxb + x] - (uint32_t)__popcll(m) + lanes_below64(m);
                 if (dst < capacity) list[dst] = idx[st];
                 else atomicOr(overflow, 1u);
             }
         }
-        GSR_WAVE_SYNC();
-        // sweep 2: the lowest lane of every bin's set advances that bin's running destination
-        for (int y = b.y0; y <= b.y1; y++) {
-            const uint64_t rm = rowm[y];
-            for (int x = b.x0; x <= b.x1; x++) {
-                const uint64_t m = rm & colm[x];
-                if ((m & (mybit - 1)) == 0ull) mycnt[y * nbxb + x] += (uint32_t)__popcll(m);
-            }
-        }
-        GSR_WAVE_SYNC();
-        // clear the words this lane set
+        GSR_WAVE_ORDER();
         for (int x = b.x0; x <= b.x1; x++) colm[x] = 0ull;
         for (int y = b.y0; y <= b.y1 && b.x0 <= b.x1; y++) rowm[y] = 0ull;
-        GSR_WAVE_SYNC();
+        GSR_WAVE_ORDER();
     }
-#undef GSR_WAVE_SYNC
+#undef GSR_WAVE_ORDER
 }
 
 void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s)

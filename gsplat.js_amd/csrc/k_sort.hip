@@ -39,8 +39,7 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t digit, bool valid)
 
 // ---------------------------------------------------------------------------
 // A2: q = (uint32)((float)(uint32)(depth - minDepth) * depthInv), plus the
-// workgroup histogram of the pass-1 digit (and, through atomics, the global
-// digit totals of both passes).
+// workgroup histogram of the pass-1 digit.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(SORT_THREADS) void k_quantise_hist(const int32_t* __restrict__ depth,
                                                                 const int32_t* __restrict__ minmax, uint32_t n,
@@ -49,11 +48,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_quantise_hist(const int32_t* _
                                                                 uint32_t* __restrict__ digit_total)
 {
     __shared__ uint32_t h_lo[RADIX_LO_BINS];
-    __shared__ uint32_t h_hi[RADIX_HI_BINS];
-    for (int d = threadIdx.x; d < RADIX_HI_BINS; d += SORT_THREADS) {
-        h_hi[d] = 0;
-        if (d < RADIX_LO_BINS) h_lo[d] = 0;
-    }
+    for (int d = threadIdx.x; d < RADIX_LO_BINS; d += SORT_THREADS) h_lo[d] = 0;
     __syncthreads();
 
     const int32_t minDepth = minmax[0], maxDepth = minmax[1];
@@ -70,18 +65,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_quantise_hist(const int32_t* _
         q = min(q, DEPTH_RANGE);
         keys[i] = q;
         atomicAdd(&h_lo[q & (RADIX_LO_BINS - 1)], 1u);
-        atomicAdd(&h_hi[q >> RADIX_LO_BITS], 1u);
     }
     __syncthreads();
-    for (int d = threadIdx.x; d < RADIX_HI_BINS; d += SORT_THREADS) {
-        if (d < RADIX_LO_BINS) {
-            const uint32_t c = h_lo[d];
-            block_hist[(size_t)blockIdx.x * RADIX_LO_BINS + d] = c;
-            if (c) atomicAdd(&digit_total[d], c);
-        }
-        const uint32_t c2 = h_hi[d];
-        if (c2) atomicAdd(&digit_total[RADIX_LO_BINS + d], c2);
-    }
+    for (int d = threadIdx.x; d < RADIX_LO_BINS; d += SORT_THREADS) block_hist[(size_t)blockIdx.x * RADIX_LO_BINS + d] = h_lo[d];
 }
 
 // Workgroup histogram of the pass-2 digit over the pass-1 output order.
@@ -99,22 +85,17 @@ __global__ __launch_bounds__(SORT_THREADS) void k_hist_hi(const uint32_t* __rest
 }
 
 // ---------------------------------------------------------------------------
-// One wave per digit d: base[b][d] = sum(total[d'] for d' < d) + sum(hist[b'][d] for b' < b).
-// In place over block_hist (block-major so the histogram and scatter kernels
-// touch it coalesced; this small kernel takes the strided accesses).
+// One wave per digit d: block_hist[b][d] <- keys with digit d in workgroups before b; total[d] = all of them.
+// In place over block_hist (block-major so the histogram and scatter kernels touch it coalesced; this small
+// kernel takes the strided accesses).  No global atomics anywhere in the sort.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(SORT_THREADS) void k_digit_scan(uint32_t* __restrict__ block_hist,
-                                                             const uint32_t* __restrict__ total, int nbins,
-                                                             uint32_t nblocks)
+                                                             uint32_t* __restrict__ total, int nbins, uint32_t nblocks)
 {
     const int lane = threadIdx.x & 63;
     const int d = blockIdx.x * SORT_WAVES + (threadIdx.x >> 6);
     if (d >= nbins) return;
-    uint32_t acc = 0;
-    for (int j = lane; j < d; j += WAVE) acc += total[j];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-    uint32_t run = acc;  // exclusive prefix over all smaller digits
+    uint32_t run = 0;
     for (uint32_t b0 = 0; b0 < nblocks; b0 += WAVE) {
         const uint32_t b = b0 + lane;
         const uint32_t v = (b < nblocks) ? block_hist[(size_t)b * nbins + d] : 0u;
@@ -127,6 +108,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_digit_scan(uint32_t* __restric
         if (b < nblocks) block_hist[(size_t)b * nbins + d] = run + incl - v;
         run += __shfl(incl, WAVE - 1);
     }
+    if (lane == 0) total[d] = run;
 }
 
 // ---------------------------------------------------------------------------
@@ -140,10 +122,14 @@ template <int BITS, int SHIFT, bool FIRST>
 __global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint32_t* __restrict__ keys_in,
                                                           const uint32_t* __restrict__ idx_in, uint32_t n,
                                                           uint32_t keys_per_block, const uint32_t* __restrict__ base,
+                                                          const uint32_t* __restrict__ total,
                                                           uint32_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out)
 {
     constexpr int BINS = 1 << BITS;
+    constexpr int PER = BINS / SORT_THREADS;  // digits per thread in the prologue (1 or 2)
     __shared__ uint32_t cnt[SORT_WAVES][BINS];
+    __shared__ uint32_t dstart[BINS];          // keys with a smaller digit, all workgroups
+    __shared__ uint32_t wsum[SORT_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int d = threadIdx.x; d < SORT_WAVES * BINS; d += SORT_THREADS) (&cnt[0][0])[d] = 0;
     __syncthreads();
@@ -158,9 +144,28 @@ __global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint32_t* __rest
         if (i < wend) atomicAdd(&cnt[wave][(keys_in[i] >> SHIFT) & (BINS - 1)], 1u);
     }
     __syncthreads();
-    // phase 2: cnt[w][d] <- global base of digit d for this workgroup + counts of earlier waves
+    // digit starts: exclusive scan of total[0..BINS) (thread t owns digits t*PER .. t*PER+PER-1)
+    {
+        uint32_t t[PER], s = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) { t[k] = total[threadIdx.x * PER + k]; s += t[k]; }
+        uint32_t incl = s;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const uint32_t u = __shfl_up(incl, off);
+            if (lane >= off) incl += u;
+        }
+        if (lane == WAVE - 1) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - s;
+        for (int w = 0; w < wave; w++) run += wsum[w];
+#pragma unroll
+        for (int k = 0; k < PER; k++) { dstart[threadIdx.x * PER + k] = run; run += t[k]; }
+    }
+    __syncthreads();
+    // phase 2: cnt[w][d] <- first destination of digit d for this workgroup + counts of earlier waves
     for (int d = threadIdx.x; d < BINS; d += SORT_THREADS) {
-        uint32_t run = base[(size_t)blockIdx.x * BINS + d];
+        uint32_t run = dstart[d] + base[(size_t)blockIdx.x * BINS + d];
 #pragma unroll
         for (int w = 0; w < SORT_WAVES; w++) {
             const uint32_t c = cnt[w][d];
@@ -199,18 +204,21 @@ void launch_sort(const SortBuffers& b, uint32_t n, hipStream_t s)
 {
     if (!n) return;
     const dim3 grid(b.nblocks), block(SORT_THREADS);
+    uint32_t* total_lo = b.digit_total;
+    uint32_t* total_hi = b.digit_total + RADIX_LO_BINS;
     hipLaunchKernelGGL(k_quantise_hist, grid, block, 0, s, b.depth, b.minmax, n, b.keys_per_block, b.keys, b.block_hist,
                        b.digit_total);
-    hipLaunchKernelGGL(k_digit_scan, dim3(RADIX_LO_BINS / SORT_WAVES), block, 0, s, b.block_hist, b.digit_total,
-                       RADIX_LO_BINS, b.nblocks);
+    hipLaunchKernelGGL(k_digit_scan, dim3(RADIX_LO_BINS / SORT_WAVES), block, 0, s, b.block_hist, total_lo, RADIX_LO_BINS,
+                       b.nblocks);
     hipLaunchKernelGGL((k_scatter<RADIX_LO_BITS, 0, true>), grid, block, 0, s, (const uint32_t*)b.keys,
-                       (const uint32_t*)nullptr, n, b.keys_per_block, (const uint32_t*)b.block_hist, b.keys_tmp, b.idx_tmp);
+                       (const uint32_t*)nullptr, n, b.keys_per_block, (const uint32_t*)b.block_hist,
+                       (const uint32_t*)total_lo, b.keys_tmp, b.idx_tmp);
     hipLaunchKernelGGL(k_hist_hi, grid, block, 0, s, (const uint32_t*)b.keys_tmp, n, b.keys_per_block, b.block_hist);
-    hipLaunchKernelGGL(k_digit_scan, dim3(RADIX_HI_BINS / SORT_WAVES), block, 0, s, b.block_hist,
-                       b.digit_total + RADIX_LO_BINS, RADIX_HI_BINS, b.nblocks);
+    hipLaunchKernelGGL(k_digit_scan, dim3(RADIX_HI_BINS / SORT_WAVES), block, 0, s, b.block_hist, total_hi, RADIX_HI_BINS,
+                       b.nblocks);
     hipLaunchKernelGGL((k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, false>), grid, block, 0, s, (const uint32_t*)b.keys_tmp,
                        (const uint32_t*)b.idx_tmp, n, b.keys_per_block, (const uint32_t*)b.block_hist,
-                       (uint32_t*)nullptr, b.depth_index);
+                       (const uint32_t*)total_hi, (uint32_t*)nullptr, b.depth_index);
 }
 
 }  // namespace gsr

@@ -1,11 +1,14 @@
+#!/bin/bash
+# One GPU-box visit: parity tests, bench (exact + early-out), kernel-trace profile.  Outputs under gpurun_out/.
 set -x
 cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
 tail -5 gpurun_out/pytest_gpu.log
 timeout -k 10 300 python bench.py --steps 240 --warmup 20 > gpurun_out/bench1.json 2> gpurun_out/bench1.err; echo "bench rc=$?"
-cat gpurun_out/bench1.json
 timeout -k 10 300 python bench.py --steps 240 --warmup 20 --early-out-eps 1e-4 --no-cpu-baseline > gpurun_out/bench1_eo.json 2>> gpurun_out/bench1.err; echo "bench eo rc=$?"
-cat gpurun_out/bench1_eo.json
+for seg in 256 1024; do
+  GSR_SEG_LEN=$seg timeout -k 10 300 python bench.py --steps 240 --warmup 20 --no-cpu-baseline > gpurun_out/bench1_seg$seg.json 2>> gpurun_out/bench1.err; echo "bench seg$seg rc=$?"
+done
+rm -rf gpurun_out/prof1
 cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof1 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 60 --warmup 10 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof1.log 2>&1; echo "prof rc=$?"
-find $GRAFT_REPO_ROOT/gpurun_out/prof1 -name "*stats*" | head
