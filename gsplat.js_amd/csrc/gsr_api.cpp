@@ -162,7 +162,7 @@ int alloc_bins(gsr_ctx* c)
         items_dirty = true;
     }
     if (!c->bin_capacity) {
-        c->bin_capacity = std::max<uint32_t>(4u * c->n + (1u << 20), 1u << 22);
+        c->bin_capacity = std::max<uint32_t>(6u * c->n + (1u << 20), 1u << 22);
         if (int r = dev_alloc(c, &c->bin_list, c->bin_capacity)) return r;
         items_dirty = true;
     }
@@ -233,7 +233,8 @@ int enqueue_frame(gsr_ctx* c, bool render)
         launch_bin(bb, g, c->n, s);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BIN], s));
         BlendBuffers bl{c->items, c->seg_start, c->bin_start, c->bin_list, c->rec, c->bbox, c->fb, c->partial,
-                        &c->fstate->queue, c->seg_len, std::min<uint32_t>(c->max_items, 2048u)};
+                        &c->fstate->queue, c->seg_len, std::min<uint32_t>(c->max_items, 2048u), c->bin_capacity,
+                        std::max(c->n, 1u)};
         launch_blend(bl, g, c->opt.early_out_eps, s);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BLEND], s));
     }
@@ -280,7 +281,7 @@ int check_frame_words(gsr_ctx* c, bool* overflowed)
     const BinGrid g = make_grid(c);
     const int nbins = (g.bx_hi - g.bx_lo) * g.nby;
     HIP_TRY(c, hipMemcpyAsync(&total, c->bin_start + nbins, 4, hipMemcpyDeviceToHost, c->stream));
-    uint64_t acc[4] = {0, 0, 0, 0};
+    uint64_t acc[5] = {0, 0, 0, 0, 0};
     HIP_TRY(c, hipMemcpyAsync(acc, c->accum, sizeof acc, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->tm.sum_visible = acc[0]; c->tm.sum_bin_entries = acc[1]; c->tm.sum_tile_entries = acc[2]; c->tm.sum_frames = acc[3];
@@ -290,7 +291,8 @@ int check_frame_words(gsr_ctx* c, bool* overflowed)
     c->tm.n = c->n;
     *overflowed = c->fstate_host->overflow != 0;
     if (*overflowed) {
-        const uint64_t want = (uint64_t)total + (total >> 2) + (1u << 20);
+        const uint64_t need = std::max<uint64_t>(acc[4], total);
+        const uint64_t want = need + (need >> 2) + (1u << 20);
         if (want > 0xfffffff0ull) return fail(c, GSR_ERR_OVERFLOW, "bin list would need %llu entries", (unsigned long long)want);
         c->bin_capacity = (uint32_t)want;
         if (int r = dev_alloc(c, &c->bin_list, c->bin_capacity)) return r;
@@ -335,8 +337,8 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
     CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CREATE_TRY(hipMalloc((void**)&c->fstate, sizeof(FrameState)));
     CREATE_TRY(hipMalloc((void**)&c->fstate_init, sizeof(FrameState)));
-    CREATE_TRY(hipMalloc((void**)&c->accum, 4 * sizeof(uint64_t)));
-    CREATE_TRY(hipMemset(c->accum, 0, 4 * sizeof(uint64_t)));
+    CREATE_TRY(hipMalloc((void**)&c->accum, 8 * sizeof(uint64_t)));
+    CREATE_TRY(hipMemset(c->accum, 0, 8 * sizeof(uint64_t)));
     CREATE_TRY(hipHostMalloc((void**)&c->fstate_host, sizeof(FrameState), hipHostMallocDefault));
     memset(c->fstate_host, 0, sizeof(FrameState));
     c->fstate_host->minmax[0] = 0x7fffffff;            // wasm/wasm.cpp:14

@@ -85,7 +85,7 @@ struct BinBuffers {
     uint32_t* overflow;          // bit 0: list too small, bit 1: item table too small
     uint64_t* visible;           // V counter
     uint64_t* tile_entries;      // D counter (16x16 tiles overlapped by visible bboxes)
-    uint64_t* accum;             // [4] running sums over frames: visible, bin entries, tile entries, frames
+    uint64_t* accum;             // [5] running sums over frames: visible, bin entries, tile entries, frames; [4] = entries the last frame needs
     uint32_t capacity;
     uint32_t max_items;
     uint32_t seg_len;            // list entries per compositor work item (multiple of 256)
@@ -105,6 +105,8 @@ struct BlendBuffers {
     uint32_t* queue;            // device-wide work-item counter, zero at frame start
     uint32_t seg_len;           // >= 0x40000000: one item per bin (early termination mode)
     uint32_t grid;              // persistent workgroups launched
+    uint32_t capacity;          // entries the list can hold
+    uint32_t nsplats;
 };
 void launch_blend(const BlendBuffers& b, const BinGrid& g, float early_out_eps, hipStream_t s);
 void launch_clear_fb(float4* fb, int32_t W, int32_t H, hipStream_t s);

@@ -4,16 +4,22 @@
 // No second sort of duplicated (tile, depth) pairs is needed: the split is a
 // stable counting pass (count -> scan -> scatter).
 //
-// Stability in the scatter: a wave walks 64 consecutive ranks at a time.  For
-// one step, the set of lanes whose box covers bin (X, Y) is
-//     colmask[X] & rowmask[Y]
+// Stability in the scatter: a wave owns 8 steps of 64 consecutive ranks.  For
+// step s, the set of lanes whose box covers bin (X, Y) is
+//     colmask[s][X] & rowmask[s][Y]
 // where colmask/rowmask are 64-bit lane sets built in LDS with ds_or_b64, one
 // word per bin column / bin row (boxes are rectangles, so coverage separates).
-// A splat's slot inside the step is the population count of that set below its
-// lane: wavefront ballot arithmetic, no atomics with ordering requirements.
+// A splat's slot in a bin is the wave's first slot there, plus the sizes of the
+// sets of the earlier steps, plus the population count of its own step's set
+// below its lane: wavefront ballot arithmetic, no atomics with ordering
+// requirements, and no running counter to update between steps.
 #include "gsr_internal.h"
 
 #include <algorithm>
+
+#ifndef GSR_EXP_STOP
+#define GSR_EXP_STOP 0   // experiment builds only (scripts/build_exp.sh): stop k_bin_scatter after phase k
+#endif
 
 namespace gsr {
 
@@ -156,7 +162,7 @@ __device__ __forceinline__ U3 block_exclusive_scan3(U3 v, uint32_t (*s_w)[FIN_WA
 }
 
 __global__ __launch_bounds__(FIN_THREADS) void k_bin_finalize(const uint32_t* __restrict__ bin_total, int nbins,
-                                                              uint32_t seg_len, uint32_t max_items,
+                                                              uint32_t seg_len, uint32_t max_items, uint32_t capacity,
                                                               const uint2* __restrict__ blk_counts, uint32_t nblocks,
                                                               uint32_t* __restrict__ bin_start,
                                                               uint32_t* __restrict__ seg_start, uint32_t* __restrict__ items,
@@ -179,17 +185,18 @@ __global__ __launch_bounds__(FIN_THREADS) void k_bin_finalize(const uint32_t* __
     const U3 ex3 = block_exclusive_scan3(mine, s_w, &tot);
     uint32_t ex = ex3.a, sx = ex3.b, fx = ex3.c;
     uint32_t px = tot.c + (sx - fx);  // partial/empty items follow all full ones
+    // A frame whose lists do not fit (entries > capacity or items > max_items) must not be composited:
+    // it publishes no work items at all (every index the compositor derives stays in range), raises the
+    // overflow word, and the host regrows the buffers and renders the frame again (gsr_sync).
+    const bool fits = tot.a <= capacity && tot.b <= max_items;
     for (int b = b0; b < b1; b++) {
         const uint32_t c = bin_total[b];
         const uint32_t ns = max(1u, (c + seg_len - 1) / seg_len);
         const uint32_t nf = c / seg_len;
-        bin_start[b] = ex;
-        seg_start[b] = sx;
-        if (sx + ns > max_items) atomicOr(overflow, 2u);
-        for (uint32_t k = 0; k < ns; k++) {
-            const uint32_t slot = (k < nf) ? fx + k : px;
-            if (slot < max_items) items[slot] = (uint32_t)b | (k << 16);
-        }
+        bin_start[b] = fits ? ex : 0u;
+        seg_start[b] = fits ? sx : 0u;
+        if (fits)
+            for (uint32_t k = 0; k < ns; k++) items[(k < nf) ? fx + k : px + (k - nf)] = (uint32_t)b | (k << 16);
         ex += c;
         sx += ns;
         fx += nf;
@@ -201,8 +208,10 @@ __global__ __launch_bounds__(FIN_THREADS) void k_bin_finalize(const uint32_t* __
     U3 ctot;
     block_exclusive_scan3(cnt, s_w, &ctot);
     if (threadIdx.x == 0) {
-        bin_start[nbins] = tot.a;
-        seg_start[nbins] = min(tot.b, max_items);
+        bin_start[nbins] = fits ? tot.a : 0u;
+        seg_start[nbins] = fits ? tot.b : 0u;
+        if (!fits) atomicOr(overflow, tot.a > capacity ? 1u : 2u);
+        accum[4] = tot.a;  // entries this frame needs (the host sizes the regrowth from it)
         *visible = ctot.a;
         *tile_entries = ctot.b;
         accum[0] += ctot.a; accum[1] += tot.a; accum[2] += ctot.b; accum[3] += 1;
@@ -224,15 +233,21 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_scatter(const uint32_t* __r
     extern __shared__ uint32_t s_mem[];
     const int nbxb = g.bx_hi - g.bx_lo, nbins = nbxb * g.nby;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t* cnt = s_mem;                                   // [BIN_WAVES][nbins]
-    // per-wave lane sets: [nbxb] column words then [nby] row words (8-byte aligned region)
+    // LDS: base[nbins] (u32: the workgroup's first slot in each bin), pair[2][nbins] (two 16-bit per-wave
+    // counts/offsets per word: waves 0|1 and 2|3; a wave holds 512 ranks, so 16 bits suffice), then the lane sets.
+    uint32_t* base = s_mem;
+    uint32_t* pair = s_mem + nbins;
     const int nmask = nbxb + g.nby;
-    uint64_t* masks = reinterpret_cast<uint64_t*>(s_mem + ((BIN_WAVES * nbins + 1) & ~1));
-    unsigned long long* colm = reinterpret_cast<unsigned long long*>(masks + (size_t)wave * nmask);
-    unsigned long long* rowm = colm + nbxb;
+    unsigned long long* masks = reinterpret_cast<unsigned long long*>(s_mem + ((3 * nbins + 1) & ~1));
+    unsigned long long* wmask = masks + (size_t)wave * BIN_STEPS * nmask;   // step s: wmask + s*nmask
+    // splat indices parked in LDS: phase 3 must not depend on registers filled by global loads, or the
+    // compiler fences every step with s_waitcnt vmcnt(0) and each step waits for the previous step's stores
+    uint32_t* sidx = reinterpret_cast<uint32_t*>(masks + (size_t)BIN_WAVES * BIN_STEPS * nmask) + wave * (BIN_STEPS * WAVE);
+    uint32_t* mypair = pair + (size_t)(wave >> 1) * nbins;
+    const int myshift = (wave & 1) * 16;
 
-    for (int b = threadIdx.x; b < BIN_WAVES * nbins; b += BIN_THREADS) cnt[b] = 0;
-    for (int b = threadIdx.x; b < BIN_WAVES * nmask; b += BIN_THREADS) masks[b] = 0;
+    for (int b = threadIdx.x; b < 2 * nbins; b += BIN_THREADS) pair[b] = 0;
+    for (int b = threadIdx.x; b < BIN_WAVES * BIN_STEPS * nmask; b += BIN_THREADS) masks[b] = 0;
     __syncthreads();
 
     // this wave's 8 steps of 64 consecutive ranks: indices and bin rectangles stay in registers
@@ -250,63 +265,74 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_scatter(const uint32_t* __r
         if (r < n) br[st] = bin_rect(bbox[idx[st]], g);
         else { br[st].x0 = 1; br[st].x1 = 0; br[st].y0 = 1; br[st].y1 = 0; }
     }
+#if GSR_EXP_STOP == 1
+    { uint32_t acc = 0; for (int st = 0; st < BIN_STEPS; st++) acc += idx[st] + br[st].x0 + br[st].y1; if (acc == 0xdeadbeefu) list[0] = acc; return; }
+#endif
+#pragma unroll
+    for (int st = 0; st < BIN_STEPS; st++) sidx[st * WAVE + lane] = idx[st];
     // phase 1: per-wave counts
-    uint32_t* mycnt = cnt + (size_t)wave * nbins;
+    const uint32_t one = 1u << myshift;
 #pragma unroll
     for (int st = 0; st < BIN_STEPS; st++)
         for (int y = br[st].y0; y <= br[st].y1; y++)
-            for (int x = br[st].x0; x <= br[st].x1; x++) atomicAdd(&mycnt[y * nbxb + x], 1u);
+            for (int x = br[st].x0; x <= br[st].x1; x++) atomicAdd(&mypair[y * nbxb + x], one);
     __syncthreads();
-    // phase 2: running destinations: workgroup base + earlier waves
+#if GSR_EXP_STOP == 2
+    if (capacity != 0xdeadbeefu) return;
+#endif
+    // phase 2: counts -> offsets of each wave inside the workgroup's run; workgroup base from the table
     for (int b = threadIdx.x; b < nbins; b += BIN_THREADS) {
-        uint32_t run = bin_start[b] + table[(size_t)blockIdx.x * nbins + b];
-#pragma unroll
-        for (int w = 0; w < BIN_WAVES; w++) {
-            const uint32_t c = cnt[(size_t)w * nbins + b];
-            cnt[(size_t)w * nbins + b] = run;
-            run += c;
-        }
+        base[b] = bin_start[b] + table[(size_t)blockIdx.x * nbins + b];
+        const uint32_t c01 = pair[b], c23 = pair[nbins + b];
+        const uint32_t o1 = c01 & 0xffffu, o2 = o1 + (c01 >> 16), o3 = o2 + (c23 & 0xffffu);
+        pair[b] = o1 << 16;                // wave 0: 0, wave 1: o1
+        pair[nbins + b] = o2 | (o3 << 16); // wave 2: o2, wave 3: o3
     }
     __syncthreads();
-    // phase 3: per step of 64 ranks: (a) every lane ORs its bit into the column/row lane sets of its box and adds
-    // 1 to the running destination of every bin it covers; (b) it reads them back: the set of lanes covering bin
-    // (X,Y) is colmask[X] & rowmask[Y], the bin's first slot for this step is the advanced counter minus the
-    // set's size, and the lane's own slot adds the number of lower lanes in the set -- input order, no leader,
-    // no ordered atomics; (c) it clears the words it set.  One wave, its own LDS words: LDS executes a wave's
-    // operations in order, so (a) < (b) < (c) < next step's (a) needs no waiting, only the compiler kept from
-    // reordering (wavefront-scope fences).
-#define GSR_WAVE_ORDER()                                       \
-    do {                                                       \
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); \
-        __builtin_amdgcn_wave_barrier();                       \
-    } while (0)
+#if GSR_EXP_STOP == 3
+    if (capacity != 0xdeadbeefu) return;
+#endif
+    // phase 3a: every lane ORs its bit into the column/row lane sets of its box, for all 8 steps at once
     const unsigned long long mybit = 1ull << lane;
+#ifdef GSR_EXP_NO_PHASE3
+    if (capacity != 0xdeadbeefu) return;
+#endif
 #pragma unroll
     for (int st = 0; st < BIN_STEPS; st++) {
         const BinRect b = br[st];
-        const bool any = __ballot(b.x0 <= b.x1) != 0ull;
-        if (!any) continue;  // wave-uniform
+        unsigned long long* colm = wmask + st * nmask;
+        unsigned long long* rowm = colm + nbxb;
         for (int x = b.x0; x <= b.x1; x++) atomicOr(&colm[x], mybit);
+        for (int y = b.y0; y <= b.y1 && b.x0 <= b.x1; y++) atomicOr(&rowm[y], mybit);
+    }
+#if GSR_EXP_STOP == 4
+    if (capacity != 0xdeadbeefu) return;
+#endif
+    // One wave talking to its own LDS words: LDS executes a wave's operations in order, so the reads
+    // below see every OR above; the fence only keeps the compiler from reordering across it.
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    // phase 3b: slots.  base[bin] + this wave's 16-bit offset = the wave's first slot in the bin.
+#pragma unroll
+    for (int st = 0; st < BIN_STEPS; st++) {
+        const BinRect b = br[st];
+        const uint32_t myidx = sidx[st * WAVE + lane];
         for (int y = b.y0; y <= b.y1; y++) {
-            if (b.x0 <= b.x1) atomicOr(&rowm[y], mybit);
-            for (int x = b.x0; x <= b.x1; x++) atomicAdd(&mycnt[y * nbxb + x], 1u);
-        }
-        GSR_WAVE_ORDER();
-        for (int y = b.y0; y <= b.y1; y++) {
-            const uint64_t rm = rowm[y];
             for (int x = b.x0; x <= b.x1; x++) {
-                const uint64_t m = rm & colm[x];
-                const uint32_t dst = mycnt[y * nbxb + x] - (uint32_t)__popcll(m) + lanes_below64(m);
-                if (dst < capacity) list[dst] = idx[st];
+                uint32_t dst = base[y * nbxb + x] + ((mypair[y * nbxb + x] >> myshift) & 0xffffu);
+#pragma unroll
+                for (int e = 0; e < st; e++)  // entries the earlier steps of this wave put into the bin
+                    dst += (uint32_t)__popcll(wmask[e * nmask + x] & wmask[e * nmask + nbxb + y]);
+                dst += lanes_below64(wmask[st * nmask + x] & wmask[st * nmask + nbxb + y]);
+#ifdef GSR_EXP_NO_LIST_STORE
+                if (dst == 0xffffffffu) list[0] = myidx;
+#else
+                if (dst < capacity) list[dst] = myidx;
                 else atomicOr(overflow, 1u);
+#endif
             }
         }
-        GSR_WAVE_ORDER();
-        for (int x = b.x0; x <= b.x1; x++) colm[x] = 0ull;
-        for (int y = b.y0; y <= b.y1 && b.x0 <= b.x1; y++) rowm[y] = 0ull;
-        GSR_WAVE_ORDER();
     }
-#undef GSR_WAVE_ORDER
 }
 
 void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s)
@@ -314,7 +340,8 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
     const int nbxb = g.bx_hi - g.bx_lo, nbins = nbxb * g.nby;
     if (nbins <= 0) return;
     const dim3 grid(b.nblocks), block(BIN_THREADS);
-    const size_t lds = (size_t)((BIN_WAVES * nbins + 1) & ~1) * 4 + (size_t)BIN_WAVES * (nbxb + g.nby) * 8;
+    const size_t lds = (size_t)((3 * nbins + 1) & ~1) * 4 + (size_t)BIN_WAVES * BIN_STEPS * (nbxb + g.nby) * 8 +
+                       (size_t)BIN_THREADS * BIN_STEPS * 4;
     // dynamic LDS above the 64 KiB default needs the attribute raised (4K: 8160 bins -> 130 KiB)
     static size_t lds_allowed = 64 * 1024;
     if (lds > lds_allowed) {
@@ -331,7 +358,7 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
                            b.nblocks);
     }
     hipLaunchKernelGGL(k_bin_finalize, dim3(1), dim3(FIN_THREADS), 0, s, (const uint32_t*)b.bin_total, nbins, b.seg_len,
-                       b.max_items, (const uint2*)b.blk_counts, n ? b.nblocks : 0u, b.bin_start, b.seg_start, b.items,
+                       b.max_items, b.capacity, (const uint2*)b.blk_counts, n ? b.nblocks : 0u, b.bin_start, b.seg_start, b.items,
                        b.overflow, b.visible, b.tile_entries, b.accum);
     if (n)
         hipLaunchKernelGGL(k_bin_scatter, grid, block, lds, s, b.depth_index, b.bbox, n, g, (const uint32_t*)b.table,

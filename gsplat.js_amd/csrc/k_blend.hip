@@ -39,7 +39,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t* __restr
                                                          const Record* __restrict__ rec,
                                                          const uint2* __restrict__ bbox, float4* __restrict__ fb,
                                                          float4* __restrict__ partial, uint32_t* __restrict__ queue,
-                                                         BinGrid g, float eps, uint32_t seg_len)
+                                                         BinGrid g, float eps, uint32_t seg_len, uint32_t capacity, uint32_t nsplats)
 {
     __shared__ float4 s_ra[CHUNK];   // cx, cy, ux, uy
     __shared__ float4 s_rb[CHUNK];   // wx, wy, log2(opacity), red
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t* __restr
         float g00 = 0.f, g10 = 0.f, g01 = 0.f, g11 = 0.f;
         float b00 = 0.f, b10 = 0.f, b01 = 0.f, b11 = 0.f;
 
-        const uint32_t bin_end = bin_start[bin + 1];
+        const uint32_t bin_end = min(bin_start[bin + 1], capacity);
         const uint32_t begin = min(bin_start[bin] + seg * seg_len, bin_end);
         const uint32_t end = min(begin + seg_len, bin_end);
         bool done = false;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t* __restr
             const uint32_t e = base + threadIdx.x;
             uint32_t mask = 0;
             if (e < end) {
-                const uint32_t i = list[e];
+                const uint32_t i = min(list[e], nsplats - 1u);
                 const float4* rp = reinterpret_cast<const float4*>(rec + i);
                 const float4 ra = rp[0], rb = rp[1];
                 const uint2 bb = bbox[i];
@@ -248,7 +248,7 @@ void launch_blend(const BlendBuffers& b, const BinGrid& g, float early_out_eps, 
     const int nbins = (g.bx_hi - g.bx_lo) * g.nby;
     if (nbins <= 0) return;
     hipLaunchKernelGGL(k_blend, dim3(b.grid), dim3(BLEND_THREADS), 0, s, b.items, b.seg_start, b.bin_start, b.list, b.rec,
-                       b.bbox, b.fb, b.partial, b.queue, g, early_out_eps, b.seg_len);
+                       b.bbox, b.fb, b.partial, b.queue, g, early_out_eps, b.seg_len, b.capacity, b.nsplats);
     if (b.seg_len < 0x40000000u)
         hipLaunchKernelGGL(k_combine, dim3(nbins), dim3(BLEND_THREADS), 0, s, b.seg_start, (const float4*)b.partial, b.fb, g);
 }

@@ -187,10 +187,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint32_t* __rest
         // wavefront-scope fences keep the compiler from moving the read below the write.
         uint32_t* wc = cnt[wave];
         const uint32_t start = wc[digit];
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
         if (valid && rank == 0) wc[digit] = start + (uint32_t)__popcll(m);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
         if (valid) {
             const uint32_t dst = start + rank;

@@ -58,7 +58,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("GSPLAT_HIP_LIB") or LIB_PATH   # GSPLAT_HIP_LIB: experiment builds
     if not os.path.exists(p):
         raise GsplatError("libgsplat_hip.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`" % p)
     L = ctypes.CDLL(p)

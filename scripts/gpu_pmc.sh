@@ -1,7 +1,6 @@
 #!/bin/bash
-# PMC passes over the bench (separate rocprofv3 runs; no tracing domains combined with --pmc).
-# usage: bash scripts/gpu_pmc.sh [extra bench args]
-cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/pmc
+# PMC passes over the bench (separate rocprofv3 runs; --pmc is never combined with tracing domains).
+cd $GRAFT_REPO_ROOT && rm -rf gpurun_out/pmc && mkdir -p gpurun_out/pmc
 export TMPDIR=/tmp
 cd /tmp
 run() {
@@ -10,7 +9,6 @@ run() {
   echo "$name rc=$?"
 }
 run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY && \
-run sq2 SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU GRBM_GUI_ACTIVE && \
+run sq2 SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU GRBM_GUI_ACTIVE && \
 run fetch FETCH_SIZE && \
 run write WRITE_SIZE
-ls $GRAFT_REPO_ROOT/gpurun_out/pmc/*

@@ -174,3 +174,54 @@ def test_band_split_equals_full_frame(gh, oracle, scenes):
         assert not part[:, :x0].any() and not part[:, x1:].any()
         parts[:, x0:x1] = part[:, x0:x1]
     assert np.array_equal(parts, full)
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json full sizes
+# ---------------------------------------------------------------------------
+def _full_size_checks(gh, oracle, scenes, name, k, image=True, eps=0.0):
+    cfg = gh.synth.CONFIGS[name]
+    rows, data, pos = scenes(name)
+    cam = _camera(gh, k, cfg)
+    r = gh.HIPRenderer(cfg["width"], cfg["height"], early_out_eps=eps)
+    r.set_raw_scene(data, pos)
+    r.set_camera(cam)
+    r.render_async(); r.sync()
+    di = r.lastDepthIndex()
+    keys, mm = r.read_keys()
+    st = r.stats()
+    # size-independent properties: a permutation, keys non-decreasing along it, ties in index order
+    assert np.array_equal(np.sort(di), np.arange(cfg["n"], dtype=np.uint32))
+    ks = keys[di].astype(np.int64)
+    assert (np.diff(ks) >= 0).all()
+    same = np.diff(ks) == 0
+    assert (np.diff(di.astype(np.int64))[same] > 0).all()
+    # and the oracle itself
+    v, p, vp = cam.f32()
+    odi, okeys, omm = oracle.sort(vp, pos)
+    assert mm == omm and np.array_equal(keys, okeys) and np.array_equal(di, odi)
+    rec, bbox = r.read_records()
+    orec, obbox, oraw = oracle.project(data, v, p, cfg["fx"], cfg["fx"], cfg["width"], cfg["height"])
+    _compare_records(rec, bbox, orec, obbox, oraw)
+    V, D = oracle.tile_stats(obbox)
+    assert st["visible"] == V and st["tile_entries"] == D
+    if image:
+        img = r.readPixelsFloat()
+        oimg = oracle.render(odi, oraw, orec, obbox, cfg["width"], cfg["height"], 1)
+        err = np.abs(img.astype(np.float64) - oimg.astype(np.float64)).max()
+        assert err <= (TOL_EARLY if eps > 0 else TOL_EXACT), err
+        a = img[..., 3]
+        assert a.min() >= 0.0 and a.max() <= 1.0 + 1e-6
+    r.dispose()
+
+
+def test_full_size_c3_1m_1080p(gh, oracle, scenes):
+    _full_size_checks(gh, oracle, scenes, "C3", 21)
+
+
+def test_full_size_c3_early_out(gh, oracle, scenes):
+    _full_size_checks(gh, oracle, scenes, "C3", 84, eps=1e-4)
+
+
+def test_full_size_c4_5m_4k(gh, oracle, scenes):
+    _full_size_checks(gh, oracle, scenes, "C4", 50)
