@@ -17,9 +17,6 @@
 
 #include <algorithm>
 
-#ifndef GSR_EXP_STOP
-#define GSR_EXP_STOP 0   // experiment builds only (scripts/build_exp.sh): stop k_bin_scatter after phase k
-#endif
 
 namespace gsr {
 
@@ -220,116 +217,98 @@ __global__ __launch_bounds__(FIN_THREADS) void k_bin_finalize(const uint32_t* __
 
 // ---------------------------------------------------------------------------
 // scatter: list[...] = splat index, bins in raster order, depth order inside a bin.
-// Workgroup = 4 waves over 2048 consecutive ranks; wave w owns steps
-// [w*8, w*8+8) of 64 ranks, so input order = (workgroup, wave, step, lane).
+// Workgroup = 16 waves over 2048 consecutive ranks.  The ranks form 4 groups of 512 (8 steps of 64);
+// group g is shared by waves 4g..4g+3, each owning 2 of its steps, so input order is
+// (workgroup, group, step, lane).  Sixteen waves instead of four do the same work with 4x the
+// latency hiding: the pass is a chain of dependent LDS / global round trips, not arithmetic.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(BIN_THREADS) void k_bin_scatter(const uint32_t* __restrict__ depth_index,
-                                                             const uint2* __restrict__ bbox, uint32_t n, BinGrid g,
-                                                             const uint32_t* __restrict__ table,
-                                                             const uint32_t* __restrict__ bin_start,
-                                                             uint32_t* __restrict__ list, uint32_t capacity,
-                                                             uint32_t* __restrict__ overflow)
+constexpr int SCAT_THREADS = 1024;
+constexpr int SCAT_GROUPS = 4;                       // rank groups per workgroup (512 ranks each)
+constexpr int SCAT_WAVES_PER_GROUP = 4;
+constexpr int SCAT_STEPS_PER_WAVE = BIN_STEPS / SCAT_WAVES_PER_GROUP;  // 2
+static_assert(SCAT_GROUPS * BIN_STEPS * WAVE == (int)BIN_RANKS_PER_BLOCK, "scatter and count must cut the ranks alike");
+
+__global__ __launch_bounds__(SCAT_THREADS) void k_bin_scatter(const uint32_t* __restrict__ depth_index,
+                                                              const uint2* __restrict__ bbox, uint32_t n, BinGrid g,
+                                                              const uint32_t* __restrict__ table,
+                                                              const uint32_t* __restrict__ bin_start,
+                                                              uint32_t* __restrict__ list, uint32_t capacity,
+                                                              uint32_t* __restrict__ overflow)
 {
     extern __shared__ uint32_t s_mem[];
     const int nbxb = g.bx_hi - g.bx_lo, nbins = nbxb * g.nby;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // LDS: base[nbins] (u32: the workgroup's first slot in each bin), pair[2][nbins] (two 16-bit per-wave
-    // counts/offsets per word: waves 0|1 and 2|3; a wave holds 512 ranks, so 16 bits suffice), then the lane sets.
+    const int group = wave / SCAT_WAVES_PER_GROUP, sub = wave % SCAT_WAVES_PER_GROUP;
+    // LDS: base[nbins] (u32: the workgroup's first slot in each bin), pair[2][nbins] (two 16-bit per-group
+    // counts/offsets per word: groups 0|1 and 2|3; a group holds 512 ranks, so 16 bits suffice), then the
+    // lane sets: per group, per step: [nbxb] column words + [nby] row words.
     uint32_t* base = s_mem;
     uint32_t* pair = s_mem + nbins;
     const int nmask = nbxb + g.nby;
     unsigned long long* masks = reinterpret_cast<unsigned long long*>(s_mem + ((3 * nbins + 1) & ~1));
-    unsigned long long* wmask = masks + (size_t)wave * BIN_STEPS * nmask;   // step s: wmask + s*nmask
-    // splat indices parked in LDS: phase 3 must not depend on registers filled by global loads, or the
-    // compiler fences every step with s_waitcnt vmcnt(0) and each step waits for the previous step's stores
-    uint32_t* sidx = reinterpret_cast<uint32_t*>(masks + (size_t)BIN_WAVES * BIN_STEPS * nmask) + wave * (BIN_STEPS * WAVE);
-    uint32_t* mypair = pair + (size_t)(wave >> 1) * nbins;
-    const int myshift = (wave & 1) * 16;
+    unsigned long long* gmask = masks + (size_t)group * BIN_STEPS * nmask;   // step s of my group: gmask + s*nmask
+    uint32_t* mypair = pair + (size_t)(group >> 1) * nbins;
+    const int myshift = (group & 1) * 16;
 
-    for (int b = threadIdx.x; b < 2 * nbins; b += BIN_THREADS) pair[b] = 0;
-    for (int b = threadIdx.x; b < BIN_WAVES * BIN_STEPS * nmask; b += BIN_THREADS) masks[b] = 0;
+    for (int b = threadIdx.x; b < 2 * nbins; b += SCAT_THREADS) pair[b] = 0;
+    for (int b = threadIdx.x; b < SCAT_GROUPS * BIN_STEPS * nmask; b += SCAT_THREADS) masks[b] = 0;
     __syncthreads();
 
-    // this wave's 8 steps of 64 consecutive ranks: indices and bin rectangles stay in registers
-    const uint32_t wbegin = blockIdx.x * BIN_RANKS_PER_BLOCK + wave * (BIN_STEPS * WAVE);
-    uint32_t idx[BIN_STEPS];
-    BinRect br[BIN_STEPS];
+    // this wave's 2 steps of 64 consecutive ranks
+    const uint32_t gbegin = blockIdx.x * BIN_RANKS_PER_BLOCK + group * (BIN_STEPS * WAVE);
+    uint32_t idx[SCAT_STEPS_PER_WAVE];
+    BinRect br[SCAT_STEPS_PER_WAVE];
 #pragma unroll
-    for (int st = 0; st < BIN_STEPS; st++) {
-        const uint32_t r = wbegin + st * WAVE + lane;
-        idx[st] = (r < n) ? depth_index[r] : 0u;
+    for (int k = 0; k < SCAT_STEPS_PER_WAVE; k++) {
+        const uint32_t r = gbegin + (sub * SCAT_STEPS_PER_WAVE + k) * WAVE + lane;
+        idx[k] = (r < n) ? depth_index[r] : 0xffffffffu;
     }
 #pragma unroll
-    for (int st = 0; st < BIN_STEPS; st++) {
-        const uint32_t r = wbegin + st * WAVE + lane;
-        if (r < n) br[st] = bin_rect(bbox[idx[st]], g);
-        else { br[st].x0 = 1; br[st].x1 = 0; br[st].y0 = 1; br[st].y1 = 0; }
+    for (int k = 0; k < SCAT_STEPS_PER_WAVE; k++) {
+        if (idx[k] != 0xffffffffu) br[k] = bin_rect(bbox[idx[k]], g);
+        else { br[k].x0 = 1; br[k].x1 = 0; br[k].y0 = 1; br[k].y1 = 0; }
     }
-#if GSR_EXP_STOP == 1
-    { uint32_t acc = 0; for (int st = 0; st < BIN_STEPS; st++) acc += idx[st] + br[st].x0 + br[st].y1; if (acc == 0xdeadbeefu) list[0] = acc; return; }
-#endif
-#pragma unroll
-    for (int st = 0; st < BIN_STEPS; st++) sidx[st * WAVE + lane] = idx[st];
-    // phase 1: per-wave counts
+    // phase 1: per-group counts, and every lane ORs its bit into the column/row lane sets of its box
     const uint32_t one = 1u << myshift;
+    const unsigned long long mybit = 1ull << lane;
 #pragma unroll
-    for (int st = 0; st < BIN_STEPS; st++)
-        for (int y = br[st].y0; y <= br[st].y1; y++)
-            for (int x = br[st].x0; x <= br[st].x1; x++) atomicAdd(&mypair[y * nbxb + x], one);
+    for (int k = 0; k < SCAT_STEPS_PER_WAVE; k++) {
+        const BinRect b = br[k];
+        unsigned long long* colm = gmask + (sub * SCAT_STEPS_PER_WAVE + k) * nmask;
+        unsigned long long* rowm = colm + nbxb;
+        for (int x = b.x0; x <= b.x1; x++) atomicOr(&colm[x], mybit);
+        for (int y = b.y0; y <= b.y1; y++) {
+            if (b.x0 <= b.x1) atomicOr(&rowm[y], mybit);
+            for (int x = b.x0; x <= b.x1; x++) atomicAdd(&mypair[y * nbxb + x], one);
+        }
+    }
     __syncthreads();
-#if GSR_EXP_STOP == 2
-    if (capacity != 0xdeadbeefu) return;
-#endif
-    // phase 2: counts -> offsets of each wave inside the workgroup's run; workgroup base from the table
-    for (int b = threadIdx.x; b < nbins; b += BIN_THREADS) {
+    // phase 2: counts -> offsets of each group inside the workgroup's run; workgroup base from the table
+    for (int b = threadIdx.x; b < nbins; b += SCAT_THREADS) {
         base[b] = bin_start[b] + table[(size_t)blockIdx.x * nbins + b];
         const uint32_t c01 = pair[b], c23 = pair[nbins + b];
         const uint32_t o1 = c01 & 0xffffu, o2 = o1 + (c01 >> 16), o3 = o2 + (c23 & 0xffffu);
-        pair[b] = o1 << 16;                // wave 0: 0, wave 1: o1
-        pair[nbins + b] = o2 | (o3 << 16); // wave 2: o2, wave 3: o3
+        pair[b] = o1 << 16;                // group 0: 0, group 1: o1
+        pair[nbins + b] = o2 | (o3 << 16); // group 2: o2, group 3: o3
     }
     __syncthreads();
-#if GSR_EXP_STOP == 3
-    if (capacity != 0xdeadbeefu) return;
-#endif
-    // phase 3a: every lane ORs its bit into the column/row lane sets of its box, for all 8 steps at once
-    const unsigned long long mybit = 1ull << lane;
-#ifdef GSR_EXP_NO_PHASE3
-    if (capacity != 0xdeadbeefu) return;
-#endif
+    // phase 3: slots.  The set of lanes of step s covering bin (X,Y) is col[s][X] & row[s][Y]; a splat's slot is
+    // base[bin] + its group's offset + the sizes of the sets of the group's earlier steps + the number of
+    // lower lanes in its own step's set: input order, from ballot-style arithmetic on LDS words that are
+    // read-only by now (no ordered atomics, no running counter).
 #pragma unroll
-    for (int st = 0; st < BIN_STEPS; st++) {
-        const BinRect b = br[st];
-        unsigned long long* colm = wmask + st * nmask;
-        unsigned long long* rowm = colm + nbxb;
-        for (int x = b.x0; x <= b.x1; x++) atomicOr(&colm[x], mybit);
-        for (int y = b.y0; y <= b.y1 && b.x0 <= b.x1; y++) atomicOr(&rowm[y], mybit);
-    }
-#if GSR_EXP_STOP == 4
-    if (capacity != 0xdeadbeefu) return;
-#endif
-    // One wave talking to its own LDS words: LDS executes a wave's operations in order, so the reads
-    // below see every OR above; the fence only keeps the compiler from reordering across it.
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
-    __builtin_amdgcn_wave_barrier();
-    // phase 3b: slots.  base[bin] + this wave's 16-bit offset = the wave's first slot in the bin.
-#pragma unroll
-    for (int st = 0; st < BIN_STEPS; st++) {
-        const BinRect b = br[st];
-        const uint32_t myidx = sidx[st * WAVE + lane];
+    for (int k = 0; k < SCAT_STEPS_PER_WAVE; k++) {
+        const BinRect b = br[k];
+        const int st = sub * SCAT_STEPS_PER_WAVE + k;
+        const uint32_t myidx = idx[k];
         for (int y = b.y0; y <= b.y1; y++) {
             for (int x = b.x0; x <= b.x1; x++) {
                 uint32_t dst = base[y * nbxb + x] + ((mypair[y * nbxb + x] >> myshift) & 0xffffu);
-#pragma unroll
-                for (int e = 0; e < st; e++)  // entries the earlier steps of this wave put into the bin
-                    dst += (uint32_t)__popcll(wmask[e * nmask + x] & wmask[e * nmask + nbxb + y]);
-                dst += lanes_below64(wmask[st * nmask + x] & wmask[st * nmask + nbxb + y]);
-#ifdef GSR_EXP_NO_LIST_STORE
-                if (dst == 0xffffffffu) list[0] = myidx;
-#else
+                for (int e = 0; e < st; e++)  // entries the earlier steps of this group put into the bin
+                    dst += (uint32_t)__popcll(gmask[e * nmask + x] & gmask[e * nmask + nbxb + y]);
+                dst += lanes_below64(gmask[st * nmask + x] & gmask[st * nmask + nbxb + y]);
                 if (dst < capacity) list[dst] = myidx;
                 else atomicOr(overflow, 1u);
-#endif
             }
         }
     }
@@ -340,8 +319,7 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
     const int nbxb = g.bx_hi - g.bx_lo, nbins = nbxb * g.nby;
     if (nbins <= 0) return;
     const dim3 grid(b.nblocks), block(BIN_THREADS);
-    const size_t lds = (size_t)((3 * nbins + 1) & ~1) * 4 + (size_t)BIN_WAVES * BIN_STEPS * (nbxb + g.nby) * 8 +
-                       (size_t)BIN_THREADS * BIN_STEPS * 4;
+    const size_t lds = (size_t)((3 * nbins + 1) & ~1) * 4 + (size_t)SCAT_GROUPS * BIN_STEPS * (nbxb + g.nby) * 8;
     // dynamic LDS above the 64 KiB default needs the attribute raised (4K: 8160 bins -> 130 KiB)
     static size_t lds_allowed = 64 * 1024;
     if (lds > lds_allowed) {
@@ -361,7 +339,7 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
                        b.max_items, b.capacity, (const uint2*)b.blk_counts, n ? b.nblocks : 0u, b.bin_start, b.seg_start, b.items,
                        b.overflow, b.visible, b.tile_entries, b.accum);
     if (n)
-        hipLaunchKernelGGL(k_bin_scatter, grid, block, lds, s, b.depth_index, b.bbox, n, g, (const uint32_t*)b.table,
+        hipLaunchKernelGGL(k_bin_scatter, grid, dim3(SCAT_THREADS), lds, s, b.depth_index, b.bbox, n, g, (const uint32_t*)b.table,
                            (const uint32_t*)b.bin_start, b.list, b.capacity, b.overflow);
 }
 

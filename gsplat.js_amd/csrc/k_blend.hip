@@ -37,7 +37,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t* __restr
                                                          const uint32_t* __restrict__ bin_start,
                                                          const uint32_t* __restrict__ list,
                                                          const Record* __restrict__ rec,
-                                                         const uint2* __restrict__ bbox, float4* __restrict__ fb,
+                                                         float4* __restrict__ fb,
                                                          float4* __restrict__ partial, uint32_t* __restrict__ queue,
                                                          BinGrid g, float eps, uint32_t seg_len, uint32_t capacity, uint32_t nsplats)
 {
@@ -89,44 +89,35 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t* __restr
             if (s_done == BLEND_THREADS / WAVE) break;  // every tile of the bin is saturated
             // ---- stage one entry per thread: record, unpacked colour, and a 16-bit mask of the bin's
             //      8x8-pixel quadrants the splat can touch (bit = tile*4 + quadrant).  The mask is a
-            //      conservative cull only: a quadrant is dropped when the splat's pixel box misses it, when
-            //      it lies outside the oriented box |vPosition.x|,|vPosition.y| <= 2 (separating axes u, w),
-            //      or farther from the centre than the longer semi-axis.  Pixels that pass are still
-            //      tested exactly (q <= 4) below. ----
+            //      conservative cull only: a quadrant is dropped when it lies outside the oriented box
+            //      |vPosition.x|,|vPosition.y| <= 2 (separating axes u, w) or farther from the centre than the
+            //      longer semi-axis.  Pixels that pass are still tested exactly (q <= 4) below. ----
             const uint32_t e = base + threadIdx.x;
             uint32_t mask = 0;
             if (e < end) {
                 const uint32_t i = min(list[e], nsplats - 1u);
                 const float4* rp = reinterpret_cast<const float4*>(rec + i);
                 const float4 ra = rp[0], rb = rp[1];
-                const uint2 bb = bbox[i];
-                const int px0 = bb.x & 0xffff, px1 = bb.x >> 16, py0 = bb.y & 0xffff, py1 = bb.y >> 16;
-                const float aux = fabsf(ra.z), auy = fabsf(ra.w), awx = fabsf(rb.x), awy = fabsf(rb.y);
-                const float eu = 3.5f * (aux + auy) + 2.0005f, ew = 3.5f * (awx + awy) + 2.0005f;
+                const float eu = 3.5f * (fabsf(ra.z) + fabsf(ra.w)) + 2.0005f;
+                const float ew = 3.5f * (fabsf(rb.x) + fabsf(rb.y)) + 2.0005f;
                 const float minlen2 = fminf(ra.z * ra.z + ra.w * ra.w, rb.x * rb.x + rb.y * rb.y);
                 float ucol[4], wcol[4], dcol[4];
-                uint32_t colok = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const int qx = binX0 + 8 * k;
-                    const float dc = (float)(qx + 4) - ra.x;
+                    const float dc = (float)(binX0 + 8 * k + 4) - ra.x;
                     ucol[k] = ra.z * dc; wcol[k] = rb.x * dc;
                     const float dd = fmaxf(fabsf(dc) - 3.5f, 0.0f);
                     dcol[k] = dd * dd;
-                    if (px0 <= qx + 7 && px1 >= qx) colok |= 1u << k;
                 }
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int qy = binY0 + 8 * r;
-                    if (!(py0 <= qy + 7 && py1 >= qy)) continue;
-                    const float dc = (float)(qy + 4) - ra.y;
+                    const float dc = (float)(binY0 + 8 * r + 4) - ra.y;
                     const float ur = ra.w * dc, wr = rb.y * dc;
                     const float dd = fmaxf(fabsf(dc) - 3.5f, 0.0f);
                     const float d2 = dd * dd;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        const bool hit = ((colok >> k) & 1u) && fabsf(ucol[k] + ur) <= eu && fabsf(wcol[k] + wr) <= ew &&
-                                         (dcol[k] + d2) * minlen2 <= 4.002f;
+                        const bool hit = fabsf(ucol[k] + ur) <= eu && fabsf(wcol[k] + wr) <= ew && (dcol[k] + d2) * minlen2 <= 4.002f;
                         // quadrant (k, r) of the bin -> tile (k>>1, r>>1), quadrant (k&1, r&1)
                         if (hit) mask |= 1u << ((((r >> 1) * 2 + (k >> 1)) << 2) + ((r & 1) * 2 + (k & 1)));
                     }
@@ -248,7 +239,7 @@ void launch_blend(const BlendBuffers& b, const BinGrid& g, float early_out_eps, 
     const int nbins = (g.bx_hi - g.bx_lo) * g.nby;
     if (nbins <= 0) return;
     hipLaunchKernelGGL(k_blend, dim3(b.grid), dim3(BLEND_THREADS), 0, s, b.items, b.seg_start, b.bin_start, b.list, b.rec,
-                       b.bbox, b.fb, b.partial, b.queue, g, early_out_eps, b.seg_len, b.capacity, b.nsplats);
+                       b.fb, b.partial, b.queue, g, early_out_eps, b.seg_len, b.capacity, b.nsplats);
     if (b.seg_len < 0x40000000u)
         hipLaunchKernelGGL(k_combine, dim3(nbins), dim3(BLEND_THREADS), 0, s, b.seg_start, (const float4*)b.partial, b.fb, g);
 }
