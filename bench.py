@@ -27,13 +27,6 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ORBIT_FRAMES = 120
 
 
-class _DevArray:
-    """Expose a raw device pointer to torch (zero copy) through __cuda_array_interface__."""
-
-    def __init__(self, ptr, shape):
-        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
-
-
 def cpu_baseline(gh, cfg, data, pos, sample_frames=2, sort_calls=10):
     """The reference's CPU path timed on this host.  Sort: the reference's own wasm/wasm.cpp compiled
     natively (oracle/_ref) when present, else the bit-identical restatement; 1 thread like the
@@ -119,7 +112,7 @@ def main():
 
     fb = xchg = None
     if world > 1:
-        fb = torch.as_tensor(_DevArray(r.framebuffer_ptr(), (H, W, 4)), device="cuda:%d" % local_rank)
+        fb = bands.framebuffer_tensor(torch, r, "cuda:%d" % local_rank)
         xchg = bands.FrameExchange(dist, torch, W, H, rank, world, fb.device)
 
     # Camera.update for the 120 poses is host JS/Python f64 work outside the device path: precomputed

@@ -50,29 +50,32 @@ __device__ __forceinline__ uint32_t lanes_below64(uint64_t mask)
 // No global atomics: hundreds of workgroups hitting the same few words cost
 // more than the whole pass.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __restrict__ depth_index,
+constexpr int CNT_THREADS = 1024;
+constexpr int CNT_STEPS = (int)BIN_RANKS_PER_BLOCK / CNT_THREADS;  // 2
+
+__global__ __launch_bounds__(CNT_THREADS) void k_bin_count(const uint32_t* __restrict__ depth_index,
                                                            const uint2* __restrict__ bbox, uint32_t n, BinGrid g,
                                                            uint32_t* __restrict__ table, uint2* __restrict__ blk_counts)
 {
     extern __shared__ uint32_t s_cnt[];  // nbins
-    __shared__ uint32_t s_red[2 * BIN_WAVES];
+    __shared__ uint32_t s_red[2 * (CNT_THREADS / WAVE)];
     const int nbxb = g.bx_hi - g.bx_lo, nbins = nbxb * g.nby;
-    for (int b = threadIdx.x; b < nbins; b += BIN_THREADS) s_cnt[b] = 0;
+    for (int b = threadIdx.x; b < nbins; b += CNT_THREADS) s_cnt[b] = 0;
     __syncthreads();
     const uint32_t begin = blockIdx.x * BIN_RANKS_PER_BLOCK;
     uint32_t vis = 0, tiles = 0;
-    uint32_t idx[BIN_STEPS];
+    uint32_t idx[CNT_STEPS];
 #pragma unroll
-    for (int st = 0; st < BIN_STEPS; st++) {
-        const uint32_t r = begin + st * BIN_THREADS + threadIdx.x;
+    for (int st = 0; st < CNT_STEPS; st++) {
+        const uint32_t r = begin + st * CNT_THREADS + threadIdx.x;
         idx[st] = (r < n) ? depth_index[r] : 0xffffffffu;
     }
-    uint2 bbs[BIN_STEPS];
+    uint2 bbs[CNT_STEPS];
 #pragma unroll
-    for (int st = 0; st < BIN_STEPS; st++)
+    for (int st = 0; st < CNT_STEPS; st++)
         bbs[st] = (idx[st] != 0xffffffffu) ? bbox[idx[st]] : make_uint2(BBOX_INVISIBLE_X, BBOX_INVISIBLE_Y);
 #pragma unroll
-    for (int st = 0; st < BIN_STEPS; st++) {
+    for (int st = 0; st < CNT_STEPS; st++) {
         const uint2 bb = bbs[st];
         const BinRect br = bin_rect(bb, g);
         if (br.x0 <= br.x1) {
@@ -89,12 +92,13 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
         vis += __shfl_xor(vis, off);
         tiles += __shfl_xor(tiles, off);
     }
-    if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6] = vis; s_red[BIN_WAVES + (threadIdx.x >> 6)] = tiles; }
+    constexpr int NW = CNT_THREADS / WAVE;
+    if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6] = vis; s_red[NW + (threadIdx.x >> 6)] = tiles; }
     __syncthreads();
-    for (int b = threadIdx.x; b < nbins; b += BIN_THREADS) table[(size_t)blockIdx.x * nbins + b] = s_cnt[b];
+    for (int b = threadIdx.x; b < nbins; b += CNT_THREADS) table[(size_t)blockIdx.x * nbins + b] = s_cnt[b];
     if (threadIdx.x == 0) {
         uint32_t v = 0, t = 0;
-        for (int w = 0; w < BIN_WAVES; w++) { v += s_red[w]; t += s_red[BIN_WAVES + w]; }
+        for (int w = 0; w < NW; w++) { v += s_red[w]; t += s_red[NW + w]; }
         blk_counts[blockIdx.x] = make_uint2(v, t);
     }
 }
@@ -109,18 +113,29 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_scan(uint32_t* __restrict__
     const int lane = threadIdx.x & 63;
     const int bin = blockIdx.x * BIN_WAVES + (threadIdx.x >> 6);
     if (bin >= nbins) return;
+    // One wave per column: lane l takes rows l, l+64, ...  The strided loads of a batch are issued together
+    // (independent), then scanned; doing them one at a time made this kernel a chain of L2 round trips.
+    constexpr int BATCH = 8;
     uint32_t run = 0;
-    for (uint32_t b0 = 0; b0 < nblocks; b0 += WAVE) {
-        const uint32_t b = b0 + lane;
-        const uint32_t v = (b < nblocks) ? table[(size_t)b * nbins + bin] : 0u;
-        uint32_t incl = v;
+    for (uint32_t b0 = 0; b0 < nblocks; b0 += BATCH * WAVE) {
+        uint32_t v[BATCH];
 #pragma unroll
-        for (int off = 1; off < WAVE; off <<= 1) {
-            const uint32_t t = __shfl_up(incl, off);
-            if (lane >= off) incl += t;
+        for (int k = 0; k < BATCH; k++) {
+            const uint32_t b = b0 + k * WAVE + lane;
+            v[k] = (b < nblocks) ? table[(size_t)b * nbins + bin] : 0u;
         }
-        if (b < nblocks) table[(size_t)b * nbins + bin] = run + incl - v;
-        run += __shfl(incl, WAVE - 1);
+#pragma unroll
+        for (int k = 0; k < BATCH; k++) {
+            const uint32_t b = b0 + k * WAVE + lane;
+            uint32_t incl = v[k];
+#pragma unroll
+            for (int off = 1; off < WAVE; off <<= 1) {
+                const uint32_t t = __shfl_up(incl, off);
+                if (lane >= off) incl += t;
+            }
+            if (b < nblocks) table[(size_t)b * nbins + bin] = run + incl - v[k];
+            run += __shfl(incl, WAVE - 1);
+        }
     }
     if (lane == 0) bin_total[bin] = run;
 }
@@ -330,7 +345,7 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
         lds_allowed = (size_t)want;
     }
     if (n) {
-        hipLaunchKernelGGL(k_bin_count, grid, block, nbins * sizeof(uint32_t), s, b.depth_index, b.bbox, n, g, b.table,
+        hipLaunchKernelGGL(k_bin_count, grid, dim3(CNT_THREADS), nbins * sizeof(uint32_t), s, b.depth_index, b.bbox, n, g, b.table,
                            b.blk_counts);
         hipLaunchKernelGGL(k_bin_scan, dim3((nbins + BIN_WAVES - 1) / BIN_WAVES), block, 0, s, b.table, b.bin_total, nbins,
                            b.nblocks);

@@ -95,79 +95,98 @@ __global__ __launch_bounds__(SORT_THREADS) void k_digit_scan(uint32_t* __restric
     const int lane = threadIdx.x & 63;
     const int d = blockIdx.x * SORT_WAVES + (threadIdx.x >> 6);
     if (d >= nbins) return;
+    // One wave per column: lane l takes rows l, l+64, ...  The strided loads of a batch are issued together
+    // (independent), then scanned; doing them one at a time made this kernel a chain of L2 round trips.
+    constexpr int BATCH = 8;
     uint32_t run = 0;
-    for (uint32_t b0 = 0; b0 < nblocks; b0 += WAVE) {
-        const uint32_t b = b0 + lane;
-        const uint32_t v = (b < nblocks) ? block_hist[(size_t)b * nbins + d] : 0u;
-        uint32_t incl = v;
+    for (uint32_t b0 = 0; b0 < nblocks; b0 += BATCH * WAVE) {
+        uint32_t v[BATCH];
 #pragma unroll
-        for (int off = 1; off < WAVE; off <<= 1) {
-            const uint32_t t = __shfl_up(incl, off);
-            if (lane >= off) incl += t;
+        for (int k = 0; k < BATCH; k++) {
+            const uint32_t b = b0 + k * WAVE + lane;
+            v[k] = (b < nblocks) ? block_hist[(size_t)b * nbins + d] : 0u;
         }
-        if (b < nblocks) block_hist[(size_t)b * nbins + d] = run + incl - v;
-        run += __shfl(incl, WAVE - 1);
+#pragma unroll
+        for (int k = 0; k < BATCH; k++) {
+            const uint32_t b = b0 + k * WAVE + lane;
+            uint32_t incl = v[k];
+#pragma unroll
+            for (int off = 1; off < WAVE; off <<= 1) {
+                const uint32_t t = __shfl_up(incl, off);
+                if (lane >= off) incl += t;
+            }
+            if (b < nblocks) block_hist[(size_t)b * nbins + d] = run + incl - v[k];
+            run += __shfl(incl, WAVE - 1);
+        }
     }
     if (lane == 0) total[d] = run;
 }
 
 // ---------------------------------------------------------------------------
-// Stable scatter of one pass.  Workgroup = 4 waves over keys_per_block keys;
-// wave w owns the w-th quarter (contiguous), walked in 64-key steps, so the
-// order of equal digits is: workgroup, then wave, then step, then lane = input
-// order.  Phase 1 counts per wave, phase 2 turns the counts into running
-// destinations, phase 3 ranks with ballot matching and scatters.
+// Stable scatter of one pass.  Workgroup = 16 waves over keys_per_block (2048) keys; wave w owns the w-th
+// sixteenth (contiguous, 2 steps of 64 keys), so the order of equal digits is: workgroup, then wave, then
+// step, then lane = input order.  Phase 1 counts per wave, phase 2 turns the counts into running destinations,
+// phase 3 ranks with ballot matching and scatters.  Sixteen waves (not four) because the pass is a chain of
+// dependent round trips: more waves in flight hide them.
 // ---------------------------------------------------------------------------
+constexpr int SCAT_THREADS = 1024;
+constexpr int SCAT_WAVES = SCAT_THREADS / WAVE;
+constexpr int SCAT_MAX_STEPS = 4;  // keys_per_block <= SCAT_THREADS * SCAT_MAX_STEPS
+
 template <int BITS, int SHIFT, bool FIRST>
-__global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint32_t* __restrict__ keys_in,
+__global__ __launch_bounds__(SCAT_THREADS) void k_scatter(const uint32_t* __restrict__ keys_in,
                                                           const uint32_t* __restrict__ idx_in, uint32_t n,
                                                           uint32_t keys_per_block, const uint32_t* __restrict__ base,
                                                           const uint32_t* __restrict__ total,
                                                           uint32_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out)
 {
     constexpr int BINS = 1 << BITS;
-    constexpr int PER = BINS / SORT_THREADS;  // digits per thread in the prologue (1 or 2)
-    __shared__ uint32_t cnt[SORT_WAVES][BINS];
+    __shared__ uint32_t cnt[SCAT_WAVES][BINS];
     __shared__ uint32_t dstart[BINS];          // keys with a smaller digit, all workgroups
-    __shared__ uint32_t wsum[SORT_WAVES];
+    __shared__ uint32_t wsum[BINS / WAVE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int d = threadIdx.x; d < SORT_WAVES * BINS; d += SORT_THREADS) (&cnt[0][0])[d] = 0;
+    for (int d = threadIdx.x; d < SCAT_WAVES * BINS; d += SCAT_THREADS) (&cnt[0][0])[d] = 0;
     __syncthreads();
 
-    const uint32_t per_wave = keys_per_block / SORT_WAVES;  // multiple of 64
+    const uint32_t per_wave = keys_per_block / SCAT_WAVES;  // multiple of 64
+    const uint32_t steps = per_wave / WAVE;                 // <= SCAT_MAX_STEPS
     const uint32_t wbegin = blockIdx.x * keys_per_block + wave * per_wave;
     const uint32_t wend = min(wbegin + per_wave, n);
 
-    // phase 1: per-wave digit counts
-    for (uint32_t i0 = wbegin; i0 < wend; i0 += WAVE) {
-        const uint32_t i = i0 + lane;
-        if (i < wend) atomicAdd(&cnt[wave][(keys_in[i] >> SHIFT) & (BINS - 1)], 1u);
-    }
-    __syncthreads();
-    // digit starts: exclusive scan of total[0..BINS) (thread t owns digits t*PER .. t*PER+PER-1)
-    {
-        uint32_t t[PER], s = 0;
+    // phase 1: load this wave's keys (kept in registers) and count digits per wave
+    uint32_t key[SCAT_MAX_STEPS];
 #pragma unroll
-        for (int k = 0; k < PER; k++) { t[k] = total[threadIdx.x * PER + k]; s += t[k]; }
-        uint32_t incl = s;
+    for (int k = 0; k < SCAT_MAX_STEPS; k++) {
+        const uint32_t i = wbegin + k * WAVE + lane;
+        key[k] = ((uint32_t)k < steps && i < wend) ? keys_in[i] : 0xffffffffu;
+    }
+#pragma unroll
+    for (int k = 0; k < SCAT_MAX_STEPS; k++)
+        if (key[k] != 0xffffffffu) atomicAdd(&cnt[wave][(key[k] >> SHIFT) & (BINS - 1)], 1u);
+    // digit starts: exclusive scan of total[0..BINS), one digit per thread on the first BINS threads
+    uint32_t tot = 0, incl = 0;
+    if (threadIdx.x < BINS) {
+        tot = total[threadIdx.x];
+        incl = tot;
 #pragma unroll
         for (int off = 1; off < WAVE; off <<= 1) {
             const uint32_t u = __shfl_up(incl, off);
             if (lane >= off) incl += u;
         }
         if (lane == WAVE - 1) wsum[wave] = incl;
-        __syncthreads();
-        uint32_t run = incl - s;
+    }
+    __syncthreads();
+    if (threadIdx.x < BINS) {
+        uint32_t run = incl - tot;
         for (int w = 0; w < wave; w++) run += wsum[w];
-#pragma unroll
-        for (int k = 0; k < PER; k++) { dstart[threadIdx.x * PER + k] = run; run += t[k]; }
+        dstart[threadIdx.x] = run;
     }
     __syncthreads();
     // phase 2: cnt[w][d] <- first destination of digit d for this workgroup + counts of earlier waves
-    for (int d = threadIdx.x; d < BINS; d += SORT_THREADS) {
+    for (int d = threadIdx.x; d < BINS; d += SCAT_THREADS) {
         uint32_t run = dstart[d] + base[(size_t)blockIdx.x * BINS + d];
 #pragma unroll
-        for (int w = 0; w < SORT_WAVES; w++) {
+        for (int w = 0; w < SCAT_WAVES; w++) {
             const uint32_t c = cnt[w][d];
             cnt[w][d] = run;
             run += c;
@@ -175,18 +194,19 @@ __global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint32_t* __rest
     }
     __syncthreads();
     // phase 3: rank + scatter (cnt[wave][*] is private to this wave from here on)
-    for (uint32_t i0 = wbegin; i0 < wend; i0 += WAVE) {
-        const uint32_t i = i0 + lane;
-        const bool valid = i < wend;
-        const uint32_t key = valid ? keys_in[i] : 0u;
-        const uint32_t digit = (key >> SHIFT) & (BINS - 1);
+    uint32_t* wc = cnt[wave];
+#pragma unroll
+    for (int k = 0; k < SCAT_MAX_STEPS; k++) {
+        if ((uint32_t)k >= steps) break;  // wave-uniform
+        const uint32_t i = wbegin + k * WAVE + lane;
+        const bool valid = key[k] != 0xffffffffu;
+        const uint32_t digit = (key[k] >> SHIFT) & (BINS - 1);
         const uint64_t m = match_digit<BITS>(digit, valid);
         const uint32_t rank = lanes_below(m);
         // All lanes read their digit's running destination, THEN the lowest lane of every group of
         // equal digits advances it.  One wave, its own LDS words: LDS executes in order, and the
         // wavefront-scope fences keep the compiler from moving the read below the write.
-        uint32_t* wc = cnt[wave];
-        const uint32_t start = wc[digit];
+        const uint32_t start = wc[valid ? digit : 0];
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
         if (valid && rank == 0) wc[digit] = start + (uint32_t)__popcll(m);
@@ -194,7 +214,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint32_t* __rest
         __builtin_amdgcn_wave_barrier();
         if (valid) {
             const uint32_t dst = start + rank;
-            if (keys_out) keys_out[dst] = key;
+            if (keys_out) keys_out[dst] = key[k];
             idx_out[dst] = FIRST ? i : idx_in[i];
         }
     }
@@ -210,13 +230,13 @@ void launch_sort(const SortBuffers& b, uint32_t n, hipStream_t s)
                        b.digit_total);
     hipLaunchKernelGGL(k_digit_scan, dim3(RADIX_LO_BINS / SORT_WAVES), block, 0, s, b.block_hist, total_lo, RADIX_LO_BINS,
                        b.nblocks);
-    hipLaunchKernelGGL((k_scatter<RADIX_LO_BITS, 0, true>), grid, block, 0, s, (const uint32_t*)b.keys,
+    hipLaunchKernelGGL((k_scatter<RADIX_LO_BITS, 0, true>), grid, dim3(SCAT_THREADS), 0, s, (const uint32_t*)b.keys,
                        (const uint32_t*)nullptr, n, b.keys_per_block, (const uint32_t*)b.block_hist,
                        (const uint32_t*)total_lo, b.keys_tmp, b.idx_tmp);
     hipLaunchKernelGGL(k_hist_hi, grid, block, 0, s, (const uint32_t*)b.keys_tmp, n, b.keys_per_block, b.block_hist);
     hipLaunchKernelGGL(k_digit_scan, dim3(RADIX_HI_BINS / SORT_WAVES), block, 0, s, b.block_hist, total_hi, RADIX_HI_BINS,
                        b.nblocks);
-    hipLaunchKernelGGL((k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, false>), grid, block, 0, s, (const uint32_t*)b.keys_tmp,
+    hipLaunchKernelGGL((k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, false>), grid, dim3(SCAT_THREADS), 0, s, (const uint32_t*)b.keys_tmp,
                        (const uint32_t*)b.idx_tmp, n, b.keys_per_block, (const uint32_t*)b.block_hist,
                        (const uint32_t*)total_hi, (uint32_t*)nullptr, b.depth_index);
 }

@@ -22,6 +22,19 @@ def slab_width(width, world):
     return -(-nbx // world) * BIN_PX
 
 
+class DevicePointer:
+    """Expose a raw device pointer to torch (zero copy) through __cuda_array_interface__:
+    `torch.as_tensor(DevicePointer(ptr, (H, W, 4)), device="cuda:0")`."""
+
+    def __init__(self, ptr, shape, typestr="<f4"):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def framebuffer_tensor(torch, renderer, device):
+    """The renderer's device framebuffer as a torch tensor [H, W, 4] float32 (no copy)."""
+    return torch.as_tensor(DevicePointer(renderer.framebuffer_ptr(), (renderer.height, renderer.width, 4)), device=device)
+
+
 class FrameExchange:
     """all-gather of per-rank band slabs into every rank's full frame."""
 

@@ -225,3 +225,19 @@ def test_full_size_c3_early_out(gh, oracle, scenes):
 
 def test_full_size_c4_5m_4k(gh, oracle, scenes):
     _full_size_checks(gh, oracle, scenes, "C4", 50)
+
+
+def test_torch_zero_copy_framebuffer(gh, scenes):
+    # bench.py's N>1 path wraps the device framebuffer as a torch tensor for the RCCL all-gather
+    import torch
+    from gsplat_hip import bands
+    cfg = gh.synth.CONFIGS["C1"]
+    rows, data, pos = scenes("C1")
+    r = gh.HIPRenderer(cfg["width"], cfg["height"])
+    r.set_raw_scene(data, pos)
+    r.set_camera(_camera(gh, 2, cfg))
+    r.render_async(); r.sync()
+    t = bands.framebuffer_tensor(torch, r, "cuda:0")
+    assert t.shape == (cfg["height"], cfg["width"], 4) and t.data_ptr() == r.framebuffer_ptr()
+    assert np.array_equal(t.cpu().numpy(), r.readPixelsFloat())
+    r.dispose()
