@@ -233,7 +233,7 @@ int enqueue_frame(gsr_ctx* c, bool render)
         launch_bin(bb, g, c->n, s);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BIN], s));
         BlendBuffers bl{c->items, c->seg_start, c->bin_start, c->bin_list, c->rec, c->bbox, c->fb, c->partial,
-                        &c->fstate->queue, c->seg_len, std::min<uint32_t>(c->max_items, 2048u), c->bin_capacity,
+                        &c->fstate->queue, c->seg_len, std::min<uint32_t>(c->max_items, getenv("GSR_BLEND_GRID") ? (uint32_t)atol(getenv("GSR_BLEND_GRID")) : 2048u), c->bin_capacity,
                         std::max(c->n, 1u)};
         launch_blend(bl, g, c->opt.early_out_eps, s);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BLEND], s));

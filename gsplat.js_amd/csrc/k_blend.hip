@@ -32,7 +32,10 @@ constexpr int CHUNK = BLEND_THREADS;
 constexpr int BIN_PIXELS = BIN_PX * BIN_PX;
 constexpr float LOG2E = 1.4426950408889634f;
 
-__global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t* __restrict__ items,
+#ifndef GSR_BLEND_MIN_WAVES
+#define GSR_BLEND_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(BLEND_THREADS, GSR_BLEND_MIN_WAVES) void k_blend(const uint32_t* __restrict__ items,
                                                          const uint32_t* __restrict__ seg_start,
                                                          const uint32_t* __restrict__ bin_start,
                                                          const uint32_t* __restrict__ list,
@@ -42,8 +45,8 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t* __restr
                                                          BinGrid g, float eps, uint32_t seg_len, uint32_t capacity, uint32_t nsplats)
 {
     __shared__ float4 s_ra[CHUNK];   // cx, cy, ux, uy
-    __shared__ float4 s_rb[CHUNK];   // wx, wy, log2(opacity), red
-    __shared__ float2 s_rc[CHUNK];   // green, blue
+    __shared__ float4 s_rb[CHUNK];   // wx, wy, log2(opacity), blue
+    __shared__ float2 s_rc[CHUNK];   // red, green (one ds_read_b64 into an aligned register pair)
     __shared__ uint32_t s_mask[CHUNK];
     __shared__ uint32_t s_done;
     __shared__ uint32_t s_item;
@@ -124,9 +127,9 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t* __restr
                 }
                 const uint32_t rgb8 = __float_as_uint(rb.w);
                 s_ra[threadIdx.x] = ra;
-                s_rb[threadIdx.x] = make_float4(rb.x, rb.y, rb.z, (float)(rgb8 & 0xffu) * (1.0f / 255.0f));
-                s_rc[threadIdx.x] = make_float2((float)((rgb8 >> 8) & 0xffu) * (1.0f / 255.0f),
-                                                (float)((rgb8 >> 16) & 0xffu) * (1.0f / 255.0f));
+                s_rb[threadIdx.x] = make_float4(rb.x, rb.y, rb.z, (float)((rgb8 >> 16) & 0xffu) * (1.0f / 255.0f));
+                s_rc[threadIdx.x] = make_float2((float)(rgb8 & 0xffu) * (1.0f / 255.0f),
+                                                (float)((rgb8 >> 8) & 0xffu) * (1.0f / 255.0f));
             }
             s_mask[threadIdx.x] = mask;
             __syncthreads();
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_blend(const uint32_t* __restr
                         const float4 ra = s_ra[c0 + j];
                         const float4 rb = s_rb[c0 + j];
                         const float2 rc = s_rc[c0 + j];
-                        const float cr = rb.w, cg = rc.x, cb = rc.y;
+                        const float cr = rc.x, cg = rc.y, cb = rb.w;
                         const float dx0 = pxf0 - ra.x, dx1 = pxf1 - ra.x;
                         const float dy0 = pyf0 - ra.y, dy1 = pyf1 - ra.y;
                         const float uy0 = ra.w * dy0, uy1 = ra.w * dy1;
