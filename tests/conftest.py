@@ -6,6 +6,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "gsplat.js_amd", "py"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def pytest_configure(config):

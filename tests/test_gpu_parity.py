@@ -241,3 +241,60 @@ def test_torch_zero_copy_framebuffer(gh, scenes):
     assert t.shape == (cfg["height"], cfg["width"], 4) and t.data_ptr() == r.framebuffer_ptr()
     assert np.array_equal(t.cpu().numpy(), r.readPixelsFloat())
     r.dispose()
+
+
+def test_api_errors_and_resize(gh, oracle, scenes):
+    rows, data, pos = scenes(3000, 31)
+    r = gh.HIPRenderer(160, 96)
+    # call order: render before a camera is an error with a message, not a crash
+    r.set_raw_scene(data, pos)
+    with pytest.raises(gh.GsplatError, match="gsr_set_camera"):
+        r.render_async()
+    # positions must equal data words 0..2 (Scene.ts keeps them in sync)
+    with pytest.raises(gh.GsplatError, match="positions differ"):
+        r.set_raw_scene(data, pos + 1.0)
+    r.set_raw_scene(data, pos)
+    with pytest.raises(gh.GsplatError):
+        r.set_band(10, 50)          # not on a bin boundary
+    with pytest.raises(gh.GsplatError):
+        r.setSize(0, 10)
+    # resize re-allocates and the next frame matches the oracle at the new size
+    for (W, H) in ((160, 96), (321, 203), (64, 64)):
+        r.setSize(W, H)
+        cam = gh.orbit_camera(4, width=W, height=H, fx=300.0)
+        r.set_camera(cam)
+        r.render_async(); r.sync()
+        v, p, vp = cam.f32()
+        oimg = oracle.render_scene(data, pos, v, p, vp, cam.fx, cam.fy, W, H, mode=1)[0]
+        assert np.abs(r.readPixelsFloat().astype(np.float64) - oimg).max() <= TOL_EXACT
+    # scene replacement with a different size
+    rows2, data2, pos2 = scenes(777, 32)
+    r.set_raw_scene(data2, pos2)
+    r.render_async(); r.sync()
+    assert r.lastDepthIndex().size == 777
+    r.dispose()
+    r.dispose()   # idempotent
+
+
+def test_giant_and_degenerate_splats(gh, oracle):
+    # a splat covering the whole screen (axis clamp 1024 px), a needle, a zero-opacity splat, and a tiny one
+    from test_oracle_render import make_scene, front_camera
+    W, H, fx = 640, 352, 900.0
+    data, pos = make_scene(oracle, [
+        dict(pos=(0.02, 0.01, 0), scale=(3.0, 2.5, 2.0), rgba=(200, 100, 50, 90), rot=(200, 160, 90, 130)),
+        dict(pos=(0.4, -0.2, 0.5), scale=(1.5, 0.002, 0.002), rgba=(10, 250, 30, 255), rot=(190, 100, 160, 140)),
+        dict(pos=(-0.5, 0.3, -0.5), scale=(0.3, 0.3, 0.3), rgba=(255, 255, 255, 0), rot=(255, 128, 128, 128)),
+        dict(pos=(0.7, 0.4, 1.0), scale=(0.001, 0.001, 0.001), rgba=(255, 0, 255, 255), rot=(130, 250, 128, 20)),
+    ])
+    cam = front_camera(W, H, fx, -4.0)
+    r = gh.HIPRenderer(W, H)
+    r.set_raw_scene(data, pos)
+    r.set_camera(cam)
+    r.render_async(); r.sync()
+    img = r.readPixelsFloat()
+    v, p, vp = cam.f32()
+    oimg, odi, V, D = oracle.render_scene(data, pos, v, p, vp, cam.fx, cam.fy, W, H, mode=1)
+    assert np.array_equal(r.lastDepthIndex(), odi)
+    assert r.stats()["visible"] == V and V >= 3
+    assert np.abs(img.astype(np.float64) - oimg).max() <= TOL_EXACT
+    r.dispose()
