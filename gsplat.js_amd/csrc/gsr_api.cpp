@@ -45,6 +45,11 @@ struct gsr_ctx {
     uint32_t n = 0;
     float *px = nullptr, *py = nullptr, *pz = nullptr;
     uint32_t *cov0 = nullptr, *cov1 = nullptr, *cov2 = nullptr, *rgba = nullptr;
+    // spherical harmonics (optional)
+    uint32_t *sh_r = nullptr, *sh_g = nullptr, *sh_b = nullptr;
+    float4* shcol = nullptr;
+    uint32_t sh_count = 0;
+    int32_t band[3] = {-1, -1, -1};
     // per frame, sized by n
     int32_t* depth = nullptr;
     uint32_t *keys = nullptr, *keys_tmp = nullptr, *idx_tmp = nullptr, *depth_index = nullptr;
@@ -210,10 +215,12 @@ int enqueue_frame(gsr_ctx* c, bool render)
         c->ev_is_render[slot] = render;
     }
     c->cam.W = c->W; c->cam.H = c->H;
+    c->cam.sh_on = c->sh_count ? 1 : 0;
+    c->cam.band[0] = c->band[0]; c->cam.band[1] = c->band[1]; c->cam.band[2] = c->band[2];
     HIP_TRY(c, hipMemcpyAsync(c->fstate, c->fstate_init, sizeof(FrameState), hipMemcpyDeviceToDevice, s));
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BEGIN], s));
     if (c->n) {
-        SceneSoA sc{c->px, c->py, c->pz, c->cov0, c->cov1, c->cov2, c->rgba};
+        SceneSoA sc{c->px, c->py, c->pz, c->cov0, c->cov1, c->cov2, c->rgba, c->sh_r, c->sh_g, c->sh_b, c->shcol};
         launch_project_key(sc, c->n, c->cam, render ? 1 : 0, c->depth, c->fstate->minmax, c->rec, c->bbox, s);
     }
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_PROJECT], s));
@@ -232,7 +239,7 @@ int enqueue_frame(gsr_ctx* c, bool render)
                       c->accum, c->bin_capacity, c->max_items, c->seg_len, c->bin_blocks};
         launch_bin(bb, g, c->n, s);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BIN], s));
-        BlendBuffers bl{c->items, c->seg_start, c->bin_start, c->bin_list, c->rec, c->bbox, c->fb, c->partial,
+        BlendBuffers bl{c->items, c->seg_start, c->bin_start, c->bin_list, c->rec, c->bbox, c->shcol, c->fb, c->partial,
                         &c->fstate->queue, c->seg_len, std::min<uint32_t>(c->max_items, getenv("GSR_BLEND_GRID") ? (uint32_t)atol(getenv("GSR_BLEND_GRID")) : 2048u), c->bin_capacity,
                         std::max(c->n, 1u)};
         launch_blend(bl, g, c->opt.early_out_eps, s);
@@ -370,6 +377,7 @@ int gsr_destroy(gsr_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dev_free(&c->px); dev_free(&c->py); dev_free(&c->pz);
     dev_free(&c->cov0); dev_free(&c->cov1); dev_free(&c->cov2); dev_free(&c->rgba);
+    dev_free(&c->sh_r); dev_free(&c->sh_g); dev_free(&c->sh_b); dev_free(&c->shcol);
     dev_free(&c->depth); dev_free(&c->keys); dev_free(&c->keys_tmp); dev_free(&c->idx_tmp); dev_free(&c->depth_index);
     dev_free(&c->block_hist); dev_free(&c->rec); dev_free(&c->bbox);
     dev_free(&c->bin_table); dev_free(&c->bin_total); dev_free(&c->bin_start); dev_free(&c->bin_list);
@@ -391,6 +399,8 @@ int gsr_set_scene(gsr_ctx* c, const uint32_t* data, const float* positions, uint
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->n = 0; c->have_frame = false; c->have_sort = false;
+    c->sh_count = 0; c->band[0] = c->band[1] = c->band[2] = -1;
+    dev_free(&c->sh_r); dev_free(&c->sh_g); dev_free(&c->sh_b); dev_free(&c->shcol);
     int r;
     if ((r = dev_alloc(c, &c->px, n)) || (r = dev_alloc(c, &c->py, n)) || (r = dev_alloc(c, &c->pz, n)) ||
         (r = dev_alloc(c, &c->cov0, n)) || (r = dev_alloc(c, &c->cov1, n)) || (r = dev_alloc(c, &c->cov2, n)) ||
@@ -422,6 +432,33 @@ int gsr_set_scene(gsr_ctx* c, const uint32_t* data, const float* positions, uint
     c->n = n;
     c->bin_capacity = 0;
     return alloc_bins(c);
+}
+
+int gsr_set_scene_sh(gsr_ctx* c, const uint32_t* sh_r, const uint32_t* sh_g, const uint32_t* sh_b, uint32_t sh_count,
+                     const int32_t* band_index)
+{
+    if (!c) return GSR_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->sh_count = 0; c->band[0] = c->band[1] = c->band[2] = -1;
+    c->have_frame = false;
+    if (!sh_count) return GSR_OK;
+    if (!sh_r || !sh_g || !sh_b || !band_index) return fail(c, GSR_ERR_ARG, "SH texture or band_index pointer is NULL");
+    if (band_index[0] < -1 || (uint64_t)(band_index[0] + 1) + sh_count != c->n)
+        return fail(c, GSR_ERR_SCENE, "sh_count (%u) must be vertexCount (%u) - (bandsIndices[0] + 1) (%d)", sh_count, c->n,
+                    band_index[0] + 1);
+    int r;
+    if ((r = dev_alloc(c, &c->sh_r, (size_t)sh_count * 8)) || (r = dev_alloc(c, &c->sh_g, (size_t)sh_count * 8)) ||
+        (r = dev_alloc(c, &c->sh_b, (size_t)sh_count * 8)) || (r = dev_alloc(c, &c->shcol, (size_t)c->n)))
+        return r;
+    HIP_TRY(c, hipMemcpyAsync(c->sh_r, sh_r, (size_t)sh_count * 32, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->sh_g, sh_g, (size_t)sh_count * 32, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->sh_b, sh_b, (size_t)sh_count * 32, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->shcol, 0, (size_t)c->n * sizeof(float4), c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->sh_count = sh_count;
+    c->band[0] = band_index[0]; c->band[1] = band_index[1]; c->band[2] = band_index[2];
+    return GSR_OK;
 }
 
 int gsr_resize(gsr_ctx* c, int32_t w, int32_t h)
@@ -582,6 +619,16 @@ int gsr_read_records(gsr_ctx* c, float* rec, int32_t* bbox)
             bbox[4 * (size_t)i + 2] = (int32_t)(tmp[i].x >> 16);
             bbox[4 * (size_t)i + 3] = (int32_t)(tmp[i].y >> 16);
         }
+    return GSR_OK;
+}
+
+int gsr_read_sh_colors(gsr_ctx* c, float* rgba)
+{
+    if (!c || !rgba) return c ? fail(c, GSR_ERR_ARG, "out is NULL") : GSR_ERR_ARG;
+    if (!c->have_frame || !c->sh_count) return fail(c, GSR_ERR_ARG, "no frame rendered with SH colours yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(rgba, c->shcol, (size_t)c->n * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return GSR_OK;
 }
 

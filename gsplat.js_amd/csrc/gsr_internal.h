@@ -25,6 +25,8 @@ struct CamParams {
     float vp2, vp6, vp10;   // row 2 of viewProj: wasm/wasm.cpp:18-20
     float fx, fy;
     int32_t W, H;
+    int32_t sh_on;          // scene carries SH textures
+    int32_t band[3];        // Scene.bandsIndices
 };
 
 // 32-byte projected record consumed by the tile compositor (image coordinates, row 0 = top).
@@ -32,8 +34,9 @@ struct CamParams {
 struct __attribute__((aligned(16))) Record {
     float cx, cy, ux, uy;
     float wx, wy, la;       // la = log2(opacity)
-    uint32_t rgb8;          // r | g<<8 | b<<16
+    uint32_t rgb8;          // r | g<<8 | b<<16; or RGB8_IN_SHCOL: the colour is the float triple shcol[splat]
 };
+constexpr uint32_t RGB8_IN_SHCOL = 0x01000000u;
 static_assert(sizeof(Record) == 32, "record must be 32 bytes");
 
 // Packed inclusive pixel bounding box: x = x0 | x1<<16, y = y0 | y1<<16; invisible when x0 > x1.
@@ -43,6 +46,8 @@ constexpr uint32_t BBOX_INVISIBLE_Y = 1u;
 struct SceneSoA {
     const float *px, *py, *pz;
     const uint32_t *cov0, *cov1, *cov2, *rgba;
+    const uint32_t *sh_r, *sh_g, *sh_b;  // 8 u32 per SH-carrying splat and channel (null without SH)
+    float4* shcol;                       // out: evaluated SH colour per splat (null without SH)
 };
 
 // ---- launchers (each enqueues on `s`; none synchronises) ----
@@ -100,6 +105,7 @@ struct BlendBuffers {
     const uint32_t* list;
     const Record* rec;
     const uint2* bbox;
+    const float4* shcol;        // evaluated SH colours (may be null)
     float4* fb;
     float4* partial;            // max_items * 1024 float4: per-segment (colour, transmittance), slot = seg_start[bin] + segment
     uint32_t* queue;            // device-wide work-item counter, zero at frame start

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(BLEND_THREADS, GSR_BLEND_MIN_WAVES) void k_blend(co
                                                          const uint32_t* __restrict__ bin_start,
                                                          const uint32_t* __restrict__ list,
                                                          const Record* __restrict__ rec,
-                                                         float4* __restrict__ fb,
+                                                         const float4* __restrict__ shcol, float4* __restrict__ fb,
                                                          float4* __restrict__ partial, uint32_t* __restrict__ queue,
                                                          BinGrid g, float eps, uint32_t seg_len, uint32_t capacity, uint32_t nsplats)
 {
@@ -126,10 +126,15 @@ __global__ __launch_bounds__(BLEND_THREADS, GSR_BLEND_MIN_WAVES) void k_blend(co
                     }
                 }
                 const uint32_t rgb8 = __float_as_uint(rb.w);
+                float cr = (float)(rgb8 & 0xffu) * (1.0f / 255.0f), cg = (float)((rgb8 >> 8) & 0xffu) * (1.0f / 255.0f),
+                      cb = (float)((rgb8 >> 16) & 0xffu) * (1.0f / 255.0f);
+                if (rgb8 & RGB8_IN_SHCOL) {  // SH-coloured splat: the projection kernel evaluated its colour for this view
+                    const float4 sc = shcol[i];
+                    cr = sc.x; cg = sc.y; cb = sc.z;
+                }
                 s_ra[threadIdx.x] = ra;
-                s_rb[threadIdx.x] = make_float4(rb.x, rb.y, rb.z, (float)((rgb8 >> 16) & 0xffu) * (1.0f / 255.0f));
-                s_rc[threadIdx.x] = make_float2((float)(rgb8 & 0xffu) * (1.0f / 255.0f),
-                                                (float)((rgb8 >> 8) & 0xffu) * (1.0f / 255.0f));
+                s_rb[threadIdx.x] = make_float4(rb.x, rb.y, rb.z, cb);
+                s_rc[threadIdx.x] = make_float2(cr, cg);
             }
             s_mask[threadIdx.x] = mask;
             __syncthreads();
@@ -242,7 +247,7 @@ void launch_blend(const BlendBuffers& b, const BinGrid& g, float early_out_eps, 
     const int nbins = (g.bx_hi - g.bx_lo) * g.nby;
     if (nbins <= 0) return;
     hipLaunchKernelGGL(k_blend, dim3(b.grid), dim3(BLEND_THREADS), 0, s, b.items, b.seg_start, b.bin_start, b.list, b.rec,
-                       b.fb, b.partial, b.queue, g, early_out_eps, b.seg_len, b.capacity, b.nsplats);
+                       b.shcol, b.fb, b.partial, b.queue, g, early_out_eps, b.seg_len, b.capacity, b.nsplats);
     if (b.seg_len < 0x40000000u)
         hipLaunchKernelGGL(k_combine, dim3(nbins), dim3(BLEND_THREADS), 0, s, b.seg_start, (const float4*)b.partial, b.fb, g);
 }

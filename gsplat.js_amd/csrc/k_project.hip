@@ -64,6 +64,56 @@ __device__ __forceinline__ bool finite4(float a, float b, float c, float d)
 }
 
 // ---------------------------------------------------------------------------
+// SH colour, vertex.glsl.ts:57-104 (eval_sh_rgb) in f32, products and sums in the written order.
+// k[0..15]: the 16 coefficients of one colour channel.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float eval_sh_channel(const float* k, uint32_t deg, float x, float y, float z)
+{
+    constexpr float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+    constexpr float C2_0 = 1.0925484305920792f, C2_1 = -1.0925484305920792f, C2_2 = 0.31539156525252005f,
+                    C2_3 = -1.0925484305920792f, C2_4 = 0.5462742152960396f;
+    constexpr float C3_0 = -0.5900435899266435f, C3_1 = 2.890611442640554f, C3_2 = -0.4570457994644658f,
+                    C3_3 = 0.3731763325901154f, C3_4 = -0.4570457994644658f, C3_5 = 1.445305721320277f,
+                    C3_6 = -0.5900435899266435f;
+    float r = C0 * k[0];
+    if (deg > 0) {
+        r = r - ((((C1 * y) * k[1]) + ((C1 * z) * k[2])) - ((C1 * x) * k[3]));
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            float s2 = (C2_0 * xy) * k[4];
+            s2 = s2 + (C2_1 * yz) * k[5];
+            s2 = s2 + (C2_2 * ((2.0f * zz - xx) - yy)) * k[6];
+            s2 = s2 + (C2_3 * xz) * k[7];
+            s2 = s2 + (C2_4 * (xx - yy)) * k[8];
+            r = r + s2;
+            if (deg > 2) {
+                float s3 = ((C3_0 * y) * (3.0f * xx - yy)) * k[9];
+                s3 = s3 + ((C3_1 * xy) * z) * k[10];
+                s3 = s3 + ((C3_2 * y) * ((4.0f * zz - xx) - yy)) * k[11];
+                s3 = s3 + ((C3_3 * z) * ((2.0f * zz - 3.0f * xx) - 3.0f * yy)) * k[12];
+                s3 = s3 + ((C3_4 * x) * ((4.0f * zz - xx) - yy)) * k[13];
+                s3 = s3 + ((C3_5 * z) * (xx - yy)) * k[14];
+                s3 = s3 + ((C3_6 * x) * (xx - 3.0f * yy)) * k[15];
+                r = r + s3;
+            }
+        }
+    }
+    r = r + 0.5f;
+    r = (r > 0.0f) ? r : 0.0f;  // :103 max(result, 0)
+    return (r < 1.0f) ? r : 1.0f;  // :200 min(rgb, 1)
+}
+
+__device__ __forceinline__ float eval_sh_texture(const uint32_t* __restrict__ tex, uint32_t t, uint32_t deg, float x, float y, float z)
+{
+    const uint4 a = reinterpret_cast<const uint4*>(tex)[2 * (size_t)t], b = reinterpret_cast<const uint4*>(tex)[2 * (size_t)t + 1];
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    float k[16];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { k[2 * j] = half_bits_to_float(w[j]); k[2 * j + 1] = half_bits_to_float(w[j] >> 16); }
+    return eval_sh_channel(k, deg, x, y, z);
+}
+
+// ---------------------------------------------------------------------------
 // One thread per splat, original order (fully coalesced SoA reads).
 //   A1  depth key + min/max        wasm/wasm.cpp:14-31
 //   B1-B6 projection               vertex.glsl.ts:130-231 (non-SH colour branch, scalingFactor 1)
@@ -174,6 +224,25 @@ __global__ __launch_bounds__(256) void k_project_key(SceneSoA sc, uint32_t n, Ca
                 if (!(finite4(r.ux, r.uy, r.wx, r.wy) && isfinite(cx) && isfinite(cy))) break;
                 r.la = __log2f(opacity);
                 r.rgb8 = cw & 0x00ffffffu;
+                if (cam.sh_on && (int32_t)i > cam.band[0]) {  // vertex.glsl.ts:180-204
+                    const uint32_t deg = (int32_t)i > cam.band[1] ? ((int32_t)i > cam.band[2] ? 3u : 2u) : 1u;
+                    // inverse(view)[3].xyz for the rigid view matrix [A | b]: -A^T b
+                    float cp[3];
+#pragma unroll
+                    for (int q = 0; q < 3; q++) {
+                        float t = cam.view[q * 4 + 0] * cam.view[12];
+                        t = t + cam.view[q * 4 + 1] * cam.view[13];
+                        t = t + cam.view[q * 4 + 2] * cam.view[14];
+                        cp[q] = -t;
+                    }
+                    const float dvx = x - cp[0], dvy = y - cp[1], dvz = z - cp[2];
+                    const float dl = sqrtf((dvx * dvx + dvy * dvy) + dvz * dvz);
+                    const float dxn = dvx / dl, dyn = dvy / dl, dzn = dvz / dl;
+                    const uint32_t t = i - (uint32_t)(cam.band[0] + 1);
+                    sc.shcol[i] = make_float4(eval_sh_texture(sc.sh_r, t, deg, dxn, dyn, dzn), eval_sh_texture(sc.sh_g, t, deg, dxn, dyn, dzn),
+                                              eval_sh_texture(sc.sh_b, t, deg, dxn, dyn, dzn), 0.0f);
+                    r.rgb8 = RGB8_IN_SHCOL;
+                }
                 // bounding box of the |vPosition| <= 2 ellipse, pixel centres at +0.5
                 const float ex = sqrtf(majx * majx + minx * minx);
                 const float ey = sqrtf(majy * majy + miny * miny);

@@ -147,6 +147,28 @@ napi_value SetScene(napi_env env, napi_callback_info info)
     return rc ? throw_gsr(env, c, rc, "gsr_set_scene") : undefined(env);
 }
 
+// setSceneSh(handle, Uint32Array r, Uint32Array g, Uint32Array b, shCount, Int32Array bandsIndices)
+napi_value SetSceneSh(napi_env env, napi_callback_info info)
+{
+    napi_value argv[6];
+    if (!get_args(env, info, 6, argv)) return nullptr;
+    gsr_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return nullptr;
+    void *t[3], *band;
+    size_t len[3], nb;
+    int32_t count;
+    for (int k = 0; k < 3; k++)
+        if (!get_typed(env, argv[1 + k], napi_uint32_array, &t[k], &len[k])) return nullptr;
+    if (!get_i32(env, argv[4], &count) || !get_typed(env, argv[5], napi_int32_array, &band, &nb)) return nullptr;
+    if (count < 0 || nb < 3 || len[0] < (size_t)count * 8 || len[1] < (size_t)count * 8 || len[2] < (size_t)count * 8) {
+        napi_throw_range_error(env, nullptr, "SH buffers are smaller than shCount requires");
+        return nullptr;
+    }
+    const int rc = gsr_set_scene_sh(c, (const uint32_t*)t[0], (const uint32_t*)t[1], (const uint32_t*)t[2], (uint32_t)count,
+                                    (const int32_t*)band);
+    return rc ? throw_gsr(env, c, rc, "gsr_set_scene_sh") : undefined(env);
+}
+
 napi_value Resize(napi_env env, napi_callback_info info)
 {
     napi_value argv[3];
@@ -308,7 +330,7 @@ napi_value SortHost(napi_env env, napi_callback_info info)
 napi_value Init(napi_env env, napi_value exports)
 {
     struct { const char* name; napi_callback fn; } fns[] = {
-        {"create", Create}, {"destroy", Destroy}, {"setScene", SetScene}, {"resize", Resize}, {"setBand", SetBand},
+        {"create", Create}, {"destroy", Destroy}, {"setScene", SetScene}, {"setSceneSh", SetSceneSh}, {"resize", Resize}, {"setBand", SetBand},
         {"setCamera", SetCamera}, {"sort", Call0<gsr_sort>}, {"render", Call0<gsr_render>},
         {"renderAsync", Call0<gsr_render_async>}, {"sync", Call0<gsr_sync>}, {"resetTimings", Call0<gsr_reset_timings>},
         {"readDepthIndex", ReadDepthIndex}, {"readPixels", ReadPixels}, {"getTimings", GetTimings},

@@ -42,6 +42,7 @@ class HIPRenderer {
         const upload = () => {   // initWebGL's scene part: worker init + texImage2D (WebGLRenderer.ts:105-110,185-195)
             vertexCount = activeScene.vertexCount;
             this._n.setScene(this._h, activeScene.data, activeScene.positions, vertexCount);
+            this.setShTextures();
             for (const p of passes) p.init(this, null);
             initialized = true;
         };
@@ -63,6 +64,13 @@ class HIPRenderer {
             this._n.setCamera(this._h, f32.view, f32.proj, f32.vp, activeCamera.fx, activeCamera.fy);
         };
         this.setCameraBuffers = () => pushCamera();
+        // SH textures + u_bandIndex, only for scenes that carry SH data (WebGLRenderer.ts:202-211,321-366)
+        this.setShTextures = () => {
+            if (!activeScene || !activeScene.shHeight) return;
+            const band = activeScene.bandsIndices;
+            const t = activeScene.shs_rgb;
+            this._n.setSceneSh(this._h, t[0], t[1], t[2], activeScene.vertexCount - (band[0] + 1), band);
+        };
 
         // WebGLRenderer.ts:241-296
         this.render = (scene, camera) => {

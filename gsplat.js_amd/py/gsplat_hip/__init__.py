@@ -46,7 +46,7 @@ _lib = None
 
 # every symbol include/gsplat_hip.h declares
 EXPORTS = [
-    "gsr_create", "gsr_destroy", "gsr_last_error", "gsr_set_scene", "gsr_resize", "gsr_set_band", "gsr_set_camera",
+    "gsr_create", "gsr_destroy", "gsr_last_error", "gsr_set_scene", "gsr_set_scene_sh", "gsr_read_sh_colors", "gsr_resize", "gsr_set_band", "gsr_set_camera",
     "gsr_sort", "gsr_render", "gsr_render_async", "gsr_sync", "gsr_read_depth_index", "gsr_read_pixels_rgba32f",
     "gsr_read_pixels_rgba8", "gsr_get_timings", "gsr_reset_timings", "gsr_read_keys", "gsr_read_records",
     "gsr_framebuffer_device_ptr", "gsr_stream_handle", "gsr_device_info", "gsplat_sort_host",
@@ -68,6 +68,8 @@ def load_library(path=None):
     L.gsr_last_error.argtypes = [vp]
     L.gsr_last_error.restype = ctypes.c_char_p
     L.gsr_set_scene.argtypes = [vp, vp, vp, ctypes.c_uint32]
+    L.gsr_set_scene_sh.argtypes = [vp, vp, vp, vp, ctypes.c_uint32, vp]
+    L.gsr_read_sh_colors.argtypes = [vp, vp]
     L.gsr_resize.argtypes = [vp, ctypes.c_int32, ctypes.c_int32]
     L.gsr_set_band.argtypes = [vp, ctypes.c_int32, ctypes.c_int32]
     L.gsr_set_camera.argtypes = [vp, vp, vp, vp, ctypes.c_float, ctypes.c_float]
@@ -133,6 +135,9 @@ class Scene:
         self.vertexCount = 0
         self.width = 2048
         self.height = 0
+        self.shHeight = 0
+        self.shs_rgb = [np.zeros(0, dtype=np.uint32) for _ in range(3)]
+        self.bandsIndices = np.array([-1, -1, -1], dtype=np.int32)
 
     # EventDispatcher surface used by the renderer (src/core/EventDispatcher.ts)
     def addEventListener(self, kind, fn):
@@ -146,8 +151,8 @@ class Scene:
         for fn in list(self._listeners.get(kind, [])):
             fn({"type": kind})
 
-    def setData(self, rows):
-        """Scene.ts:58-180 without the SH branch."""
+    def setData(self, rows, shs=None):
+        """Scene.ts:58-180.  shs: 48 floats per SH-carrying splat (set bandsIndices first, like the loader does)."""
         rows = np.ascontiguousarray(rows, dtype=np.uint8).reshape(-1)
         if rows.size % self.RowLength:
             raise ValueError("data length must be a multiple of %d" % self.RowLength)
@@ -180,6 +185,18 @@ class Scene:
         d[:, 5] = pack_half2x16(4 * sg[2], 4 * sg[3])
         d[:, 6] = pack_half2x16(4 * sg[4], 4 * sg[5])
         self.data = data
+        if shs is not None:   # Scene.ts:83-124: three half textures, one per colour channel
+            shs = np.ascontiguousarray(shs, dtype=np.float32).reshape(-1)
+            count = n - (int(self.bandsIndices[0]) + 1)
+            self.shHeight = -(-(2 * count) // self.width)
+            c = shs[:count * 48].reshape(count, 8, 2, 3).astype(np.float64)   # (splat, word, half, channel)
+            self.shs_rgb = []
+            for ch in range(3):
+                tex = np.zeros(self.width * self.shHeight * 4, dtype=np.uint32)
+                tex[:8 * count] = pack_half2x16(c[:, :, 0, ch].reshape(-1), c[:, :, 1, ch].reshape(-1))
+                self.shs_rgb.append(tex)
+        else:
+            self.shHeight = 0
         self.dispatchEvent("change")
 
 
@@ -213,6 +230,8 @@ class HIPRenderer:
         pos = np.ascontiguousarray(scene.positions, dtype=np.float32)
         self._check(self._L.gsr_set_scene(self._ctx, data.ctypes.data, pos.ctypes.data, scene.vertexCount))
         self._n = scene.vertexCount
+        if getattr(scene, "shHeight", 0):   # WebGLRenderer.ts:202-211: SH textures + u_bandIndex only when the scene has them
+            self.set_sh(scene.shs_rgb, scene.bandsIndices)
 
     # -- reference surface --
     def setSize(self, width, height):
@@ -230,6 +249,18 @@ class HIPRenderer:
         self._check(self._L.gsr_set_scene(self._ctx, data.ctypes.data, pos.ctypes.data, n))
         self._n = n
         self._scene = None
+
+    def set_sh(self, shs_rgb, bands_indices):
+        band = np.ascontiguousarray(bands_indices, dtype=np.int32)
+        count = self._n - (int(band[0]) + 1)
+        tex = [np.ascontiguousarray(t, dtype=np.uint32) for t in shs_rgb]
+        self._check(self._L.gsr_set_scene_sh(self._ctx, tex[0].ctypes.data, tex[1].ctypes.data, tex[2].ctypes.data, count,
+                                             band.ctypes.data))
+
+    def read_sh_colors(self):
+        out = np.empty((self._n, 4), dtype=np.float32)
+        self._check(self._L.gsr_read_sh_colors(self._ctx, out.ctypes.data))
+        return out
 
     def set_camera(self, camera):
         camera.update(self.width, self.height)

@@ -15,6 +15,8 @@
  *   worker scene init                Worker.ts:23-34 (positions copied once per scene)
  *   + texImage2D(scene.data)         src/renderers/WebGLRenderer.ts:185-195
  *                                      -> gsr_set_scene
+ *   setShTextures + u_bandIndex      WebGLRenderer.ts:202-211,321-366
+ *                                      -> gsr_set_scene_sh
  *   uniforms projection/view/focal/viewport + postMessage({viewProj})
  *                                    WebGLRenderer.ts:144-159,268-269,275
  *                                      -> gsr_set_camera, gsr_resize
@@ -84,6 +86,14 @@ const char *gsr_last_error(gsr_ctx *ctx); /* ctx may be NULL: error of the faile
  * Repacked once into SoA on the device. */
 int gsr_set_scene(gsr_ctx *ctx, const uint32_t *data, const float *positions, uint32_t n);
 
+/* Spherical-harmonics colour (the fork's SH textures): sh_r/g/b = Scene.shs_rgb (8 u32 = 16 truncated halves per
+ * SH-carrying splat and channel, src/core/Scene.ts:108-124; uploaded by setShTextures, WebGLRenderer.ts:321-366),
+ * band_index = Scene.bandsIndices (uniform u_bandIndex, WebGLRenderer.ts:209-211): splat i > band_index[0] takes its
+ * colour from eval_sh_rgb (vertex.glsl.ts:57-104,180-204) with degree 1/2/3 by band_index[1], band_index[2].
+ * sh_count must be n - (band_index[0] + 1).  Call after gsr_set_scene (which clears any SH state); sh_count 0 clears. */
+int gsr_set_scene_sh(gsr_ctx *ctx, const uint32_t *sh_r, const uint32_t *sh_g, const uint32_t *sh_b, uint32_t sh_count,
+                     const int32_t *band_index /* 3 */);
+
 /* ---- per resize / per frame ---- */
 int gsr_resize(gsr_ctx *ctx, int32_t width, int32_t height);
 int gsr_set_band(gsr_ctx *ctx, int32_t x0, int32_t x1);
@@ -106,6 +116,7 @@ int gsr_reset_timings(gsr_ctx *ctx);
 /* ---- parity/debug read-backs (intermediate device buffers of the last frame) ---- */
 int gsr_read_keys(gsr_ctx *ctx, uint32_t *keys /* n, 17-bit */, int32_t *minmax /* 2 */);
 int gsr_read_records(gsr_ctx *ctx, float *rec /* 8n */, int32_t *bbox /* 4n: x0,y0,x1,y1 */);
+int gsr_read_sh_colors(gsr_ctx *ctx, float *rgba /* 4n: evaluated SH colour of every splat that has one */);
 
 /* ---- device interop (torch / RCCL plumbing in the harness) ---- */
 void *gsr_framebuffer_device_ptr(gsr_ctx *ctx); /* float4[h][w] on the device */

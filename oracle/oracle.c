@@ -137,6 +137,20 @@ uint32_t orc_pack_half2x16(double x, double y)
     return (orc_float_to_half(x) | (orc_float_to_half(y) << 16));
 }
 
+/* Scene.ts:108-124: shs holds 48 floats per SH-carrying splat, laid out (coefficient k, channel c) at 3k+c; texture c,
+ * word j of a splat packs coefficients 2j (low half) and 2j+1 (high half) of channel c. */
+void orc_scene_pack_sh(const float *shs, uint32_t count, uint32_t *sh_r, uint32_t *sh_g, uint32_t *sh_b)
+{
+    uint32_t *out[3] = { sh_r, sh_g, sh_b };
+    for (uint32_t i = 0; i < count; i++) {
+        uint32_t ind = i * 48;
+        for (int j = 0; j < 8; j++) {
+            for (int c = 0; c < 3; c++) out[c][8 * (size_t)i + j] = orc_pack_half2x16(shs[ind + c], shs[ind + 3 + c]);
+            ind += 6;
+        }
+    }
+}
+
 void orc_scene_pack(const uint8_t *rows, uint32_t n, uint32_t *data, float *positions)
 {
     for (uint32_t i = 0; i < n; i++) {
@@ -231,12 +245,80 @@ static void mat3_transpose(const float *a, float *r)
         for (int ro = 0; ro < 3; ro++) r[c * 3 + ro] = a[ro * 3 + c];
 }
 
+
+/* ------------------------------------------------------------------------
+ * SH colour: vertex.glsl.ts:9-104 (constants, fill_sh_from_packed, eval_sh_rgb) and :180-204.
+ * Three RGBA32UI textures (one per colour channel), 8 u32 = 16 truncated halves per splat
+ * (Scene.ts:108-124); coefficient k of channel c is half k of texture c.  f32, products and sums in the
+ * written order (left to right), no fused multiply-add; normalize(v) = v / sqrt(dot(v,v)).
+ * ---------------------------------------------------------------------- */
+static const float ORC_SH_C0 = 0.28209479177387814f;
+static const float ORC_SH_C1 = 0.4886025119029199f;
+static const float ORC_SH_C2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f };
+static const float ORC_SH_C3[7] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                                    -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f };
+
+static void orc_eval_sh(const uint32_t *const sh[3], uint32_t t, uint32_t deg, const float dir[3], float rgb[3])
+{
+    float c[3][16];
+    for (int ch = 0; ch < 3; ch++)
+        for (int j = 0; j < 8; j++) {
+            uint32_t w = sh[ch][(size_t)8 * t + j];
+            c[ch][2 * j] = half_to_float(w & 0xffff);
+            c[ch][2 * j + 1] = half_to_float(w >> 16);
+        }
+    const float x = dir[0], y = dir[1], z = dir[2];
+    for (int ch = 0; ch < 3; ch++) {
+        const float *k = c[ch];
+        float r = ORC_SH_C0 * k[0];
+        if (deg > 0) {
+            r = r - ((((ORC_SH_C1 * y) * k[1]) + ((ORC_SH_C1 * z) * k[2])) - ((ORC_SH_C1 * x) * k[3]));
+            if (deg > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                float s2 = (ORC_SH_C2[0] * xy) * k[4];
+                s2 = s2 + (ORC_SH_C2[1] * yz) * k[5];
+                s2 = s2 + (ORC_SH_C2[2] * ((2.0f * zz - xx) - yy)) * k[6];
+                s2 = s2 + (ORC_SH_C2[3] * xz) * k[7];
+                s2 = s2 + (ORC_SH_C2[4] * (xx - yy)) * k[8];
+                r = r + s2;
+                if (deg > 2) {
+                    float s3 = ((ORC_SH_C3[0] * y) * (3.0f * xx - yy)) * k[9];
+                    s3 = s3 + ((ORC_SH_C3[1] * xy) * z) * k[10];
+                    s3 = s3 + ((ORC_SH_C3[2] * y) * ((4.0f * zz - xx) - yy)) * k[11];
+                    s3 = s3 + ((ORC_SH_C3[3] * z) * ((2.0f * zz - 3.0f * xx) - 3.0f * yy)) * k[12];
+                    s3 = s3 + ((ORC_SH_C3[4] * x) * ((4.0f * zz - xx) - yy)) * k[13];
+                    s3 = s3 + ((ORC_SH_C3[5] * z) * (xx - yy)) * k[14];
+                    s3 = s3 + ((ORC_SH_C3[6] * x) * (xx - 3.0f * yy)) * k[15];
+                    r = r + s3;
+                }
+            }
+        }
+        r = r + 0.5f;
+        r = (r > 0.0f) ? r : 0.0f;   /* :103 max(result, 0) */
+        r = (r < 1.0f) ? r : 1.0f;   /* :200 min(rgb, 1)    */
+        rgb[ch] = r;
+    }
+}
+
 #define ORC_INVISIBLE(bb) do { (bb)[0] = 1; (bb)[1] = 1; (bb)[2] = 0; (bb)[3] = 0; } while (0)
 
-void orc_project(const uint32_t *data, uint32_t n, const float *view, const float *proj,
-                 float fx, float fy, int W, int H,
-                 float *rec_out /*8n, nullable*/, int32_t *bbox_out /*4n, nullable*/, float *raw_out /*12n, nullable*/)
+/* sh_r/g/b (nullable together): the three SH textures; band[3] = Scene.bandsIndices (index of the last splat with
+ * 0 / <=1 / <=2 SH bands).  With SH, splat i > band[0] takes its colour from eval_sh_rgb (vertex.glsl.ts:180-204) and its
+ * record's rgb8 word is 0x01000000 ("colour is in raw[7..9]"). */
+void orc_project_sh(const uint32_t *data, uint32_t n, const float *view, const float *proj,
+                    float fx, float fy, int W, int H,
+                    const uint32_t *sh_r, const uint32_t *sh_g, const uint32_t *sh_b, const int32_t *band,
+                    float *rec_out /*8n, nullable*/, int32_t *bbox_out /*4n, nullable*/, float *raw_out /*12n, nullable*/)
 {
+    const uint32_t *const sh[3] = { sh_r, sh_g, sh_b };
+    /* inverse(view)[3].xyz (vertex.glsl.ts:197) for a rigid view matrix [A | b]: -A^T b */
+    float campos[3];
+    for (int r = 0; r < 3; r++) {
+        float t = view[r * 4 + 0] * view[12];
+        t = t + view[r * 4 + 1] * view[13];
+        t = t + view[r * 4 + 2] * view[14];
+        campos[r] = -t;
+    }
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t *d = data + (size_t)8 * i;
         float raw[12];
@@ -317,6 +399,16 @@ void orc_project(const uint32_t *data, uint32_t n, const float *view, const floa
             uint32_t cw = d[7];
             float opacity = (float)((cw >> 24) & 0xff) / 255.0f;
             float cr = (float)(cw & 0xff) / 255.0f, cg = (float)((cw >> 8) & 0xff) / 255.0f, cb = (float)((cw >> 16) & 0xff) / 255.0f;
+            int use_sh = sh_r && (int32_t)i > band[0];   /* :180 */
+            if (use_sh) {
+                uint32_t deg = (int32_t)i > band[1] ? ((int32_t)i > band[2] ? 3u : 2u) : 1u;   /* :189 */
+                float dv[3] = { p[0] - campos[0], p[1] - campos[1], p[2] - campos[2] };
+                float dl = sqrtf((dv[0] * dv[0] + dv[1] * dv[1]) + dv[2] * dv[2]);
+                float dir[3] = { dv[0] / dl, dv[1] / dl, dv[2] / dl };
+                float rgb[3];
+                orc_eval_sh(sh, i - (uint32_t)(band[0] + 1), deg, dir, rgb);
+                cr = rgb[0]; cg = rgb[1]; cb = rgb[2];
+            }
             /* :226-229 + the GL viewport transform */
             float vcx = pos2d[0] / pos2d[3], vcy = pos2d[1] / pos2d[3];
             float xw = ((vcx + 1.0f) * 0.5f) * (float)W;
@@ -341,7 +433,7 @@ void orc_project(const uint32_t *data, uint32_t n, const float *view, const floa
             fx1 = fminf(fx1, (float)(W - 1)); fy1 = fminf(fy1, (float)(H - 1));
             rec[0] = cx; rec[1] = cy; rec[2] = ux; rec[3] = uy; rec[4] = wx; rec[5] = wy;
             rec[6] = log2f(opacity); /* compared with a 2-ulp tolerance, not bitwise: v_log_f32 */
-            recu7 = cw & 0x00ffffffu;
+            recu7 = use_sh ? 0x01000000u : (cw & 0x00ffffffu);
             if (fx0 > fx1 || fy0 > fy1) break; /* off-screen: keeps raw visible flag, empty bbox */
             bb[0] = (int32_t)fx0; bb[1] = (int32_t)fy0; bb[2] = (int32_t)fx1; bb[3] = (int32_t)fy1;
         } while (0);
@@ -352,6 +444,12 @@ void orc_project(const uint32_t *data, uint32_t n, const float *view, const floa
         }
         if (bbox_out) memcpy(bbox_out + (size_t)4 * i, bb, sizeof bb);
     }
+}
+
+void orc_project(const uint32_t *data, uint32_t n, const float *view, const float *proj,
+                 float fx, float fy, int W, int H, float *rec_out, int32_t *bbox_out, float *raw_out)
+{
+    orc_project_sh(data, n, view, proj, fx, fy, W, H, NULL, NULL, NULL, NULL, rec_out, bbox_out, raw_out);
 }
 
 /* Counts used by the bench's byte model: V = splats with a

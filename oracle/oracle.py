@@ -42,6 +42,11 @@ def lib():
         L.orc_project.argtypes = [u32p, ctypes.c_uint32, f32p, f32p, ctypes.c_float, ctypes.c_float,
                                   ctypes.c_int, ctypes.c_int, f32p, i32p, f32p]
         L.orc_project.restype = None
+        L.orc_project_sh.argtypes = [u32p, ctypes.c_uint32, f32p, f32p, ctypes.c_float, ctypes.c_float,
+                                     ctypes.c_int, ctypes.c_int, u32p, u32p, u32p, i32p, f32p, i32p, f32p]
+        L.orc_project_sh.restype = None
+        L.orc_scene_pack_sh.argtypes = [f32p, ctypes.c_uint32, u32p, u32p, u32p]
+        L.orc_scene_pack_sh.restype = None
         L.orc_tile_stats.argtypes = [i32p, ctypes.c_uint32, ctypes.c_int,
                                      ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
         L.orc_tile_stats.restype = None
@@ -83,8 +88,17 @@ def float_to_half(x):
     return int(lib().orc_float_to_half(float(x)))
 
 
-def project(data, view, proj, fx, fy, W, H):
-    """(rec f32[n,8] (col 7 holds rgb8 bits), bbox i32[n,4], raw f32[n,12])."""
+def scene_pack_sh(shs):
+    """Scene.setData's SH packing (Scene.ts:108-124): 48 floats per splat -> three u32[8*count] half textures."""
+    shs = np.ascontiguousarray(shs, dtype=np.float32).reshape(-1)
+    count = shs.size // 48
+    out = [np.zeros(8 * count, dtype=np.uint32) for _ in range(3)]
+    lib().orc_scene_pack_sh(_p(shs, f32p), count, _p(out[0], u32p), _p(out[1], u32p), _p(out[2], u32p))
+    return out
+
+
+def project(data, view, proj, fx, fy, W, H, sh=None, band=None):
+    """(rec f32[n,8] (col 7 holds rgb8 bits), bbox i32[n,4], raw f32[n,12]).  sh: three u32 arrays + band[3]."""
     data = np.ascontiguousarray(data, dtype=np.uint32).reshape(-1)
     n = data.size // 8
     view = np.ascontiguousarray(view, dtype=np.float32)
@@ -92,8 +106,15 @@ def project(data, view, proj, fx, fy, W, H):
     rec = np.zeros((n, 8), dtype=np.float32)
     bbox = np.zeros((n, 4), dtype=np.int32)
     raw = np.zeros((n, 12), dtype=np.float32)
-    lib().orc_project(_p(data, u32p), n, _p(view, f32p), _p(proj, f32p), fx, fy, W, H,
-                      _p(rec, f32p), _p(bbox, i32p), _p(raw, f32p))
+    if sh is None:
+        lib().orc_project(_p(data, u32p), n, _p(view, f32p), _p(proj, f32p), fx, fy, W, H,
+                          _p(rec, f32p), _p(bbox, i32p), _p(raw, f32p))
+    else:
+        sh = [np.ascontiguousarray(a, dtype=np.uint32) for a in sh]
+        band = np.ascontiguousarray(band, dtype=np.int32)
+        lib().orc_project_sh(_p(data, u32p), n, _p(view, f32p), _p(proj, f32p), fx, fy, W, H,
+                             _p(sh[0], u32p), _p(sh[1], u32p), _p(sh[2], u32p), _p(band, i32p),
+                             _p(rec, f32p), _p(bbox, i32p), _p(raw, f32p))
     return rec, bbox, raw
 
 
@@ -132,10 +153,10 @@ def render(depth_index, raw, rec, bbox, W, H, mode=1, threads=None):
     return out
 
 
-def render_scene(data, pos, view, proj, viewproj, fx, fy, W, H, mode=1, threads=None):
+def render_scene(data, pos, view, proj, viewproj, fx, fy, W, H, mode=1, threads=None, sh=None, band=None):
     """Full oracle frame: (image, depth_index, V, D)."""
     di, _, _ = sort(viewproj, pos)
-    rec, bbox, raw = project(data, view, proj, fx, fy, W, H)
+    rec, bbox, raw = project(data, view, proj, fx, fy, W, H, sh, band)
     img = render(di, raw, rec, bbox, W, H, mode, threads)
     V, D = tile_stats(bbox)
     return img, di, V, D

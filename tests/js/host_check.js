@@ -40,6 +40,18 @@ if (mode === "pack") {                     // pack <splat> <outprefix> <W> <H> <
     writeBin(out + ".xf.data.bin", s2.data);
     fs.writeFileSync(out + ".json", JSON.stringify({ events, vertexCount: scene.vertexCount, width: scene.width, height: scene.height,
                                                      dataLength: scene.data.length, cams, xfCount: s2.vertexCount }));
+} else if (mode === "packsh") {             // packsh <splat> <shs.f32> <outprefix> <b0> <b1> <b2>
+    const [file, shfile, out, b0, b1, b2] = a;
+    const scene = new G.Scene();
+    scene.bandsIndices = new Int32Array([+b0, +b1, +b2]);
+    const raw = fs.readFileSync(shfile);
+    const shs = new Float32Array(raw.buffer.slice(raw.byteOffset, raw.byteOffset + raw.byteLength));
+    const rows = fs.readFileSync(file);
+    const bytes = new Uint8Array(rows.length);
+    bytes.set(rows);
+    scene.setData(bytes, shs);
+    for (let c = 0; c < 3; c++) writeBin(out + ".sh" + c + ".bin", scene.shs_rgb[c]);
+    fs.writeFileSync(out + ".json", JSON.stringify({ shHeight: scene.shHeight, vertexCount: scene.vertexCount }));
 } else if (mode === "render") {            // render <splat> <outprefix> <W> <H> <fx> <pose> [eps]
     const [file, out, W, H, fx, pose, eps] = a;
     const scene = new G.Scene();

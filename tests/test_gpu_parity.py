@@ -298,3 +298,37 @@ def test_giant_and_degenerate_splats(gh, oracle):
     assert r.stats()["visible"] == V and V >= 3
     assert np.abs(img.astype(np.float64) - oimg).max() <= TOL_EXACT
     r.dispose()
+
+
+def test_sh_colour_parity(gh, oracle, scenes):
+    # SH colour, degree 0..3 by bandsIndices; colours bit-exact, image within tolerance
+    n = 40000
+    rows, data, pos = scenes(n, 41)
+    rng = np.random.default_rng(8)
+    b0, b1, b2 = 9999, 19999, 29999          # splats 0..9999: no SH; then degree 1, 2, 3
+    shs = (rng.standard_normal((n - (b0 + 1), 48)) * 0.35).astype(np.float32)
+    scene = gh.Scene()
+    scene.bandsIndices = np.array([b0, b1, b2], dtype=np.int32)
+    scene.setData(rows, shs)
+    W, H = 640, 480
+    cam = gh.orbit_camera(33, width=W, height=H)
+    r = gh.HIPRenderer(W, H)
+    r.render(scene, cam)
+    img = r.readPixelsFloat()
+    col = r.read_sh_colors()
+    rec, bbox = r.read_records()
+    r.dispose()
+    v, p, vp = cam.f32()
+    sh = oracle.scene_pack_sh(shs)
+    orec, obbox, oraw = oracle.project(data, v, p, cam.fx, cam.fy, W, H, sh=sh, band=scene.bandsIndices)
+    _compare_records(rec, bbox, orec, obbox, oraw)
+    vis = (oraw[:, 11] == 1.0) & (np.arange(n) > b0)
+    assert vis.sum() > 1000
+    assert np.array_equal(col[vis, :3].view(np.uint32), oraw[vis, 7:10].view(np.uint32))
+    assert (rec[vis, 7].view(np.uint32) == 0x01000000).all()
+    di = oracle.sort(vp, pos)[0]
+    oimg = oracle.render(di, oraw, orec, obbox, W, H, 1)
+    assert np.abs(img.astype(np.float64) - oimg).max() <= TOL_EXACT
+    # and the colours really are view dependent and differ from the rgba8 fallback
+    plain = oracle.project(data, v, p, cam.fx, cam.fy, W, H)[2]
+    assert np.abs(plain[vis, 7:10] - oraw[vis, 7:10]).max() > 0.05

@@ -63,6 +63,24 @@ def test_scene_and_camera_bits(tmp_path, oracle):
     assert np.array_equal(xdata[:, [0, 1, 2, 7]], odata[:, [0, 1, 2, 7]])       # positions and colours survive exactly
 
 
+def test_js_scene_sh_packing(tmp_path, oracle):
+    import gsplat_hip as gh
+    n, first = 500, 120
+    rows = gh.synth.synth_rows(n, 9)
+    shs = (np.random.default_rng(4).standard_normal((n - first, 48)) * 0.4).astype(np.float32)
+    f, g = tmp_path / "s.splat", tmp_path / "s.shs"
+    rows.tofile(f)
+    shs.tofile(g)
+    out = str(tmp_path / "o")
+    run("packsh", f, g, out, first - 1, 250, 400)
+    want = oracle.scene_pack_sh(shs)
+    meta = json.load(open(out + ".json"))
+    assert meta["shHeight"] == -(-(2 * (n - first)) // 2048)
+    for c in range(3):
+        got = np.fromfile(out + ".sh%d.bin" % c, dtype=np.uint32)
+        assert np.array_equal(got[:want[c].size], want[c]) and not got[want[c].size:].any()
+
+
 def test_js_renderer_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():

@@ -87,3 +87,19 @@ def test_band_edges_cover_the_image():
             for (a, b), (c, d) in zip(e[:-1], e[1:]):
                 assert b == c and (a % 32 == 0 or a == W)
             assert all(b - a <= bands.slab_width(W, world) for a, b in e)
+
+
+def test_scene_sh_packing_matches_oracle(oracle):
+    import gsplat_hip as gh
+    n, first = 600, 150
+    rows = gh.synth.synth_rows(n, 5)
+    rng = np.random.default_rng(3)
+    shs = (rng.standard_normal((n - first, 48)) * 0.4).astype(np.float32)
+    sc = gh.Scene()
+    sc.bandsIndices = np.array([first - 1, 300, 450], dtype=np.int32)
+    sc.setData(rows, shs)
+    want = oracle.scene_pack_sh(shs)
+    assert sc.shHeight == math.ceil(2 * (n - first) / 2048)
+    for c in range(3):
+        assert sc.shs_rgb[c].size == 2048 * sc.shHeight * 4
+        assert np.array_equal(sc.shs_rgb[c][:want[c].size], want[c])
