@@ -500,6 +500,14 @@ int gsr_set_camera(gsr_ctx* c, const float* view, const float* proj, const float
     return GSR_OK;
 }
 
+int gsr_set_depth_fade(gsr_ctx* c, int32_t use_depth_fade, float depth_fade)
+{
+    if (!c) return GSR_ERR_ARG;
+    c->cam.use_fade = use_depth_fade ? 1 : 0;
+    c->cam.fade = depth_fade;
+    return GSR_OK;
+}
+
 int gsr_render_async(gsr_ctx* c)
 {
     if (!c) return GSR_ERR_ARG;

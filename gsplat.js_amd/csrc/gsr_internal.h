@@ -27,6 +27,8 @@ struct CamParams {
     int32_t W, H;
     int32_t sh_on;          // scene carries SH textures
     int32_t band[3];        // Scene.bandsIndices
+    int32_t use_fade;       // u_useDepthFade
+    float fade;             // u_depthFade
 };
 
 // 32-byte projected record consumed by the tile compositor (image coordinates, row 0 = top).

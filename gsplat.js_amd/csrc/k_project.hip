@@ -205,8 +205,19 @@ __global__ __launch_bounds__(256) void k_project_key(SceneSoA sc, uint32_t n, Ca
                 float smaj = sqrtf(2.0f * lambda1), smin = sqrtf(2.0f * lambda2);
                 smaj = (1024.0f < smaj) ? 1024.0f : smaj;
                 smin = (1024.0f < smin) ? 1024.0f : smin;
-                const float majx = smaj * dgx, majy = smaj * dgy;
-                const float minx = smin * dgy, miny = smin * -dgx;
+                float majx = smaj * dgx, majy = smaj * dgy;
+                float minx = smin * dgy, miny = smin * -dgx;
+                if (cam.use_fade) {  // :216-223, FadeInPass: axes scaled by the depth-dependent factor
+                    const float depthNorm = (pos2d[2] / pos2d[3] + 1.0f) / 2.0f;
+                    const float nearv = 0.1f, farv = 100.0f;
+                    const float normalizedDepth = (2.0f * nearv) / (farv + nearv - depthNorm * (farv - nearv));
+                    float st = normalizedDepth - 0.1f; st = (st > 0.0f) ? st : 0.0f;
+                    float en = normalizedDepth + 0.1f; en = (en < 1.0f) ? en : 1.0f;
+                    float sf = (cam.fade - st) / (en - st);
+                    sf = (sf < 0.0f) ? 0.0f : ((sf > 1.0f) ? 1.0f : sf);
+                    if (!(sf > 0.0f)) break;  // zero-area quad: nothing drawn
+                    majx = majx * sf; majy = majy * sf; minx = minx * sf; miny = miny * sf;
+                }
                 if (!finite4(majx, majy, minx, miny)) break;  // normalize(0,0) -> NaN: splat dropped
                 // :177-178: opacity; colour stays packed (:207 divides by 255 at composite time)
                 const float opacity = (float)((cw >> 24) & 0xffu) / 255.0f;

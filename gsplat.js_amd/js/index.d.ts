@@ -104,6 +104,7 @@ export class HIPRenderer {
     setBand(x0: number, x1: number): void;
     setCameraBuffers(): void;
     setShTextures(): void;
+    setDepthFade(useDepthFade: boolean, depthFade: number): void;
     dispose(): void;
     /** RGBA8, row 0 = top, round(clamp(x,0,1)*255), premultiplied alpha */
     readPixels(): Uint8Array;

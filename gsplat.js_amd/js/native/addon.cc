@@ -169,6 +169,18 @@ napi_value SetSceneSh(napi_env env, napi_callback_info info)
     return rc ? throw_gsr(env, c, rc, "gsr_set_scene_sh") : undefined(env);
 }
 
+napi_value SetDepthFade(napi_env env, napi_callback_info info)
+{
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return nullptr;
+    gsr_ctx* c = get_ctx(env, argv[0]);
+    int32_t use;
+    double v;
+    if (!c || !get_i32(env, argv[1], &use) || !get_f64(env, argv[2], &v)) return nullptr;
+    const int rc = gsr_set_depth_fade(c, use, (float)v);
+    return rc ? throw_gsr(env, c, rc, "gsr_set_depth_fade") : undefined(env);
+}
+
 napi_value Resize(napi_env env, napi_callback_info info)
 {
     napi_value argv[3];
@@ -330,7 +342,7 @@ napi_value SortHost(napi_env env, napi_callback_info info)
 napi_value Init(napi_env env, napi_value exports)
 {
     struct { const char* name; napi_callback fn; } fns[] = {
-        {"create", Create}, {"destroy", Destroy}, {"setScene", SetScene}, {"setSceneSh", SetSceneSh}, {"resize", Resize}, {"setBand", SetBand},
+        {"create", Create}, {"destroy", Destroy}, {"setScene", SetScene}, {"setSceneSh", SetSceneSh}, {"setDepthFade", SetDepthFade}, {"resize", Resize}, {"setBand", SetBand},
         {"setCamera", SetCamera}, {"sort", Call0<gsr_sort>}, {"render", Call0<gsr_render>},
         {"renderAsync", Call0<gsr_render_async>}, {"sync", Call0<gsr_sync>}, {"resetTimings", Call0<gsr_reset_timings>},
         {"readDepthIndex", ReadDepthIndex}, {"readPixels", ReadPixels}, {"getTimings", GetTimings},

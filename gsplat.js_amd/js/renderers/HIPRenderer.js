@@ -64,6 +64,8 @@ class HIPRenderer {
             this._n.setCamera(this._h, f32.view, f32.proj, f32.vp, activeCamera.fx, activeCamera.fy);
         };
         this.setCameraBuffers = () => pushCamera();
+        // the two uniforms a FadeInPass drives (u_useDepthFade, u_depthFade)
+        this.setDepthFade = (use, value) => this._n.setDepthFade(this._h, use ? 1 : 0, value);
         // SH textures + u_bandIndex, only for scenes that carry SH data (WebGLRenderer.ts:202-211,321-366)
         this.setShTextures = () => {
             if (!activeScene || !activeScene.shHeight) return;

@@ -46,7 +46,7 @@ _lib = None
 
 # every symbol include/gsplat_hip.h declares
 EXPORTS = [
-    "gsr_create", "gsr_destroy", "gsr_last_error", "gsr_set_scene", "gsr_set_scene_sh", "gsr_read_sh_colors", "gsr_resize", "gsr_set_band", "gsr_set_camera",
+    "gsr_create", "gsr_destroy", "gsr_last_error", "gsr_set_scene", "gsr_set_scene_sh", "gsr_read_sh_colors", "gsr_set_depth_fade", "gsr_resize", "gsr_set_band", "gsr_set_camera",
     "gsr_sort", "gsr_render", "gsr_render_async", "gsr_sync", "gsr_read_depth_index", "gsr_read_pixels_rgba32f",
     "gsr_read_pixels_rgba8", "gsr_get_timings", "gsr_reset_timings", "gsr_read_keys", "gsr_read_records",
     "gsr_framebuffer_device_ptr", "gsr_stream_handle", "gsr_device_info", "gsplat_sort_host",
@@ -70,6 +70,7 @@ def load_library(path=None):
     L.gsr_set_scene.argtypes = [vp, vp, vp, ctypes.c_uint32]
     L.gsr_set_scene_sh.argtypes = [vp, vp, vp, vp, ctypes.c_uint32, vp]
     L.gsr_read_sh_colors.argtypes = [vp, vp]
+    L.gsr_set_depth_fade.argtypes = [vp, ctypes.c_int32, ctypes.c_float]
     L.gsr_resize.argtypes = [vp, ctypes.c_int32, ctypes.c_int32]
     L.gsr_set_band.argtypes = [vp, ctypes.c_int32, ctypes.c_int32]
     L.gsr_set_camera.argtypes = [vp, vp, vp, vp, ctypes.c_float, ctypes.c_float]
@@ -261,6 +262,10 @@ class HIPRenderer:
         out = np.empty((self._n, 4), dtype=np.float32)
         self._check(self._L.gsr_read_sh_colors(self._ctx, out.ctypes.data))
         return out
+
+    def set_depth_fade(self, use, value):
+        """u_useDepthFade / u_depthFade of FadeInPass."""
+        self._check(self._L.gsr_set_depth_fade(self._ctx, 1 if use else 0, float(value)))
 
     def set_camera(self, camera):
         camera.update(self.width, self.height)

@@ -101,6 +101,10 @@ int gsr_set_band(gsr_ctx *ctx, int32_t x0, int32_t x1);
  * of Camera.viewMatrix / projectionMatrix / viewProj (src/cameras/Camera.ts:81-92). */
 int gsr_set_camera(gsr_ctx *ctx, const float *view, const float *proj, const float *view_proj, float fx, float fy);
 
+/* FadeInPass uniforms u_useDepthFade / u_depthFade (src/renderers/webgl/passes/FadeInPass.ts:8-37, consumed at
+ * vertex.glsl.ts:214-229): while enabled every splat's axes are scaled by the depth-dependent factor. Off by default. */
+int gsr_set_depth_fade(gsr_ctx *ctx, int32_t use_depth_fade, float depth_fade);
+
 int gsr_sort(gsr_ctx *ctx);         /* depth key + sort only (blocking)                    */
 int gsr_render(gsr_ctx *ctx);       /* sort + project + bin + composite (blocking)         */
 int gsr_render_async(gsr_ctx *ctx); /* enqueue one frame on the context's stream           */

@@ -304,11 +304,14 @@ static void orc_eval_sh(const uint32_t *const sh[3], uint32_t t, uint32_t deg, c
 
 /* sh_r/g/b (nullable together): the three SH textures; band[3] = Scene.bandsIndices (index of the last splat with
  * 0 / <=1 / <=2 SH bands).  With SH, splat i > band[0] takes its colour from eval_sh_rgb (vertex.glsl.ts:180-204) and its
- * record's rgb8 word is 0x01000000 ("colour is in raw[7..9]"). */
-void orc_project_sh(const uint32_t *data, uint32_t n, const float *view, const float *proj,
-                    float fx, float fy, int W, int H,
-                    const uint32_t *sh_r, const uint32_t *sh_g, const uint32_t *sh_b, const int32_t *band,
-                    float *rec_out /*8n, nullable*/, int32_t *bbox_out /*4n, nullable*/, float *raw_out /*12n, nullable*/)
+ * record's rgb8 word is 0x01000000 ("colour is in raw[7..9]").
+ * use_fade / fade: u_useDepthFade / u_depthFade (FadeInPass.ts:8-37): the quad's axes are scaled by
+ * scalingFactor (vertex.glsl.ts:214-229); raw[2..5] hold the scaled axes; factor 0 = nothing drawn. */
+void orc_project_full(const uint32_t *data, uint32_t n, const float *view, const float *proj,
+                      float fx, float fy, int W, int H,
+                      const uint32_t *sh_r, const uint32_t *sh_g, const uint32_t *sh_b, const int32_t *band,
+                      int use_fade, float fade,
+                      float *rec_out /*8n, nullable*/, int32_t *bbox_out /*4n, nullable*/, float *raw_out /*12n, nullable*/)
 {
     const uint32_t *const sh[3] = { sh_r, sh_g, sh_b };
     /* inverse(view)[3].xyz (vertex.glsl.ts:197) for a rigid view matrix [A | b]: -A^T b */
@@ -394,6 +397,17 @@ void orc_project_sh(const uint32_t *data, uint32_t n, const float *view, const f
             smin = (1024.0f < smin) ? 1024.0f : smin;
             float majx = smaj * dgx, majy = smaj * dgy;
             float minx = smin * dgy, miny = smin * -dgx;
+            if (use_fade) {   /* :216-223 */
+                float depthNorm = (pos2d[2] / pos2d[3] + 1.0f) / 2.0f;
+                float nearv = 0.1f, farv = 100.0f;
+                float normalizedDepth = (2.0f * nearv) / (farv + nearv - depthNorm * (farv - nearv));
+                float st = normalizedDepth - 0.1f; st = (st > 0.0f) ? st : 0.0f;
+                float en = normalizedDepth + 0.1f; en = (en < 1.0f) ? en : 1.0f;
+                float sf = (fade - st) / (en - st);
+                sf = (sf < 0.0f) ? 0.0f : ((sf > 1.0f) ? 1.0f : sf);   /* clamp(x, 0, 1) = min(max(x, 0), 1) */
+                if (!(sf > 0.0f)) break;   /* zero-area quad: no fragments (NaN factor: position undefined, dropped) */
+                majx = majx * sf; majy = majy * sf; minx = minx * sf; miny = miny * sf;   /* :226-229 */
+            }
             if (!(isfinite(majx) && isfinite(majy) && isfinite(minx) && isfinite(miny))) break; /* normalize(0,0): dropped */
             /* :177-178, :207 */
             uint32_t cw = d[7];
@@ -446,10 +460,17 @@ void orc_project_sh(const uint32_t *data, uint32_t n, const float *view, const f
     }
 }
 
+void orc_project_sh(const uint32_t *data, uint32_t n, const float *view, const float *proj, float fx, float fy, int W, int H,
+                    const uint32_t *sh_r, const uint32_t *sh_g, const uint32_t *sh_b, const int32_t *band,
+                    float *rec_out, int32_t *bbox_out, float *raw_out)
+{
+    orc_project_full(data, n, view, proj, fx, fy, W, H, sh_r, sh_g, sh_b, band, 0, 1.0f, rec_out, bbox_out, raw_out);
+}
+
 void orc_project(const uint32_t *data, uint32_t n, const float *view, const float *proj,
                  float fx, float fy, int W, int H, float *rec_out, int32_t *bbox_out, float *raw_out)
 {
-    orc_project_sh(data, n, view, proj, fx, fy, W, H, NULL, NULL, NULL, NULL, rec_out, bbox_out, raw_out);
+    orc_project_full(data, n, view, proj, fx, fy, W, H, NULL, NULL, NULL, NULL, 0, 1.0f, rec_out, bbox_out, raw_out);
 }
 
 /* Counts used by the bench's byte model: V = splats with a

@@ -45,6 +45,10 @@ def lib():
         L.orc_project_sh.argtypes = [u32p, ctypes.c_uint32, f32p, f32p, ctypes.c_float, ctypes.c_float,
                                      ctypes.c_int, ctypes.c_int, u32p, u32p, u32p, i32p, f32p, i32p, f32p]
         L.orc_project_sh.restype = None
+        L.orc_project_full.argtypes = [u32p, ctypes.c_uint32, f32p, f32p, ctypes.c_float, ctypes.c_float,
+                                       ctypes.c_int, ctypes.c_int, u32p, u32p, u32p, i32p, ctypes.c_int, ctypes.c_float,
+                                       f32p, i32p, f32p]
+        L.orc_project_full.restype = None
         L.orc_scene_pack_sh.argtypes = [f32p, ctypes.c_uint32, u32p, u32p, u32p]
         L.orc_scene_pack_sh.restype = None
         L.orc_tile_stats.argtypes = [i32p, ctypes.c_uint32, ctypes.c_int,
@@ -97,7 +101,7 @@ def scene_pack_sh(shs):
     return out
 
 
-def project(data, view, proj, fx, fy, W, H, sh=None, band=None):
+def project(data, view, proj, fx, fy, W, H, sh=None, band=None, fade=None):
     """(rec f32[n,8] (col 7 holds rgb8 bits), bbox i32[n,4], raw f32[n,12]).  sh: three u32 arrays + band[3]."""
     data = np.ascontiguousarray(data, dtype=np.uint32).reshape(-1)
     n = data.size // 8
@@ -106,7 +110,19 @@ def project(data, view, proj, fx, fy, W, H, sh=None, band=None):
     rec = np.zeros((n, 8), dtype=np.float32)
     bbox = np.zeros((n, 4), dtype=np.int32)
     raw = np.zeros((n, 12), dtype=np.float32)
-    if sh is None:
+    if fade is not None:   # depth fade (FadeInPass): fade = u_depthFade
+        null = ctypes.cast(None, u32p)
+        shp = [null, null, null] if sh is None else [_p(np.ascontiguousarray(a, dtype=np.uint32), u32p) for a in sh]
+        keep = None if sh is None else [np.ascontiguousarray(a, dtype=np.uint32) for a in sh]
+        if keep is not None:
+            shp = [_p(a, u32p) for a in keep]
+        bandp = ctypes.cast(None, i32p) if band is None else _p(np.ascontiguousarray(band, dtype=np.int32), i32p)
+        bkeep = None if band is None else np.ascontiguousarray(band, dtype=np.int32)
+        if bkeep is not None:
+            bandp = _p(bkeep, i32p)
+        lib().orc_project_full(_p(data, u32p), n, _p(view, f32p), _p(proj, f32p), fx, fy, W, H, shp[0], shp[1], shp[2], bandp,
+                               1, float(fade), _p(rec, f32p), _p(bbox, i32p), _p(raw, f32p))
+    elif sh is None:
         lib().orc_project(_p(data, u32p), n, _p(view, f32p), _p(proj, f32p), fx, fy, W, H,
                           _p(rec, f32p), _p(bbox, i32p), _p(raw, f32p))
     else:
@@ -153,10 +169,10 @@ def render(depth_index, raw, rec, bbox, W, H, mode=1, threads=None):
     return out
 
 
-def render_scene(data, pos, view, proj, viewproj, fx, fy, W, H, mode=1, threads=None, sh=None, band=None):
+def render_scene(data, pos, view, proj, viewproj, fx, fy, W, H, mode=1, threads=None, sh=None, band=None, fade=None):
     """Full oracle frame: (image, depth_index, V, D)."""
     di, _, _ = sort(viewproj, pos)
-    rec, bbox, raw = project(data, view, proj, fx, fy, W, H, sh, band)
+    rec, bbox, raw = project(data, view, proj, fx, fy, W, H, sh, band, fade)
     img = render(di, raw, rec, bbox, W, H, mode, threads)
     V, D = tile_stats(bbox)
     return img, di, V, D

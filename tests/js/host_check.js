@@ -56,7 +56,7 @@ if (mode === "pack") {                     // pack <splat> <outprefix> <W> <H> <
     const [file, out, W, H, fx, pose, eps] = a;
     const scene = new G.Scene();
     G.Loader.LoadSync(file, scene);
-    const r = new G.WebGLRenderer({ width: +W, height: +H, earlyOutEps: eps ? +eps : 0, timing: true });
+    const r = new G.WebGLRenderer({ width: +W, height: +H, earlyOutEps: eps ? +eps : 0, timing: true }, []);   // no passes: steady state
     const cam = orbitCamera(+pose, 120, +fx);
     r.render(scene, cam);
     writeBin(out + ".depthIndex.bin", r.lastDepthIndex());
@@ -72,6 +72,15 @@ if (mode === "pack") {                     // pack <splat> <outprefix> <W> <H> <
     G.sortHost(new Float32Array(cam.viewProj.buffer), scene.vertexCount, scene.positions, keys, di);
     writeBin(out + ".sortHost.depthIndex.bin", di);
     fs.writeFileSync(out + ".json", JSON.stringify({ stats: r.stats(), device: r.deviceInfo(), viewProj: cam.viewProj.buffer }));
+    r.dispose();
+} else if (mode === "renderfade") {       // renderfade <splat> <outprefix> <W> <H> <fx> <pose> <frames>: default passes = [FadeInPass]
+    const [file, out, W, H, fx, pose, frames] = a;
+    const scene = new G.Scene();
+    G.Loader.LoadSync(file, scene);
+    const r = new G.WebGLRenderer({ width: +W, height: +H });
+    const cam = orbitCamera(+pose, 120, +fx);
+    for (let k = 0; k < +frames; k++) r.render(scene, cam);
+    writeBin(out + ".rgba32f.bin", r.readPixelsFloat());
     r.dispose();
 } else if (mode === "nodevice") {
     try {

@@ -332,3 +332,31 @@ def test_sh_colour_parity(gh, oracle, scenes):
     # and the colours really are view dependent and differ from the rgba8 fallback
     plain = oracle.project(data, v, p, cam.fx, cam.fy, W, H)[2]
     assert np.abs(plain[vis, 7:10] - oraw[vis, 7:10]).max() > 0.05
+
+
+@pytest.mark.parametrize("fade", [0.02, 0.11, 0.35, 1.0])
+def test_depth_fade_parity(gh, oracle, scenes, fade):
+    # FadeInPass uniforms (vertex.glsl.ts:214-229): records bit-exact, image within tolerance, at several fade values
+    cfg = gh.synth.CONFIGS["C1"]
+    rows, data, pos = scenes("C1")
+    cam = _camera(gh, 19, cfg)
+    r = gh.HIPRenderer(cfg["width"], cfg["height"])
+    r.set_raw_scene(data, pos)
+    r.set_depth_fade(True, fade)
+    r.set_camera(cam)
+    r.render_async(); r.sync()
+    rec, bbox = r.read_records()
+    img = r.readPixelsFloat()
+    v, p, vp = cam.f32()
+    orec, obbox, oraw = oracle.project(data, v, p, cfg["fx"], cfg["fx"], cfg["width"], cfg["height"], fade=fade)
+    _compare_records(rec, bbox, orec, obbox, oraw)
+    oimg = oracle.render(oracle.sort(vp, pos)[0], oraw, orec, obbox, cfg["width"], cfg["height"], 1)
+    assert np.abs(img.astype(np.float64) - oimg).max() <= TOL_EXACT
+    # switching the pass off restores the steady state
+    r.set_depth_fade(False, fade)
+    r.render_async(); r.sync()
+    plain = oracle.render_scene(data, pos, v, p, vp, cam.fx, cam.fy, cfg["width"], cfg["height"], mode=1)[0]
+    assert np.abs(r.readPixelsFloat().astype(np.float64) - plain).max() <= TOL_EXACT
+    if fade < 0.2:
+        assert np.abs(oimg - plain).max() > 0.05
+    r.dispose()

@@ -123,3 +123,25 @@ def test_js_render_matches_oracle(tmp_path, oracle):
     # the wasm export's drop-in (7-argument sort on host arrays), called after the move
     assert np.array_equal(np.fromfile(out + ".sortHost.depthIndex.bin", dtype=np.uint32), mdi)
     assert meta["stats"]["n"] == cfg["n"] and meta["device"]["computeUnits"] > 0
+
+
+@pytest.mark.gpu
+def test_js_default_fade_in_pass(tmp_path, oracle):
+    # new WebGLRenderer() installs a FadeInPass (WebGLRenderer.ts:41-44): frame k is drawn with u_depthFade = 0.01 k
+    import gsplat_hip as gh
+    cfg = gh.synth.CONFIGS["C1"]
+    rows = gh.synth.config_rows("C1")
+    f = tmp_path / "c1.splat"
+    rows.tofile(f)
+    out = str(tmp_path / "f")
+    run("renderfade", f, out, cfg["width"], cfg["height"], cfg["fx"], 9, 30)
+    data, pos = oracle.scene_pack(rows)
+    cam = gh.orbit_camera(9, width=cfg["width"], height=cfg["height"], fx=cfg["fx"])
+    v, p, vp = cam.f32()
+    fade = 0.0
+    for _ in range(30):
+        fade = min(fade + 0.01, 1.0)
+    oimg = oracle.render_scene(data, pos, v, p, vp, cam.fx, cam.fy, cfg["width"], cfg["height"], mode=1, fade=fade)[0]
+    img = np.fromfile(out + ".rgba32f.bin", dtype=np.float32).reshape(cfg["height"], cfg["width"], 4)
+    assert oimg[..., 3].max() > 0.05
+    assert np.abs(img.astype(np.float64) - oimg).max() <= 2e-3   # pose trigonometry differs by an ulp between V8 and libm
