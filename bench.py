@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--early-out-eps", type=float, default=0.0,
                     help="0 = composite every splat like the reference (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", choices=("rgba8", "f32"), default="rgba8",
+                    help="N>1: framebuffer slab format of the per-frame all-gather (rgba8: what a display consumes)")
+    ap.add_argument("--equal-bands", action="store_true", help="N>1: equal-width bands instead of cost-balanced ones")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -102,18 +105,37 @@ def main():
     scene = gh.Scene()
     scene.setData(rows)
 
-    # tile-column bands: whole 32-px bins per rank, last band may be narrower
+    # tile-column bands: whole 32-px bins per rank.  Equal-width bands are badly unbalanced for centre-heavy scenes
+    # (a frame is as slow as its slowest band), so the edges come from a calibration frame's per-column list entries.
     from gsplat_hip import bands
-    x0, x1 = bands.band_edges(W, world)[rank]
+    edges = bands.band_edges(W, world)
+    if world > 1 and not args.equal_bands:
+        cal = gh.HIPRenderer(W, H, device=local_rank)
+        cost = np.zeros(-(-W // 32))
+        for k in (0, 30, 60, 90):
+            cal.render(scene, gh.orbit_camera(k, ORBIT_FRAMES, W, H, cfg["fx"]))
+            cost += cal.bin_totals().sum(axis=0) + 0.25 * 32 * H    # list entries + a per-pixel output term
+        cal.dispose()
+        got = [bands.balanced_edges(W, world, cost)]
+        dist.broadcast_object_list(got, src=0)    # every rank uses rank 0's edges
+        edges = got[0]
+    x0, x1 = edges[rank]
+    if world > 1 and x1 <= x0:
+        raise SystemExit("rank %d has an empty band (more ranks than 32-px bin columns)" % rank)
     band = (x0, x1) if world > 1 else None
-    r = gh.HIPRenderer(W, H, device=local_rank, early_out_eps=args.early_out_eps, band=band if (band and x1 > x0) else None,
-                       timing=True)
+    r = gh.HIPRenderer(W, H, device=local_rank, early_out_eps=args.early_out_eps, band=band, timing=True)
     r.render(scene, gh.orbit_camera(0, ORBIT_FRAMES, W, H, cfg["fx"]))  # uploads the scene, first frame
 
-    fb = xchg = None
+    fb = xchg = link = None
     if world > 1:
-        fb = bands.framebuffer_tensor(torch, r, "cuda:%d" % local_rank)
-        xchg = bands.FrameExchange(dist, torch, W, H, rank, world, fb.device)
+        dev = "cuda:%d" % local_rank
+        if args.exchange == "rgba8":
+            fb = bands.framebuffer8_tensor(torch, r, dev)
+            xchg = bands.FrameExchange(dist, torch, W, H, rank, world, fb.device, edges=edges, dtype=torch.uint8)
+        else:
+            fb = bands.framebuffer_tensor(torch, r, dev)
+            xchg = bands.FrameExchange(dist, torch, W, H, rank, world, fb.device, edges=edges)
+        link = bands.StreamLink(torch, r, dev)
 
     # Camera.update for the 120 poses is host JS/Python f64 work outside the device path: precomputed
     poses = [gh.orbit_camera(k, ORBIT_FRAMES, W, H, cfg["fx"]).f32() for k in range(ORBIT_FRAMES)]
@@ -123,8 +145,12 @@ def main():
         r.set_camera_arrays(v, p, vp, cfg["fx"], cfg["fx"])
         r.render_async()
         if world > 1:
-            r.sync()  # the library's stream -> host; torch's stream takes over for the exchange
+            # device-side ordering only: torch's stream waits for the frame, the next frame waits for the slab copy
+            if args.exchange == "rgba8":
+                r.convert_rgba8_async()
+            link.torch_waits_for_renderer()
             xchg.exchange(fb)
+            link.renderer_waits_for_torch()
 
     def fence():
         r.sync()
@@ -153,6 +179,7 @@ def main():
     sf = max(int(st["sum_frames"]), 1)
     V, D, E = st["sum_visible"] / sf, st["sum_tile_entries"] / sf, st["sum_bin_entries"] / sf
     band_px = ((x1 - x0) if world > 1 else W) * H
+    band_edges_used = edges if world > 1 else None
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -178,7 +205,7 @@ def main():
             "config": {"workload": "%s: %d synthetic gaussians (seed %d), %dx%d, 120-pose orbit, full render(scene,camera) "
                                    "= depth key + 17-bit sort + projection + binning + composite"
                                    % (args.config, N, cfg["seed"], W, H),
-                       "early_out_eps": args.early_out_eps, "parallelism": "tile-column bands x%d" % world,
+                       "early_out_eps": args.early_out_eps, "parallelism": "tile-column bands x%d%s" % (world, "" if world == 1 else (", %s all-gather, %s edges" % (args.exchange, "equal" if args.equal_bands else "cost-balanced"))),
                        "output": "RGBA f32 premultiplied, left in HBM"},
             "sorted_splats_per_sec": N / ((ms["project_key"] + ms["sort"]) * 1e-3),
             "stage_ms": ms,
@@ -196,6 +223,7 @@ def main():
                 "frame": {"bytes": b_sort + b_proj + b_bin + b_blend, "ms": ms_step,
                           "frac": (b_sort + b_proj + b_bin + b_blend) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             },
+            "band_edges": band_edges_used,
             "device": r.device_info(),
         }
         if world == 1 and not args.no_cpu_baseline:

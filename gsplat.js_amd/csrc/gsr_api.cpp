@@ -640,6 +640,31 @@ int gsr_read_sh_colors(gsr_ctx* c, float* rgba)
     return GSR_OK;
 }
 
+int gsr_read_bin_totals(gsr_ctx* c, uint32_t* out, int32_t* nbx, int32_t* nby)
+{
+    if (!c || !out) return c ? fail(c, GSR_ERR_ARG, "out is NULL") : GSR_ERR_ARG;
+    if (!c->have_frame) return fail(c, GSR_ERR_ARG, "no frame has been rendered yet");
+    const BinGrid g = make_grid(c);
+    const int w = g.bx_hi - g.bx_lo;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(out, c->bin_total, (size_t)w * g.nby * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (nbx) *nbx = w;
+    if (nby) *nby = g.nby;
+    return GSR_OK;
+}
+
+int gsr_convert_rgba8_async(gsr_ctx* c)
+{
+    if (!c) return GSR_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    launch_to_rgba8(c->fb, c->fb8, (uint32_t)c->W * (uint32_t)c->H, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return GSR_OK;
+}
+
+void* gsr_framebuffer8_device_ptr(gsr_ctx* c) { return c ? (void*)c->fb8 : nullptr; }
+
 void* gsr_framebuffer_device_ptr(gsr_ctx* c) { return c ? (void*)c->fb : nullptr; }
 void* gsr_stream_handle(gsr_ctx* c) { return c ? (void*)c->stream : nullptr; }
 

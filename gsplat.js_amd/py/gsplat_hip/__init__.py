@@ -49,6 +49,7 @@ EXPORTS = [
     "gsr_create", "gsr_destroy", "gsr_last_error", "gsr_set_scene", "gsr_set_scene_sh", "gsr_read_sh_colors", "gsr_set_depth_fade", "gsr_resize", "gsr_set_band", "gsr_set_camera",
     "gsr_sort", "gsr_render", "gsr_render_async", "gsr_sync", "gsr_read_depth_index", "gsr_read_pixels_rgba32f",
     "gsr_read_pixels_rgba8", "gsr_get_timings", "gsr_reset_timings", "gsr_read_keys", "gsr_read_records",
+    "gsr_read_bin_totals", "gsr_convert_rgba8_async", "gsr_framebuffer8_device_ptr",
     "gsr_framebuffer_device_ptr", "gsr_stream_handle", "gsr_device_info", "gsplat_sort_host",
 ]
 
@@ -82,6 +83,10 @@ def load_library(path=None):
     L.gsr_get_timings.argtypes = [vp, ctypes.POINTER(GsrTimings)]
     L.gsr_read_keys.argtypes = [vp, vp, vp]
     L.gsr_read_records.argtypes = [vp, vp, vp]
+    L.gsr_read_bin_totals.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+    L.gsr_convert_rgba8_async.argtypes = [vp]
+    L.gsr_framebuffer8_device_ptr.argtypes = [vp]
+    L.gsr_framebuffer8_device_ptr.restype = vp
     L.gsr_framebuffer_device_ptr.argtypes = [vp]
     L.gsr_framebuffer_device_ptr.restype = vp
     L.gsr_stream_handle.argtypes = [vp]
@@ -350,6 +355,20 @@ class HIPRenderer:
         cus, clk = ctypes.c_int32(0), ctypes.c_int32(0)
         self._check(self._L.gsr_device_info(self._ctx, name, 256, ctypes.byref(cus), ctypes.byref(clk)))
         return {"name": name.value.decode(), "compute_units": cus.value, "clock_khz": clk.value}
+
+    def bin_totals(self):
+        """Entries per 32x32 bin of the last frame, shape [nby, nbx] (this context's band)."""
+        nbx_all, nby_all = -(-self.width // 32), -(-self.height // 32)
+        out = np.zeros(nbx_all * nby_all, dtype=np.uint32)
+        nbx, nby = ctypes.c_int32(0), ctypes.c_int32(0)
+        self._check(self._L.gsr_read_bin_totals(self._ctx, out.ctypes.data, ctypes.byref(nbx), ctypes.byref(nby)))
+        return out[:nbx.value * nby.value].reshape(nby.value, nbx.value)
+
+    def convert_rgba8_async(self):
+        self._check(self._L.gsr_convert_rgba8_async(self._ctx))
+
+    def framebuffer8_ptr(self):
+        return self._L.gsr_framebuffer8_device_ptr(self._ctx)
 
     def framebuffer_ptr(self):
         return self._L.gsr_framebuffer_device_ptr(self._ctx)

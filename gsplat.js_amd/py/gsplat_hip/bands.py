@@ -5,6 +5,11 @@ The device side only needs gsr_set_band; this module is the host-side
 arithmetic and the slab exchange, written against torch.distributed so the same
 code runs over RCCL ("nccl" backend on ROCm) on GPUs and over gloo on CPU
 tensors in the tests.
+
+xGMI is point-to-point (7 links per GPU), so the exchange is sized for it: by
+default the slabs are RGBA8 (8.3 MB per 1080p frame in total, the format a
+display consumes) rather than RGBA f32 (33 MB), and there is exactly one
+collective per frame.
 """
 BIN_PX = 32  # must match gsr::BIN_PX (band edges are whole compositor bins)
 
@@ -17,7 +22,33 @@ def band_edges(width, world):
     return [(min(q * per * BIN_PX, width), min((q + 1) * per * BIN_PX, width)) for q in range(world)]
 
 
-def slab_width(width, world):
+def balanced_edges(width, world, column_cost):
+    """Band edges (whole bins, every rank at least one bin column) that equalise the summed cost.
+
+    column_cost[k]: work estimate of bin column k (e.g. list entries of a calibration frame plus a constant for the
+    per-pixel output).  Centre-heavy scenes make equal-width bands badly unbalanced; a frame is as slow as its
+    slowest band."""
+    nbx = -(-width // BIN_PX)
+    cost = [float(c) for c in column_cost]
+    assert len(cost) == nbx
+    if world >= nbx:
+        cuts = list(range(nbx + 1)) + [nbx] * (world - nbx)
+    else:
+        prefix = [0.0]
+        for c in cost:
+            prefix.append(prefix[-1] + c)
+        cuts = [0]
+        for q in range(1, world):
+            target = prefix[-1] * q / world
+            lo, hi = cuts[-1] + 1, nbx - (world - q)   # leave at least one column for every later rank
+            cuts.append(min(range(lo, hi + 1), key=lambda k: abs(prefix[k] - target)))
+        cuts.append(nbx)
+    return [(min(a * BIN_PX, width), min(b * BIN_PX, width)) for a, b in zip(cuts[:-1], cuts[1:])]
+
+
+def slab_width(width, world, edges=None):
+    if edges is not None:
+        return max(BIN_PX, max(b - a for a, b in edges))
     nbx = -(-width // BIN_PX)
     return -(-nbx // world) * BIN_PX
 
@@ -35,18 +66,38 @@ def framebuffer_tensor(torch, renderer, device):
     return torch.as_tensor(DevicePointer(renderer.framebuffer_ptr(), (renderer.height, renderer.width, 4)), device=device)
 
 
+def framebuffer8_tensor(torch, renderer, device):
+    """The renderer's RGBA8 device image (filled by convert_rgba8_async) as a torch tensor [H, W, 4] uint8."""
+    return torch.as_tensor(DevicePointer(renderer.framebuffer8_ptr(), (renderer.height, renderer.width, 4), "|u1"), device=device)
+
+
+class StreamLink:
+    """Orders the library's HIP stream and torch's current stream on the device, without host round trips."""
+
+    def __init__(self, torch, renderer, device):
+        self.torch = torch
+        self.ext = torch.cuda.ExternalStream(renderer.stream_handle(), device=device)
+
+    def torch_waits_for_renderer(self):
+        self.torch.cuda.current_stream().wait_stream(self.ext)
+
+    def renderer_waits_for_torch(self):
+        self.ext.wait_stream(self.torch.cuda.current_stream())
+
+
 class FrameExchange:
     """all-gather of per-rank band slabs into every rank's full frame."""
 
-    def __init__(self, dist, torch, width, height, rank, world, device, channels=4):
+    def __init__(self, dist, torch, width, height, rank, world, device, channels=4, edges=None, dtype=None):
         self.dist, self.rank, self.world = dist, rank, world
-        self.edges = band_edges(width, world)
-        sw = slab_width(width, world)
-        self.slab = torch.zeros((height, sw, channels), dtype=torch.float32, device=device)
+        self.edges = list(edges) if edges is not None else band_edges(width, world)
+        dtype = dtype or torch.float32
+        sw = slab_width(width, world, self.edges)
+        self.slab = torch.zeros((height, sw, channels), dtype=dtype, device=device)
         # concatenated along dim 0 (the layout both NCCL/RCCL and gloo accept for all_gather_into_tensor)
-        self._flat = torch.empty((world * height, sw, channels), dtype=torch.float32, device=device)
+        self._flat = torch.empty((world * height, sw, channels), dtype=dtype, device=device)
         self.gathered = self._flat.view(world, height, sw, channels)
-        self.full = torch.empty((height, width, channels), dtype=torch.float32, device=device)
+        self.full = torch.empty((height, width, channels), dtype=dtype, device=device)
 
     def exchange(self, fb):
         """fb: [H, W, C] tensor whose columns edges[rank] hold this rank's band. Returns the full frame."""

@@ -122,6 +122,13 @@ int gsr_read_keys(gsr_ctx *ctx, uint32_t *keys /* n, 17-bit */, int32_t *minmax 
 int gsr_read_records(gsr_ctx *ctx, float *rec /* 8n */, int32_t *bbox /* 4n: x0,y0,x1,y1 */);
 int gsr_read_sh_colors(gsr_ctx *ctx, float *rgba /* 4n: evaluated SH colour of every splat that has one */);
 
+/* ---- multi-GPU helpers ---- */
+/* Entries per 32x32 bin of the last rendered frame, row-major over the context's band (cost model for balanced bands). */
+int gsr_read_bin_totals(gsr_ctx *ctx, uint32_t *out /* nbx*nby */, int32_t *nbx, int32_t *nby);
+/* Enqueue the f32 -> RGBA8 conversion of the framebuffer on the context's stream (result: gsr_framebuffer8_device_ptr). */
+int gsr_convert_rgba8_async(gsr_ctx *ctx);
+void *gsr_framebuffer8_device_ptr(gsr_ctx *ctx); /* uint8[h][w][4] on the device */
+
 /* ---- device interop (torch / RCCL plumbing in the harness) ---- */
 void *gsr_framebuffer_device_ptr(gsr_ctx *ctx); /* float4[h][w] on the device */
 void *gsr_stream_handle(gsr_ctx *ctx);          /* hipStream_t */

@@ -360,3 +360,32 @@ def test_depth_fade_parity(gh, oracle, scenes, fade):
     if fade < 0.2:
         assert np.abs(oimg - plain).max() > 0.05
     r.dispose()
+
+
+def test_stream_linked_rgba8_readout(gh, scenes):
+    # bench.py's N>1 step: render_async -> convert_rgba8_async -> torch's stream waits on the library's stream -> copy
+    import torch
+    from gsplat_hip import bands
+    cfg = gh.synth.CONFIGS["C1"]
+    rows, data, pos = scenes("C1")
+    r = gh.HIPRenderer(cfg["width"], cfg["height"])
+    r.set_raw_scene(data, pos)
+    link = bands.StreamLink(torch, r, "cuda:0")
+    fb8 = bands.framebuffer8_tensor(torch, r, "cuda:0")
+    outs = []
+    for k in (3, 50):
+        r.set_camera(_camera(gh, k, cfg))
+        link.renderer_waits_for_torch()
+        r.render_async()
+        r.convert_rgba8_async()
+        link.torch_waits_for_renderer()
+        outs.append(fb8.clone())            # on torch's stream, ordered after the conversion
+    torch.cuda.synchronize()
+    r.sync()
+    assert np.array_equal(outs[1].cpu().numpy(), r.readPixels())
+    r.set_camera(_camera(gh, 3, cfg))
+    r.render_async(); r.sync()
+    assert np.array_equal(outs[0].cpu().numpy(), r.readPixels())
+    tot = r.bin_totals()
+    assert tot.shape == (-(-cfg["height"] // 32), -(-cfg["width"] // 32)) and tot.sum() == r.stats()["bin_entries"]
+    r.dispose()

@@ -35,6 +35,15 @@ def _worker(rank, world, port, W, H, out):
         for _ in range(2):                       # twice: buffers are reused frame after frame
             got = x.exchange(fb)
         ok = bool(torch.equal(got, full))
+        # the bench's default: cost-balanced (unequal) bands, RGBA8 slabs
+        cost = [1.0 + 50.0 * (abs(k - (W // 32) / 2) < 2) for k in range(-(-W // 32))]
+        edges = bands.balanced_edges(W, world, cost)
+        full8 = (full * 255).to(torch.uint8)
+        a, b = edges[rank]
+        fb8 = torch.zeros_like(full8)
+        fb8[:, a:b] = full8[:, a:b]
+        x8 = bands.FrameExchange(dist, torch, W, H, rank, world, "cpu", edges=edges, dtype=torch.uint8)
+        ok = ok and bool(torch.equal(x8.exchange(fb8), full8))
         t = torch.tensor([1.0 if ok else 0.0])
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         if rank == 0:

@@ -103,3 +103,24 @@ def test_scene_sh_packing_matches_oracle(oracle):
     for c in range(3):
         assert sc.shs_rgb[c].size == 2048 * sc.shHeight * 4
         assert np.array_equal(sc.shs_rgb[c][:want[c].size], want[c])
+
+
+def test_balanced_band_edges():
+    from gsplat_hip import bands
+    rng = np.random.default_rng(0)
+    for W in (640, 1920, 3840, 333):
+        nbx = -(-W // 32)
+        x = np.arange(nbx)
+        cost = np.exp(-0.5 * ((x - nbx / 2) / (nbx / 6)) ** 2) * 1000 + 20 + rng.random(nbx)   # centre-heavy
+        for world in (1, 2, 3, 4, 8):
+            e = bands.balanced_edges(W, world, cost)
+            assert len(e) == world and e[0][0] == 0 and e[-1][1] == W
+            for (a, b), (c, d) in zip(e[:-1], e[1:]):
+                assert b == c and (a % 32 == 0 or a == W)
+            if world <= nbx:
+                assert all(b > a for a, b in e)
+                per = [cost[a // 32:-(-b // 32)].sum() for a, b in e]
+                eq = [cost[a // 32:-(-b // 32)].sum() for a, b in bands.band_edges(W, world)]
+                assert max(per) <= max(eq) + 1e-9               # never worse than equal-width bands
+            assert all(b - a <= bands.slab_width(W, world, e) for a, b in e)
+    assert bands.balanced_edges(64, 4, [1, 1]) == [(0, 32), (32, 64), (64, 64), (64, 64)]
