@@ -215,6 +215,11 @@ int enqueue_frame(gsr_ctx* c, bool render)
         c->ev_is_render[slot] = render;
     }
     c->cam.W = c->W; c->cam.H = c->H;
+    {
+        const BinGrid bg = make_grid(c);
+        c->cam.band_px0 = bg.bx_lo * BIN_PX;
+        c->cam.band_px1 = bg.bx_hi * BIN_PX;
+    }
     c->cam.sh_on = c->sh_count ? 1 : 0;
     c->cam.band[0] = c->band[0]; c->cam.band[1] = c->band[1]; c->cam.band[2] = c->band[2];
     HIP_TRY(c, hipMemcpyAsync(c->fstate, c->fstate_init, sizeof(FrameState), hipMemcpyDeviceToDevice, s));

@@ -27,6 +27,7 @@ struct CamParams {
     int32_t W, H;
     int32_t sh_on;          // scene carries SH textures
     int32_t band[3];        // Scene.bandsIndices
+    int32_t band_px0, band_px1;  // pixel columns [x0, x1) this context composites (multi-GPU band; whole image otherwise)
     int32_t use_fade;       // u_useDepthFade
     float fade;             // u_depthFade
 };

@@ -261,6 +261,8 @@ __global__ __launch_bounds__(256) void k_project_key(SceneSoA sc, uint32_t n, Ca
                 float fy0 = floorf(cy - ey - 0.5f), fy1 = ceilf(cy + ey - 0.5f);
                 fx0 = fmaxf(fx0, 0.0f); fy0 = fmaxf(fy0, 0.0f);
                 fx1 = fminf(fx1, (float)(cam.W - 1)); fy1 = fminf(fy1, (float)(cam.H - 1));
+                // a splat whose box misses this context's column band (multi-GPU split) is somebody else's: no record
+                if (fx0 <= fx1 && (fx1 < (float)cam.band_px0 || fx0 >= (float)cam.band_px1)) break;
                 // the record is written even when the bbox is empty (parity read-back)
                 float4* rp = reinterpret_cast<float4*>(rec + i);
                 rp[0] = make_float4(r.cx, r.cy, r.ux, r.uy);
