@@ -45,6 +45,9 @@ struct gsr_ctx {
     uint32_t n = 0;
     float *px = nullptr, *py = nullptr, *pz = nullptr;
     uint32_t *cov0 = nullptr, *cov1 = nullptr, *cov2 = nullptr, *rgba = nullptr;
+    // rotations / scales, only for scenes built on the device from .splat rows
+    float4 *rotv = nullptr, *sclv = nullptr;
+    bool have_rows = false;
     // spherical harmonics (optional)
     uint32_t *sh_r = nullptr, *sh_g = nullptr, *sh_b = nullptr;
     float4* shcol = nullptr;
@@ -383,6 +386,7 @@ int gsr_destroy(gsr_ctx* c)
     dev_free(&c->px); dev_free(&c->py); dev_free(&c->pz);
     dev_free(&c->cov0); dev_free(&c->cov1); dev_free(&c->cov2); dev_free(&c->rgba);
     dev_free(&c->sh_r); dev_free(&c->sh_g); dev_free(&c->sh_b); dev_free(&c->shcol);
+    dev_free(&c->rotv); dev_free(&c->sclv);
     dev_free(&c->depth); dev_free(&c->keys); dev_free(&c->keys_tmp); dev_free(&c->idx_tmp); dev_free(&c->depth_index);
     dev_free(&c->block_hist); dev_free(&c->rec); dev_free(&c->bbox);
     dev_free(&c->bin_table); dev_free(&c->bin_total); dev_free(&c->bin_start); dev_free(&c->bin_list);
@@ -396,16 +400,17 @@ int gsr_destroy(gsr_ctx* c)
     return GSR_OK;
 }
 
-int gsr_set_scene(gsr_ctx* c, const uint32_t* data, const float* positions, uint32_t n)
+}  // extern "C"
+
+namespace {
+
+// (re)allocate everything sized by the splat count; clears SH and per-frame state
+int alloc_scene(gsr_ctx* c, uint32_t n, bool with_rows)
 {
-    if (!c) return GSR_ERR_ARG;
-    if (n && (!data || !positions)) return fail(c, GSR_ERR_ARG, "data/positions is NULL");
-    if (n > 0x7fffffffu / 8) return fail(c, GSR_ERR_ARG, "too many splats");
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->n = 0; c->have_frame = false; c->have_sort = false;
+    c->n = 0; c->have_frame = false; c->have_sort = false; c->have_rows = false;
     c->sh_count = 0; c->band[0] = c->band[1] = c->band[2] = -1;
     dev_free(&c->sh_r); dev_free(&c->sh_g); dev_free(&c->sh_b); dev_free(&c->shcol);
+    dev_free(&c->rotv); dev_free(&c->sclv);
     int r;
     if ((r = dev_alloc(c, &c->px, n)) || (r = dev_alloc(c, &c->py, n)) || (r = dev_alloc(c, &c->pz, n)) ||
         (r = dev_alloc(c, &c->cov0, n)) || (r = dev_alloc(c, &c->cov1, n)) || (r = dev_alloc(c, &c->cov2, n)) ||
@@ -413,9 +418,35 @@ int gsr_set_scene(gsr_ctx* c, const uint32_t* data, const float* positions, uint
         (r = dev_alloc(c, &c->keys_tmp, n)) || (r = dev_alloc(c, &c->idx_tmp, n)) ||
         (r = dev_alloc(c, &c->depth_index, n)) || (r = dev_alloc(c, &c->rec, n)) || (r = dev_alloc(c, &c->bbox, n)))
         return r;
+    if (with_rows && ((r = dev_alloc(c, &c->rotv, n)) || (r = dev_alloc(c, &c->sclv, n)))) return r;
     c->sort_kpb = 2048;
     c->sort_blocks = (n + c->sort_kpb - 1) / c->sort_kpb;
-    if ((r = dev_alloc(c, &c->block_hist, (size_t)std::max(c->sort_blocks, 1u) * RADIX_HI_BINS))) return r;
+    return dev_alloc(c, &c->block_hist, (size_t)std::max(c->sort_blocks, 1u) * RADIX_HI_BINS);
+}
+
+SceneDev scene_dev(gsr_ctx* c) { return SceneDev{c->px, c->py, c->pz, c->cov0, c->cov1, c->cov2, c->rgba, c->rotv, c->sclv}; }
+
+int need_rows(gsr_ctx* c)
+{
+    if (!c->have_rows) return fail(c, GSR_ERR_ARG, "scene transforms need a scene built with gsr_set_scene_rows");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->have_frame = false; c->have_sort = false;
+    return GSR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gsr_set_scene(gsr_ctx* c, const uint32_t* data, const float* positions, uint32_t n)
+{
+    if (!c) return GSR_ERR_ARG;
+    if (n && (!data || !positions)) return fail(c, GSR_ERR_ARG, "data/positions is NULL");
+    if (n > 0x7fffffffu / 8) return fail(c, GSR_ERR_ARG, "too many splats");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int r;
+    if ((r = alloc_scene(c, n, false))) return r;
     if (n) {
         uint32_t* d_data = nullptr; float* d_pos = nullptr; uint32_t* d_flag = nullptr;
         if ((r = dev_alloc(c, &d_data, (size_t)n * 8)) || (r = dev_alloc(c, &d_pos, (size_t)n * 3)) || (r = dev_alloc(c, &d_flag, 1))) {
@@ -437,6 +468,132 @@ int gsr_set_scene(gsr_ctx* c, const uint32_t* data, const float* positions, uint
     c->n = n;
     c->bin_capacity = 0;
     return alloc_bins(c);
+}
+
+int gsr_set_scene_rows(gsr_ctx* c, const uint8_t* rows, uint32_t n)
+{
+    if (!c) return GSR_ERR_ARG;
+    if (n && !rows) return fail(c, GSR_ERR_ARG, "rows is NULL");
+    if (n > 0x7fffffffu / 8) return fail(c, GSR_ERR_ARG, "too many splats");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int r;
+    if ((r = alloc_scene(c, n, true))) return r;
+    if (n) {
+        uint8_t* d_rows = nullptr;
+        if ((r = dev_alloc(c, &d_rows, (size_t)n * 32))) return r;
+        hipError_t e1 = hipMemcpyAsync(d_rows, rows, (size_t)n * 32, hipMemcpyHostToDevice, c->stream);
+        launch_build_scene(d_rows, n, scene_dev(c), c->stream);
+        hipError_t e2 = hipStreamSynchronize(c->stream);
+        dev_free(&d_rows);
+        for (hipError_t e : {e1, e2, hipGetLastError()})
+            if (e != hipSuccess) return fail(c, GSR_ERR_HIP, "scene build failed: %s", hipGetErrorString(e));
+    }
+    c->n = n;
+    c->have_rows = true;
+    c->bin_capacity = 0;
+    return alloc_bins(c);
+}
+
+int gsr_scene_translate(gsr_ctx* c, const double* t)
+{
+    if (!c || !t) return GSR_ERR_ARG;
+    if (int r = need_rows(c)) return r;
+    launch_scene_translate(c->n, scene_dev(c), t, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_scene_rotate(gsr_ctx* c, const double* q)
+{
+    if (!c || !q) return GSR_ERR_ARG;
+    if (int r = need_rows(c)) return r;
+    launch_scene_rotate(c->n, scene_dev(c), q, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_scene_scale(gsr_ctx* c, const double* sv)
+{
+    if (!c || !sv) return GSR_ERR_ARG;
+    if (int r = need_rows(c)) return r;
+    launch_scene_scale(c->n, scene_dev(c), sv, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_scene_limit_box(gsr_ctx* c, const double* box, uint32_t* new_count)
+{
+    if (!c || !box) return GSR_ERR_ARG;
+    if (box[0] >= box[1]) return fail(c, GSR_ERR_ARG, "xMin (%g) must be smaller than xMax (%g)", box[0], box[1]);   // Scene.ts:308-316
+    if (box[2] >= box[3]) return fail(c, GSR_ERR_ARG, "yMin (%g) must be smaller than yMax (%g)", box[2], box[3]);
+    if (box[4] >= box[5]) return fail(c, GSR_ERR_ARG, "zMin (%g) must be smaller than zMax (%g)", box[4], box[5]);
+    if (int r = need_rows(c)) return r;
+    const uint32_t n = c->n;
+    uint32_t kept = 0;
+    if (n) {
+        gsr_ctx tmp_holder;  // only its pointer fields are used, as a second SoA
+        gsr_ctx* d = &tmp_holder;
+        uint32_t* block_count = nullptr;
+        uint32_t* total = nullptr;
+        int r;
+        if ((r = dev_alloc(c, &d->px, n)) || (r = dev_alloc(c, &d->py, n)) || (r = dev_alloc(c, &d->pz, n)) ||
+            (r = dev_alloc(c, &d->cov0, n)) || (r = dev_alloc(c, &d->cov1, n)) || (r = dev_alloc(c, &d->cov2, n)) ||
+            (r = dev_alloc(c, &d->rgba, n)) || (r = dev_alloc(c, &d->rotv, n)) || (r = dev_alloc(c, &d->sclv, n)) ||
+            (r = dev_alloc(c, &block_count, (n + 1023) / 1024)) || (r = dev_alloc(c, &total, 1)))
+            return r;
+        launch_scene_limit_box(n, scene_dev(c), scene_dev(d), box, block_count, total, c->stream);
+        hipError_t e1 = hipMemcpyAsync(&kept, total, 4, hipMemcpyDeviceToHost, c->stream);
+        hipError_t e2 = hipStreamSynchronize(c->stream);
+        std::swap(c->px, d->px); std::swap(c->py, d->py); std::swap(c->pz, d->pz);
+        std::swap(c->cov0, d->cov0); std::swap(c->cov1, d->cov1); std::swap(c->cov2, d->cov2); std::swap(c->rgba, d->rgba);
+        std::swap(c->rotv, d->rotv); std::swap(c->sclv, d->sclv);
+        dev_free(&d->px); dev_free(&d->py); dev_free(&d->pz); dev_free(&d->cov0); dev_free(&d->cov1); dev_free(&d->cov2);
+        dev_free(&d->rgba); dev_free(&d->rotv); dev_free(&d->sclv); dev_free(&block_count); dev_free(&total);
+        for (hipError_t e : {e1, e2, hipGetLastError()})
+            if (e != hipSuccess) return fail(c, GSR_ERR_HIP, "limitBox failed: %s", hipGetErrorString(e));
+        c->n = kept;   // arrays keep their old capacity; per-frame buffers sized for the old count still fit
+        c->sort_blocks = (kept + c->sort_kpb - 1) / c->sort_kpb;
+        c->bin_blocks = (kept + 2047) / 2048;
+    }
+    if (new_count) *new_count = kept;
+    return GSR_OK;
+}
+
+int gsr_read_scene(gsr_ctx* c, uint32_t* data, float* positions, float* rotations, float* scales, uint32_t* count)
+{
+    if (!c) return GSR_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t n = c->n;
+    if (count) *count = n;
+    if ((rotations || scales) && !c->have_rows) return fail(c, GSR_ERR_ARG, "rotations/scales exist only for scenes built with gsr_set_scene_rows");
+    std::vector<float> x(n), y(n), z(n);
+    std::vector<uint32_t> c0, c1, c2, cw;
+    std::vector<float4> rv, sv;
+    HIP_TRY(c, hipMemcpyAsync(x.data(), c->px, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(y.data(), c->py, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(z.data(), c->pz, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (data) {
+        c0.resize(n); c1.resize(n); c2.resize(n); cw.resize(n);
+        HIP_TRY(c, hipMemcpyAsync(c0.data(), c->cov0, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c1.data(), c->cov1, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c2.data(), c->cov2, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(cw.data(), c->rgba, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (rotations) { rv.resize(n); HIP_TRY(c, hipMemcpyAsync(rv.data(), c->rotv, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream)); }
+    if (scales) { sv.resize(n); HIP_TRY(c, hipMemcpyAsync(sv.data(), c->sclv, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream)); }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < n; i++) {
+        if (positions) { positions[3 * (size_t)i] = x[i]; positions[3 * (size_t)i + 1] = y[i]; positions[3 * (size_t)i + 2] = z[i]; }
+        if (data) {
+            uint32_t* d = data + 8 * (size_t)i;
+            memcpy(&d[0], &x[i], 4); memcpy(&d[1], &y[i], 4); memcpy(&d[2], &z[i], 4);
+            d[3] = 0; d[4] = c0[i]; d[5] = c1[i]; d[6] = c2[i]; d[7] = cw[i];
+        }
+        if (rotations) { float* r = rotations + 4 * (size_t)i; r[0] = rv[i].x; r[1] = rv[i].y; r[2] = rv[i].z; r[3] = rv[i].w; }
+        if (scales) { float* q = scales + 3 * (size_t)i; q[0] = sv[i].x; q[1] = sv[i].y; q[2] = sv[i].z; }
+    }
+    return GSR_OK;
 }
 
 int gsr_set_scene_sh(gsr_ctx* c, const uint32_t* sh_r, const uint32_t* sh_g, const uint32_t* sh_b, uint32_t sh_count,

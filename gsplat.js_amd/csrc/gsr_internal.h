@@ -53,6 +53,20 @@ struct SceneSoA {
     float4* shcol;                       // out: evaluated SH colour per splat (null without SH)
 };
 
+// mutable device scene for the on-device build / transforms (k_scene.hip)
+struct SceneDev {
+    float *px, *py, *pz;
+    uint32_t *cov0, *cov1, *cov2, *rgba;
+    float4* rot;   // (w, x, y, z) as Scene._rotations stores them
+    float4* scl;   // Scene._scales
+};
+void launch_build_scene(const uint8_t* rows, uint32_t n, const SceneDev& sc, hipStream_t s);
+void launch_scene_translate(uint32_t n, const SceneDev& sc, const double* t, hipStream_t s);
+void launch_scene_rotate(uint32_t n, const SceneDev& sc, const double* q_xyzw, hipStream_t s);
+void launch_scene_scale(uint32_t n, const SceneDev& sc, const double* sv, hipStream_t s);
+void launch_scene_limit_box(uint32_t n, const SceneDev& src, const SceneDev& dst, const double* box, uint32_t* block_count,
+                            uint32_t* total, hipStream_t s);
+
 // ---- launchers (each enqueues on `s`; none synchronises) ----
 void launch_repack_scene(const uint32_t* data, const float* positions, uint32_t n, float* px, float* py, float* pz,
                          uint32_t* cov0, uint32_t* cov1, uint32_t* cov2, uint32_t* rgba, uint32_t* mismatch, hipStream_t s);

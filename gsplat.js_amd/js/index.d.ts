@@ -105,6 +105,14 @@ export class HIPRenderer {
     setCameraBuffers(): void;
     setShTextures(): void;
     setDepthFade(useDepthFade: boolean, depthFade: number): void;
+    /** device-side scene: .splat rows in; Scene.setData and the transforms run as kernels, bit-identical to Scene */
+    setSceneRows(rows: Uint8Array): void;
+    sceneTranslate(t: Vector3): void;
+    sceneRotate(q: Quaternion): void;
+    sceneScale(s: Vector3): void;
+    sceneLimitBox(xMin: number, xMax: number, yMin: number, yMax: number, zMin: number, zMax: number): void;
+    readSceneData(): { data: Uint32Array; positions: Float32Array; vertexCount: number };
+    renderDeviceScene(camera: Camera): void;
     dispose(): void;
     /** RGBA8, row 0 = top, round(clamp(x,0,1)*255), premultiplied alpha */
     readPixels(): Uint8Array;

@@ -169,6 +169,71 @@ napi_value SetSceneSh(napi_env env, napi_callback_info info)
     return rc ? throw_gsr(env, c, rc, "gsr_set_scene_sh") : undefined(env);
 }
 
+// setSceneRows(handle, Uint8Array rows)
+napi_value SetSceneRows(napi_env env, napi_callback_info info)
+{
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return nullptr;
+    gsr_ctx* c = get_ctx(env, argv[0]);
+    void* rows;
+    size_t len;
+    if (!c || !get_typed(env, argv[1], napi_uint8_array, &rows, &len)) return nullptr;
+    if (len % 32) { napi_throw_range_error(env, nullptr, "rows length must be a multiple of 32"); return nullptr; }
+    const int rc = gsr_set_scene_rows(c, (const uint8_t*)rows, (uint32_t)(len / 32));
+    return rc ? throw_gsr(env, c, rc, "gsr_set_scene_rows") : undefined(env);
+}
+
+// sceneTransform(handle, kind, Float64Array args): kind 0 translate(3) 1 rotate(4: x,y,z,w) 2 scale(3) 3 limitBox(6) -> new count
+napi_value SceneTransform(napi_env env, napi_callback_info info)
+{
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return nullptr;
+    gsr_ctx* c = get_ctx(env, argv[0]);
+    int32_t kind;
+    void* a;
+    size_t len;
+    if (!c || !get_i32(env, argv[1], &kind) || !get_typed(env, argv[2], napi_float64_array, &a, &len)) return nullptr;
+    static const size_t need[4] = {3, 4, 3, 6};
+    if (kind < 0 || kind > 3 || len < need[kind]) { napi_throw_range_error(env, nullptr, "bad transform arguments"); return nullptr; }
+    uint32_t count = 0;
+    int rc;
+    const double* d = (const double*)a;
+    if (kind == 0) rc = gsr_scene_translate(c, d);
+    else if (kind == 1) rc = gsr_scene_rotate(c, d);
+    else if (kind == 2) rc = gsr_scene_scale(c, d);
+    else rc = gsr_scene_limit_box(c, d, &count);
+    if (rc) return throw_gsr(env, c, rc, "gsr_scene transform");
+    if (kind != 3) gsr_read_scene(c, nullptr, nullptr, nullptr, nullptr, &count);
+    napi_value n;
+    napi_create_uint32(env, count, &n);
+    return n;
+}
+
+// readScene(handle, Uint32Array data | null, Float32Array positions | null) -> count
+napi_value ReadScene(napi_env env, napi_callback_info info)
+{
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return nullptr;
+    gsr_ctx* c = get_ctx(env, argv[0]);
+    void *data, *pos;
+    size_t nd, np;
+    if (!c || !get_typed(env, argv[1], napi_uint32_array, &data, &nd, true) || !get_typed(env, argv[2], napi_float32_array, &pos, &np, true))
+        return nullptr;
+    uint32_t count = 0;
+    int rc = gsr_read_scene(c, nullptr, nullptr, nullptr, nullptr, &count);
+    if (!rc) {
+        if ((data && nd < (size_t)count * 8) || (pos && np < (size_t)count * 3)) {
+            napi_throw_range_error(env, nullptr, "output arrays are smaller than the scene");
+            return nullptr;
+        }
+        rc = gsr_read_scene(c, (uint32_t*)data, (float*)pos, nullptr, nullptr, &count);
+    }
+    if (rc) return throw_gsr(env, c, rc, "gsr_read_scene");
+    napi_value n;
+    napi_create_uint32(env, count, &n);
+    return n;
+}
+
 napi_value SetDepthFade(napi_env env, napi_callback_info info)
 {
     napi_value argv[3];
@@ -342,7 +407,8 @@ napi_value SortHost(napi_env env, napi_callback_info info)
 napi_value Init(napi_env env, napi_value exports)
 {
     struct { const char* name; napi_callback fn; } fns[] = {
-        {"create", Create}, {"destroy", Destroy}, {"setScene", SetScene}, {"setSceneSh", SetSceneSh}, {"setDepthFade", SetDepthFade}, {"resize", Resize}, {"setBand", SetBand},
+        {"create", Create}, {"destroy", Destroy}, {"setScene", SetScene}, {"setSceneSh", SetSceneSh}, {"setDepthFade", SetDepthFade}, {"setSceneRows", SetSceneRows},
+        {"sceneTransform", SceneTransform}, {"readScene", ReadScene}, {"resize", Resize}, {"setBand", SetBand},
         {"setCamera", SetCamera}, {"sort", Call0<gsr_sort>}, {"render", Call0<gsr_render>},
         {"renderAsync", Call0<gsr_render_async>}, {"sync", Call0<gsr_sync>}, {"resetTimings", Call0<gsr_reset_timings>},
         {"readDepthIndex", ReadDepthIndex}, {"readPixels", ReadPixels}, {"getTimings", GetTimings},

@@ -98,6 +98,33 @@ class HIPRenderer {
             initialized = false;
         };
 
+        // ---- optional device-side scene (SURVEY 8(f) rank 2): .splat rows in, Scene.setData and the transforms run as
+        // kernels (bit-identical to Scene.js), no re-upload per change; render with renderDeviceScene(camera) ----
+        this.setSceneRows = (rows) => {
+            if (activeScene) activeScene.removeEventListener("change", onSceneChange);
+            activeScene = null;
+            this._n.setSceneRows(this._h, rows);
+            vertexCount = rows.length / 32;
+            for (const p of passes) p.init(this, null);
+            initialized = true;
+        };
+        const xf = (kind, args) => { vertexCount = this._n.sceneTransform(this._h, kind, new Float64Array(args)); };
+        this.sceneTranslate = (v) => xf(0, [v.x, v.y, v.z]);
+        this.sceneRotate = (q) => xf(1, [q.x, q.y, q.z, q.w]);
+        this.sceneScale = (v) => xf(2, [v.x, v.y, v.z]);
+        this.sceneLimitBox = (xMin, xMax, yMin, yMax, zMin, zMax) => xf(3, [xMin, xMax, yMin, yMax, zMin, zMax]);
+        this.readSceneData = () => {
+            const data = new Uint32Array(vertexCount * 8), positions = new Float32Array(vertexCount * 3);
+            this._n.readScene(this._h, data, positions);
+            return { data: data, positions: positions, vertexCount: vertexCount };
+        };
+        this.renderDeviceScene = (camera) => {
+            activeCamera = camera;
+            pushCamera();
+            for (const p of passes) p.render();
+            this._n.render(this._h);
+        };
+
         // ---- results ----
         this.lastDepthIndex = () => { const a = new Uint32Array(vertexCount); this._n.readDepthIndex(this._h, a); return a; };
         this.readPixels = () => { const a = new Uint8Array(this.width * this.height * 4); this._n.readPixels(this._h, a, this.width, this.height); return a; };

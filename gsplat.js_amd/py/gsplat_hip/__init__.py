@@ -46,7 +46,8 @@ _lib = None
 
 # every symbol include/gsplat_hip.h declares
 EXPORTS = [
-    "gsr_create", "gsr_destroy", "gsr_last_error", "gsr_set_scene", "gsr_set_scene_sh", "gsr_read_sh_colors", "gsr_set_depth_fade", "gsr_resize", "gsr_set_band", "gsr_set_camera",
+    "gsr_create", "gsr_destroy", "gsr_last_error", "gsr_set_scene", "gsr_set_scene_sh", "gsr_read_sh_colors", "gsr_set_depth_fade", "gsr_resize",
+    "gsr_set_scene_rows", "gsr_scene_translate", "gsr_scene_rotate", "gsr_scene_scale", "gsr_scene_limit_box", "gsr_read_scene", "gsr_set_band", "gsr_set_camera",
     "gsr_sort", "gsr_render", "gsr_render_async", "gsr_sync", "gsr_read_depth_index", "gsr_read_pixels_rgba32f",
     "gsr_read_pixels_rgba8", "gsr_get_timings", "gsr_reset_timings", "gsr_read_keys", "gsr_read_records",
     "gsr_read_bin_totals", "gsr_convert_rgba8_async", "gsr_framebuffer8_device_ptr",
@@ -72,6 +73,11 @@ def load_library(path=None):
     L.gsr_set_scene_sh.argtypes = [vp, vp, vp, vp, ctypes.c_uint32, vp]
     L.gsr_read_sh_colors.argtypes = [vp, vp]
     L.gsr_set_depth_fade.argtypes = [vp, ctypes.c_int32, ctypes.c_float]
+    L.gsr_set_scene_rows.argtypes = [vp, vp, ctypes.c_uint32]
+    for name in ("gsr_scene_translate", "gsr_scene_rotate", "gsr_scene_scale"):
+        getattr(L, name).argtypes = [vp, vp]
+    L.gsr_scene_limit_box.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_uint32)]
+    L.gsr_read_scene.argtypes = [vp, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_uint32)]
     L.gsr_resize.argtypes = [vp, ctypes.c_int32, ctypes.c_int32]
     L.gsr_set_band.argtypes = [vp, ctypes.c_int32, ctypes.c_int32]
     L.gsr_set_camera.argtypes = [vp, vp, vp, vp, ctypes.c_float, ctypes.c_float]
@@ -267,6 +273,45 @@ class HIPRenderer:
         out = np.empty((self._n, 4), dtype=np.float32)
         self._check(self._L.gsr_read_sh_colors(self._ctx, out.ctypes.data))
         return out
+
+    # -- on-device scene build and transforms (Scene.ts:58-366 as kernels) --
+    def set_scene_rows(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.uint8).reshape(-1)
+        self._check(self._L.gsr_set_scene_rows(self._ctx, rows.ctypes.data, rows.size // 32))
+        self._n = rows.size // 32
+        self._scene = None
+
+    def scene_translate(self, t):
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        self._check(self._L.gsr_scene_translate(self._ctx, t.ctypes.data))
+
+    def scene_rotate(self, q_xyzw):
+        q = np.ascontiguousarray(q_xyzw, dtype=np.float64)
+        self._check(self._L.gsr_scene_rotate(self._ctx, q.ctypes.data))
+
+    def scene_scale(self, s):
+        s = np.ascontiguousarray(s, dtype=np.float64)
+        self._check(self._L.gsr_scene_scale(self._ctx, s.ctypes.data))
+
+    def scene_limit_box(self, box):
+        box = np.ascontiguousarray(box, dtype=np.float64)
+        n = ctypes.c_uint32(0)
+        self._check(self._L.gsr_scene_limit_box(self._ctx, box.ctypes.data, ctypes.byref(n)))
+        self._n = n.value
+        return n.value
+
+    def read_scene(self, with_rows=True):
+        """(data u32[8n], positions f32[3n], rotations f32[4n] | None, scales f32[3n] | None)"""
+        n = self._n
+        data = np.zeros(8 * n, dtype=np.uint32)
+        pos = np.zeros(3 * n, dtype=np.float32)
+        rot = np.zeros(4 * n, dtype=np.float32) if with_rows else None
+        scl = np.zeros(3 * n, dtype=np.float32) if with_rows else None
+        cnt = ctypes.c_uint32(0)
+        self._check(self._L.gsr_read_scene(self._ctx, data.ctypes.data, pos.ctypes.data, rot.ctypes.data if with_rows else None,
+                                           scl.ctypes.data if with_rows else None, ctypes.byref(cnt)))
+        assert cnt.value == n
+        return data, pos, rot, scl
 
     def set_depth_fade(self, use, value):
         """u_useDepthFade / u_depthFade of FadeInPass."""

@@ -15,6 +15,8 @@
  *   worker scene init                Worker.ts:23-34 (positions copied once per scene)
  *   + texImage2D(scene.data)         src/renderers/WebGLRenderer.ts:185-195
  *                                      -> gsr_set_scene
+ *   Scene.setData / translate / rotate / scale / limitBox   src/core/Scene.ts:58-366
+ *                                      -> gsr_set_scene_rows, gsr_scene_* (optional device-side versions)
  *   setShTextures + u_bandIndex      WebGLRenderer.ts:202-211,321-366
  *                                      -> gsr_set_scene_sh
  *   uniforms projection/view/focal/viewport + postMessage({viewProj})
@@ -85,6 +87,18 @@ const char *gsr_last_error(gsr_ctx *ctx); /* ctx may be NULL: error of the faile
  * positions: Scene.positions, 3 f32 per splat, must equal data words 0..2.
  * Repacked once into SoA on the device. */
 int gsr_set_scene(gsr_ctx *ctx, const uint32_t *data, const float *positions, uint32_t n);
+
+/* On-device scene build: rows = .splat bytes, 32 per splat (src/core/Scene.ts:9,126-148).  The
+ * device does what Scene.setData does (covariance in f64, truncated halves) and keeps rotations/scales, so the
+ * transforms below run as kernels instead of JavaScript loops + full re-upload.  Results are bit-identical to the
+ * JavaScript ones (Scene.ts:126-366).  q = (x, y, z, w); box = xMin, xMax, yMin, yMax, zMin, zMax. */
+int gsr_set_scene_rows(gsr_ctx *ctx, const uint8_t *rows, uint32_t n);
+int gsr_scene_translate(gsr_ctx *ctx, const double *t /* 3 */);
+int gsr_scene_rotate(gsr_ctx *ctx, const double *q /* 4 */);
+int gsr_scene_scale(gsr_ctx *ctx, const double *s /* 3 */);
+int gsr_scene_limit_box(gsr_ctx *ctx, const double *box /* 6 */, uint32_t *new_count);
+/* Any of the outputs may be NULL.  data: 8 u32 per splat; rotations (w,x,y,z) / scales only for scenes built from rows. */
+int gsr_read_scene(gsr_ctx *ctx, uint32_t *data, float *positions, float *rotations, float *scales, uint32_t *count);
 
 /* Spherical-harmonics colour (the fork's SH textures): sh_r/g/b = Scene.shs_rgb (8 u32 = 16 truncated halves per
  * SH-carrying splat and channel, src/core/Scene.ts:108-124; uploaded by setShTextures, WebGLRenderer.ts:321-366),

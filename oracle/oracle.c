@@ -151,11 +151,45 @@ void orc_scene_pack_sh(const float *shs, uint32_t count, uint32_t *sh_r, uint32_
     }
 }
 
-void orc_scene_pack(const uint8_t *rows, uint32_t n, uint32_t *data, float *positions)
+/* 4*Sigma of one splat from its stored rotation (w,x,y,z as f32) and scale (f32), packed as six truncated halves
+ * into d[4..6].  Scene.ts:150-176 with Matrix3.ts:33-47,63-80, all in f64 in the written order. */
+static void orc_pack_cov(const float *rot, const float *scl, uint32_t *d)
+{
+    /* Scene.ts:150-157: Quaternion(x=r1, y=r2, z=r3, w=-r0); Matrix3.ts:67-80 */
+    double qx = rot[1], qy = rot[2], qz = rot[3], qw = -(double)rot[0];
+    double R[9] = {
+        1 - 2 * qy * qy - 2 * qz * qz, 2 * qx * qy - 2 * qz * qw, 2 * qx * qz + 2 * qy * qw,
+        2 * qx * qy + 2 * qz * qw, 1 - 2 * qx * qx - 2 * qz * qz, 2 * qy * qz - 2 * qx * qw,
+        2 * qx * qz - 2 * qy * qw, 2 * qy * qz + 2 * qx * qw, 1 - 2 * qx * qx - 2 * qy * qy,
+    };
+    /* Scene.ts:159-163: Diagonal(scale).multiply(rot); Matrix3.ts:33-47 with a = diag, b = R */
+    double a[9] = { (double)scl[0], 0, 0, 0, (double)scl[1], 0, 0, 0, (double)scl[2] };
+    const double *b = R;
+    double M[9] = {
+        b[0] * a[0] + b[3] * a[1] + b[6] * a[2], b[1] * a[0] + b[4] * a[1] + b[7] * a[2], b[2] * a[0] + b[5] * a[1] + b[8] * a[2],
+        b[0] * a[3] + b[3] * a[4] + b[6] * a[5], b[1] * a[3] + b[4] * a[4] + b[7] * a[5], b[2] * a[3] + b[5] * a[4] + b[8] * a[5],
+        b[0] * a[6] + b[3] * a[7] + b[6] * a[8], b[1] * a[6] + b[4] * a[7] + b[7] * a[8], b[2] * a[6] + b[5] * a[7] + b[8] * a[8],
+    };
+    /* Scene.ts:165-172 */
+    double s0 = M[0] * M[0] + M[3] * M[3] + M[6] * M[6];
+    double s1 = M[0] * M[1] + M[3] * M[4] + M[6] * M[7];
+    double s2 = M[0] * M[2] + M[3] * M[5] + M[6] * M[8];
+    double s3 = M[1] * M[1] + M[4] * M[4] + M[7] * M[7];
+    double s4 = M[1] * M[2] + M[4] * M[5] + M[7] * M[8];
+    double s5 = M[2] * M[2] + M[5] * M[5] + M[8] * M[8];
+    /* Scene.ts:174-176 */
+    d[4] = orc_pack_half2x16(4 * s0, 4 * s1);
+    d[5] = orc_pack_half2x16(4 * s2, 4 * s3);
+    d[6] = orc_pack_half2x16(4 * s4, 4 * s5);
+}
+
+/* Scene.setData: rows -> data (8 u32 per splat), positions, and the rotations (w,x,y,z) / scales the transforms use.
+ * rotations / scales may be NULL. */
+void orc_scene_build(const uint8_t *rows, uint32_t n, uint32_t *data, float *positions, float *rotations, float *scales)
 {
     for (uint32_t i = 0; i < n; i++) {
         const uint8_t *row = rows + (size_t)32 * i;
-        float f[6];
+        float f[6], rot[4];
         memcpy(f, row, 24);
         uint32_t *d = data + (size_t)8 * i;
         /* Scene.ts:128-143 */
@@ -165,35 +199,86 @@ void orc_scene_pack(const uint8_t *rows, uint32_t n, uint32_t *data, float *posi
         /* Scene.ts:145-148 */
         d[7] = (uint32_t)row[24] | ((uint32_t)row[25] << 8) | ((uint32_t)row[26] << 16) | ((uint32_t)row[27] << 24);
         /* Scene.ts:132-135 (stored in a Float32Array: exact) */
-        double r0 = ((double)row[28] - 128) / 128, r1 = ((double)row[29] - 128) / 128;
-        double r2 = ((double)row[30] - 128) / 128, r3 = ((double)row[31] - 128) / 128;
-        /* Scene.ts:150-157: Quaternion(x=r1, y=r2, z=r3, w=-r0); Matrix3.ts:67-80 */
-        double qx = r1, qy = r2, qz = r3, qw = -r0;
-        double R[9] = {
-            1 - 2 * qy * qy - 2 * qz * qz, 2 * qx * qy - 2 * qz * qw, 2 * qx * qz + 2 * qy * qw,
-            2 * qx * qy + 2 * qz * qw, 1 - 2 * qx * qx - 2 * qz * qz, 2 * qy * qz - 2 * qx * qw,
-            2 * qx * qz - 2 * qy * qw, 2 * qy * qz + 2 * qx * qw, 1 - 2 * qx * qx - 2 * qy * qy,
-        };
-        /* Scene.ts:159-163: Diagonal(scale).multiply(rot); Matrix3.ts:33-47 with a = diag, b = R */
-        double a[9] = { (double)f[3], 0, 0, 0, (double)f[4], 0, 0, 0, (double)f[5] };
-        const double *b = R;
-        double M[9] = {
-            b[0] * a[0] + b[3] * a[1] + b[6] * a[2], b[1] * a[0] + b[4] * a[1] + b[7] * a[2], b[2] * a[0] + b[5] * a[1] + b[8] * a[2],
-            b[0] * a[3] + b[3] * a[4] + b[6] * a[5], b[1] * a[3] + b[4] * a[4] + b[7] * a[5], b[2] * a[3] + b[5] * a[4] + b[8] * a[5],
-            b[0] * a[6] + b[3] * a[7] + b[6] * a[8], b[1] * a[6] + b[4] * a[7] + b[7] * a[8], b[2] * a[6] + b[5] * a[7] + b[8] * a[8],
-        };
-        /* Scene.ts:165-172 */
-        double s0 = M[0] * M[0] + M[3] * M[3] + M[6] * M[6];
-        double s1 = M[0] * M[1] + M[3] * M[4] + M[6] * M[7];
-        double s2 = M[0] * M[2] + M[3] * M[5] + M[6] * M[8];
-        double s3 = M[1] * M[1] + M[4] * M[4] + M[7] * M[7];
-        double s4 = M[1] * M[2] + M[4] * M[5] + M[7] * M[8];
-        double s5 = M[2] * M[2] + M[5] * M[5] + M[8] * M[8];
-        /* Scene.ts:174-176 */
-        d[4] = orc_pack_half2x16(4 * s0, 4 * s1);
-        d[5] = orc_pack_half2x16(4 * s2, 4 * s3);
-        d[6] = orc_pack_half2x16(4 * s4, 4 * s5);
+        for (int k = 0; k < 4; k++) rot[k] = (float)(((double)row[28 + k] - 128) / 128);
+        orc_pack_cov(rot, f + 3, d);
+        if (rotations) memcpy(rotations + (size_t)4 * i, rot, 16);
+        if (scales) memcpy(scales + (size_t)3 * i, f + 3, 12);
     }
+}
+
+void orc_scene_pack(const uint8_t *rows, uint32_t n, uint32_t *data, float *positions)
+{
+    orc_scene_build(rows, n, data, positions, NULL, NULL);
+}
+
+static void orc_write_pos(uint32_t i, uint32_t *data, const float *positions)
+{
+    memcpy(&data[(size_t)8 * i], &positions[(size_t)3 * i], 12);
+}
+
+/* Scene.translate, Scene.ts:182-195 (Float32Array += number: f64 add, rounded to f32 on store) */
+void orc_scene_translate(uint32_t n, uint32_t *data, float *positions, const double *t)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        for (int k = 0; k < 3; k++) positions[3 * i + k] = (float)((double)positions[3 * i + k] + t[k]);
+        orc_write_pos(i, data, positions);
+    }
+}
+
+/* Scene.rotate, Scene.ts:197-257.  q = (x, y, z, w). */
+void orc_scene_rotate(uint32_t n, uint32_t *data, float *positions, float *rotations, const float *scales, const double *q)
+{
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double R[9] = {   /* Matrix3.ts:67-80 */
+        1 - 2 * y * y - 2 * z * z, 2 * x * y - 2 * z * w, 2 * x * z + 2 * y * w,
+        2 * x * y + 2 * z * w, 1 - 2 * x * x - 2 * z * z, 2 * y * z - 2 * x * w,
+        2 * x * z - 2 * y * w, 2 * y * z + 2 * x * w, 1 - 2 * x * x - 2 * y * y,
+    };
+    for (uint32_t i = 0; i < n; i++) {
+        const double px = positions[3 * i], py = positions[3 * i + 1], pz = positions[3 * i + 2];
+        positions[3 * i + 0] = (float)(R[0] * px + R[1] * py + R[2] * pz);
+        positions[3 * i + 1] = (float)(R[3] * px + R[4] * py + R[5] * pz);
+        positions[3 * i + 2] = (float)(R[6] * px + R[7] * py + R[8] * pz);
+        orc_write_pos(i, data, positions);
+        float *r = rotations + (size_t)4 * i;
+        /* currentRotation = Quaternion(x=r1, y=r2, z=r3, w=r0); newRot = rotation.multiply(current), Quaternion.ts:39-55 */
+        const double w1 = w, x1 = x, y1 = y, z1 = z, w2 = r[0], x2 = r[1], y2 = r[2], z2 = r[3];
+        const double nx = w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2;
+        const double ny = w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2;
+        const double nz = w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2;
+        const double nw = w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2;
+        r[1] = (float)nx; r[2] = (float)ny; r[3] = (float)nz; r[0] = (float)nw;
+        orc_pack_cov(r, scales + (size_t)3 * i, data + (size_t)8 * i);
+    }
+}
+
+/* Scene.scale, Scene.ts:259-305 */
+void orc_scene_scale(uint32_t n, uint32_t *data, float *positions, const float *rotations, float *scales, const double *s)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        for (int k = 0; k < 3; k++) {
+            positions[3 * i + k] = (float)((double)positions[3 * i + k] * s[k]);
+            scales[3 * i + k] = (float)((double)scales[3 * i + k] * s[k]);
+        }
+        orc_write_pos(i, data, positions);
+        orc_pack_cov(rotations + (size_t)4 * i, scales + (size_t)3 * i, data + (size_t)8 * i);
+    }
+}
+
+/* Scene.limitBox, Scene.ts:307-366: keeps splats with position inside the closed box, order preserved. Returns the new count. */
+uint32_t orc_scene_limit_box(uint32_t n, uint32_t *data, float *positions, float *rotations, float *scales, const double *box)
+{
+    uint32_t kept = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const double x = positions[3 * i], y = positions[3 * i + 1], z = positions[3 * i + 2];
+        if (!(x >= box[0] && x <= box[1] && y >= box[2] && y <= box[3] && z >= box[4] && z <= box[5])) continue;
+        memmove(data + (size_t)8 * kept, data + (size_t)8 * i, 32);
+        memmove(positions + (size_t)3 * kept, positions + (size_t)3 * i, 12);
+        memmove(rotations + (size_t)4 * kept, rotations + (size_t)4 * i, 16);
+        memmove(scales + (size_t)3 * kept, scales + (size_t)3 * i, 12);
+        kept++;
+    }
+    return kept;
 }
 
 /* ------------------------------------------------------------------------

@@ -39,6 +39,17 @@ def lib():
         L.orc_pack_half2x16.restype = ctypes.c_uint32
         L.orc_scene_pack.argtypes = [u8p, ctypes.c_uint32, u32p, f32p]
         L.orc_scene_pack.restype = None
+        dp = ctypes.POINTER(ctypes.c_double)
+        L.orc_scene_build.argtypes = [u8p, ctypes.c_uint32, u32p, f32p, f32p, f32p]
+        L.orc_scene_build.restype = None
+        L.orc_scene_translate.argtypes = [ctypes.c_uint32, u32p, f32p, dp]
+        L.orc_scene_translate.restype = None
+        L.orc_scene_rotate.argtypes = [ctypes.c_uint32, u32p, f32p, f32p, f32p, dp]
+        L.orc_scene_rotate.restype = None
+        L.orc_scene_scale.argtypes = [ctypes.c_uint32, u32p, f32p, f32p, f32p, dp]
+        L.orc_scene_scale.restype = None
+        L.orc_scene_limit_box.argtypes = [ctypes.c_uint32, u32p, f32p, f32p, f32p, dp]
+        L.orc_scene_limit_box.restype = ctypes.c_uint32
         L.orc_project.argtypes = [u32p, ctypes.c_uint32, f32p, f32p, ctypes.c_float, ctypes.c_float,
                                   ctypes.c_int, ctypes.c_int, f32p, i32p, f32p]
         L.orc_project.restype = None
@@ -86,6 +97,45 @@ def scene_pack(rows):
     pos = np.zeros(3 * n, dtype=np.float32)
     lib().orc_scene_pack(_p(rows, u8p), n, _p(data, u32p), _p(pos, f32p))
     return data, pos
+
+
+class SceneState:
+    """Scene.ts state (data, positions, rotations, scales) with the reference's transforms restated in f64."""
+
+    def __init__(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.uint8).reshape(-1)
+        self.n = rows.size // 32
+        self.data = np.zeros(8 * self.n, dtype=np.uint32)
+        self.positions = np.zeros(3 * self.n, dtype=np.float32)
+        self.rotations = np.zeros(4 * self.n, dtype=np.float32)
+        self.scales = np.zeros(3 * self.n, dtype=np.float32)
+        lib().orc_scene_build(_p(rows, u8p), self.n, _p(self.data, u32p), _p(self.positions, f32p),
+                              _p(self.rotations, f32p), _p(self.scales, f32p))
+
+    @staticmethod
+    def _d(v):
+        return np.ascontiguousarray(v, dtype=np.float64)
+
+    def translate(self, t):
+        t = self._d(t)
+        lib().orc_scene_translate(self.n, _p(self.data, u32p), _p(self.positions, f32p), t.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+
+    def rotate(self, q):
+        q = self._d(q)
+        lib().orc_scene_rotate(self.n, _p(self.data, u32p), _p(self.positions, f32p), _p(self.rotations, f32p), _p(self.scales, f32p),
+                               q.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+
+    def scale(self, s):
+        s = self._d(s)
+        lib().orc_scene_scale(self.n, _p(self.data, u32p), _p(self.positions, f32p), _p(self.rotations, f32p), _p(self.scales, f32p),
+                              s.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+
+    def limit_box(self, box):
+        box = self._d(box)
+        self.n = int(lib().orc_scene_limit_box(self.n, _p(self.data, u32p), _p(self.positions, f32p), _p(self.rotations, f32p),
+                                               _p(self.scales, f32p), box.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
+        self.data, self.positions = self.data[:8 * self.n].copy(), self.positions[:3 * self.n].copy()
+        self.rotations, self.scales = self.rotations[:4 * self.n].copy(), self.scales[:3 * self.n].copy()
 
 
 def float_to_half(x):

@@ -33,13 +33,17 @@ if (mode === "pack") {                     // pack <splat> <outprefix> <W> <H> <
     const s2 = new G.Scene();
     G.Loader.LoadSync(file, s2);
     s2.translate(new G.Vector3(0.25, -0.5, 1));
-    s2.rotate(G.Quaternion.FromEuler(new G.Vector3(0.1, 0.2, 0.3)));
+    const q = G.Quaternion.FromEuler(new G.Vector3(0.1, 0.2, 0.3));
+    s2.rotate(q);
     s2.scale(new G.Vector3(1.5, 1.5, 1.5));
     s2.limitBox(-4, 4, -4, 4, -4, 4);
     writeBin(out + ".xf.splat", s2.toSplatBytes());
     writeBin(out + ".xf.data.bin", s2.data);
+    writeBin(out + ".xf.pos.bin", s2.positions);
+    writeBin(out + ".xf.rot.bin", s2.rotations);
+    writeBin(out + ".xf.scl.bin", s2.scales);
     fs.writeFileSync(out + ".json", JSON.stringify({ events, vertexCount: scene.vertexCount, width: scene.width, height: scene.height,
-                                                     dataLength: scene.data.length, cams, xfCount: s2.vertexCount }));
+                                                     dataLength: scene.data.length, cams, xfCount: s2.vertexCount, q: q.flat() }));
 } else if (mode === "packsh") {             // packsh <splat> <shs.f32> <outprefix> <b0> <b1> <b2>
     const [file, shfile, out, b0, b1, b2] = a;
     const scene = new G.Scene();
@@ -81,6 +85,32 @@ if (mode === "pack") {                     // pack <splat> <outprefix> <W> <H> <
     const cam = orbitCamera(+pose, 120, +fx);
     for (let k = 0; k < +frames; k++) r.render(scene, cam);
     writeBin(out + ".rgba32f.bin", r.readPixelsFloat());
+    r.dispose();
+} else if (mode === "devscene") {         // devscene <splat> <outprefix>: device-side setData + transforms vs the JS Scene
+    const [file, out] = a;
+    const rows = new Uint8Array(fs.readFileSync(file));
+    const scene = new G.Scene();
+    scene.setData(rows);
+    const r = new G.WebGLRenderer({ width: 320, height: 240 }, []);
+    r.setSceneRows(rows);
+    const q = G.Quaternion.FromEuler(new G.Vector3(0.2, -0.4, 0.6));
+    const t = new G.Vector3(0.5, 0.25, -1), sc = new G.Vector3(1.25, 0.8, 1.1);
+    scene.translate(t); r.sceneTranslate(t);
+    scene.rotate(q); r.sceneRotate(q);
+    scene.scale(sc); r.sceneScale(sc);
+    scene.limitBox(-3, 3, -3, 3, -3, 3); r.sceneLimitBox(-3, 3, -3, 3, -3, 3);
+    const dev = r.readSceneData();
+    let same = dev.vertexCount === scene.vertexCount;
+    for (let i = 0; same && i < dev.vertexCount * 8; i++) same = dev.data[i] === scene.data[i];
+    for (let i = 0; same && i < dev.vertexCount * 3; i++) same = Object.is(dev.positions[i], scene.positions[i]);
+    const cam = orbitCamera(20, 120, 400);
+    r.renderDeviceScene(cam);
+    const a1 = r.readPixels();
+    r.render(scene, cam);
+    const a2 = r.readPixels();
+    let samePixels = a1.length === a2.length;
+    for (let i = 0; samePixels && i < a1.length; i++) samePixels = a1[i] === a2[i];
+    fs.writeFileSync(out + ".json", JSON.stringify({ same, samePixels, n: dev.vertexCount }));
     r.dispose();
 } else if (mode === "nodevice") {
     try {

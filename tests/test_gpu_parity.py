@@ -389,3 +389,48 @@ def test_stream_linked_rgba8_readout(gh, scenes):
     tot = r.bin_totals()
     assert tot.shape == (-(-cfg["height"] // 32), -(-cfg["width"] // 32)) and tot.sum() == r.stats()["bin_entries"]
     r.dispose()
+
+
+def test_on_device_scene_build_and_transforms(gh, oracle):
+    # Scene.setData / translate / rotate / scale / limitBox as kernels, bit-exact with the
+    # f64 restatement of the JavaScript (which tests/test_js_host.py pins against the JS implementation itself)
+    rows = gh.synth.synth_rows(50000, 61)
+    r2 = rows.reshape(-1, 32).copy()
+    r2[0, 28:32] = [255, 128, 128, 128]                                  # identity rotation
+    r2[1, 12:24] = np.array([200.0, 1e-9, 3.0], dtype=np.float32).view(np.uint8)   # halves overflow / underflow
+    rows = r2.reshape(-1)
+    st = oracle.SceneState(rows)
+    W, H = 640, 480
+    r = gh.HIPRenderer(W, H)
+    r.set_scene_rows(rows)
+
+    def same():
+        data, pos, rot, scl = r.read_scene()
+        assert np.array_equal(pos, st.positions) and np.array_equal(data, st.data)
+        assert np.array_equal(rot, st.rotations) and np.array_equal(scl, st.scales)
+
+    same()
+    q = gh.camera.quaternion_from_euler(0.3, -0.2, 0.1)
+    for op, arg in (("translate", [0.25, -0.5, 1.0]), ("rotate", q), ("scale", [1.5, 0.75, 1.25]), ("translate", [1e-3, 0, -2]),
+                    ("rotate", gh.camera.quaternion_from_euler(-1.0, 2.0, 0.5))):
+        getattr(st, op)(arg)
+        getattr(r, "scene_" + op)(arg)
+        same()
+    st.limit_box([-3, 3, -2.5, 4, -4, 1.5])
+    assert r.scene_limit_box([-3, 3, -2.5, 4, -4, 1.5]) == st.n and 0 < st.n < 50000
+    same()
+    with pytest.raises(gh.GsplatError, match="xMin"):
+        r.scene_limit_box([1, 1, 0, 1, 0, 1])
+    # and the transformed device scene renders like the oracle renders the transformed host scene
+    cam = gh.orbit_camera(12, width=W, height=H)
+    r.set_camera(cam)
+    r.render_async(); r.sync()
+    v, p, vp = cam.f32()
+    oimg, odi, V, D = oracle.render_scene(st.data, st.positions, v, p, vp, cam.fx, cam.fy, W, H, mode=1)
+    assert np.array_equal(r.lastDepthIndex(), odi)
+    assert np.abs(r.readPixelsFloat().astype(np.float64) - oimg).max() <= TOL_EXACT
+    # a scene uploaded as data/positions has no rotations/scales to transform
+    r.set_raw_scene(st.data, st.positions)
+    with pytest.raises(gh.GsplatError, match="gsr_set_scene_rows"):
+        r.scene_translate([1, 0, 0])
+    r.dispose()

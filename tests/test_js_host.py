@@ -55,12 +55,18 @@ def test_scene_and_camera_bits(tmp_path, oracle):
         assert cam.viewProj == cam_js["viewProj"]
         ref = gh.orbit_camera(cam_js["pose"])
         assert np.allclose(ref.viewProj, cam_js["viewProj"], rtol=0, atol=1e-12)
-    # transforms: re-serialised rows re-pack (through the oracle) to what the JS scene holds
-    xf = np.fromfile(out + ".xf.splat", dtype=np.uint8)
-    assert xf.size == meta["xfCount"] * 32 and 0 < meta["xfCount"] < 5000
-    xdata = np.fromfile(out + ".xf.data.bin", dtype=np.uint32).reshape(-1, 8)[:meta["xfCount"]]
-    odata = oracle.scene_pack(xf)[0].reshape(-1, 8)
-    assert np.array_equal(xdata[:, [0, 1, 2, 7]], odata[:, [0, 1, 2, 7]])       # positions and colours survive exactly
+    # transforms (Scene.ts:182-366) bit-exact against the oracle's f64 restatement, same order of operations
+    st = oracle.SceneState(rows)
+    st.translate([0.25, -0.5, 1.0])
+    st.rotate(meta["q"])                      # the quaternion JS computed (V8 trigonometry), passed through exactly
+    st.scale([1.5, 1.5, 1.5])
+    st.limit_box([-4, 4, -4, 4, -4, 4])
+    assert meta["xfCount"] == st.n and 0 < st.n < 5000
+    assert np.array_equal(np.fromfile(out + ".xf.pos.bin", dtype=np.float32), st.positions)
+    assert np.array_equal(np.fromfile(out + ".xf.rot.bin", dtype=np.float32), st.rotations)
+    assert np.array_equal(np.fromfile(out + ".xf.scl.bin", dtype=np.float32), st.scales)
+    assert np.array_equal(np.fromfile(out + ".xf.data.bin", dtype=np.uint32)[:8 * st.n], st.data)
+    assert np.fromfile(out + ".xf.splat", dtype=np.uint8).size == st.n * 32
 
 
 def test_js_scene_sh_packing(tmp_path, oracle):
@@ -145,3 +151,17 @@ def test_js_default_fade_in_pass(tmp_path, oracle):
     img = np.fromfile(out + ".rgba32f.bin", dtype=np.float32).reshape(cfg["height"], cfg["width"], 4)
     assert oimg[..., 3].max() > 0.05
     assert np.abs(img.astype(np.float64) - oimg).max() <= 2e-3   # pose trigonometry differs by an ulp between V8 and libm
+
+
+@pytest.mark.gpu
+def test_js_device_scene_matches_js_scene(tmp_path):
+    # device-side Scene.setData + translate/rotate/scale/limitBox (kernels) against the JavaScript Scene: identical words,
+    # identical pixels
+    import gsplat_hip as gh
+    rows = gh.synth.synth_rows(20000, 77)
+    f = tmp_path / "s.splat"
+    rows.tofile(f)
+    out = str(tmp_path / "d")
+    run("devscene", f, out)
+    meta = json.load(open(out + ".json"))
+    assert meta["same"] and meta["samePixels"] and 0 < meta["n"] < 20000
