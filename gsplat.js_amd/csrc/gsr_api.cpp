@@ -64,6 +64,7 @@ struct gsr_ctx {
     uint32_t *bin_table = nullptr, *bin_total = nullptr, *bin_start = nullptr, *bin_list = nullptr;
     uint32_t *seg_start = nullptr, *items = nullptr;
     uint2* blk_counts = nullptr;
+    uint32_t* bin_rects = nullptr;
     float4* partial = nullptr;
     uint32_t bin_blocks = 0, bin_capacity = 0, bin_table_elems = 0, bin_nbins_alloc = 0, blk_counts_alloc = 0;
     uint32_t max_items = 0, seg_len = 0;
@@ -242,7 +243,7 @@ int enqueue_frame(gsr_ctx* c, bool render)
         const BinGrid g = make_grid(c);
         const int nbins = (g.bx_hi - g.bx_lo) * g.nby;
         if (!c->n) HIP_TRY(c, hipMemsetAsync(c->bin_total, 0, sizeof(uint32_t) * nbins, s));
-        BinBuffers bb{c->depth_index, c->bbox, c->bin_table, c->blk_counts, c->bin_total, c->bin_start, c->seg_start,
+        BinBuffers bb{c->depth_index, c->bbox, c->bin_table, c->blk_counts, c->bin_rects, c->bin_total, c->bin_start, c->seg_start,
                       c->items, c->bin_list, &c->fstate->overflow, &c->fstate->visible, &c->fstate->tile_entries,
                       c->accum, c->bin_capacity, c->max_items, c->seg_len, c->bin_blocks};
         launch_bin(bb, g, c->n, s);
@@ -333,7 +334,7 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
     gsr_options o{};
     if (opt) o = *opt;
     if (o.device < 0 || o.device >= count) return fail(nullptr, GSR_ERR_ARG, "device %d out of range (%d visible)", o.device, count);
-    if (o.width < 0 || o.height < 0 || o.width > 65535 || o.height > 65535) return fail(nullptr, GSR_ERR_ARG, "bad framebuffer size %dx%d", o.width, o.height);
+    if (o.width < 0 || o.height < 0 || o.width > 8192 || o.height > 8192) return fail(nullptr, GSR_ERR_ARG, "bad framebuffer size %dx%d (up to 8192)", o.width, o.height);
     if (!(o.early_out_eps >= 0.0f && o.early_out_eps < 1.0f)) return fail(nullptr, GSR_ERR_ARG, "early_out_eps must be in [0,1)");
     gsr_ctx* c = new gsr_ctx();
     c->device = o.device;
@@ -390,7 +391,7 @@ int gsr_destroy(gsr_ctx* c)
     dev_free(&c->depth); dev_free(&c->keys); dev_free(&c->keys_tmp); dev_free(&c->idx_tmp); dev_free(&c->depth_index);
     dev_free(&c->block_hist); dev_free(&c->rec); dev_free(&c->bbox);
     dev_free(&c->bin_table); dev_free(&c->bin_total); dev_free(&c->bin_start); dev_free(&c->bin_list);
-    dev_free(&c->seg_start); dev_free(&c->items); dev_free(&c->blk_counts); dev_free(&c->partial);
+    dev_free(&c->seg_start); dev_free(&c->items); dev_free(&c->blk_counts); dev_free(&c->partial); dev_free(&c->bin_rects);
     dev_free(&c->fstate); dev_free(&c->fstate_init); dev_free(&c->accum); dev_free(&c->fb); dev_free(&c->fb8);
     if (c->fstate_host) (void)hipHostFree(c->fstate_host);
     for (auto& set : c->evring)
@@ -416,7 +417,8 @@ int alloc_scene(gsr_ctx* c, uint32_t n, bool with_rows)
         (r = dev_alloc(c, &c->cov0, n)) || (r = dev_alloc(c, &c->cov1, n)) || (r = dev_alloc(c, &c->cov2, n)) ||
         (r = dev_alloc(c, &c->rgba, n)) || (r = dev_alloc(c, &c->depth, n)) || (r = dev_alloc(c, &c->keys, n)) ||
         (r = dev_alloc(c, &c->keys_tmp, n)) || (r = dev_alloc(c, &c->idx_tmp, n)) ||
-        (r = dev_alloc(c, &c->depth_index, n)) || (r = dev_alloc(c, &c->rec, n)) || (r = dev_alloc(c, &c->bbox, n)))
+        (r = dev_alloc(c, &c->depth_index, n)) || (r = dev_alloc(c, &c->rec, n)) || (r = dev_alloc(c, &c->bbox, n)) ||
+        (r = dev_alloc(c, &c->bin_rects, n)))
         return r;
     if (with_rows && ((r = dev_alloc(c, &c->rotv, n)) || (r = dev_alloc(c, &c->sclv, n)))) return r;
     c->sort_kpb = 2048;
@@ -626,7 +628,7 @@ int gsr_set_scene_sh(gsr_ctx* c, const uint32_t* sh_r, const uint32_t* sh_g, con
 int gsr_resize(gsr_ctx* c, int32_t w, int32_t h)
 {
     if (!c) return GSR_ERR_ARG;
-    if (w <= 0 || h <= 0 || w > 65535 || h > 65535) return fail(c, GSR_ERR_ARG, "bad framebuffer size %dx%d", w, h);
+    if (w <= 0 || h <= 0 || w > 8192 || h > 8192) return fail(c, GSR_ERR_ARG, "bad framebuffer size %dx%d (1..8192)", w, h);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->W = w; c->H = h;

@@ -99,6 +99,7 @@ struct BinBuffers {
     const uint2* bbox;           // n
     uint32_t* table;             // nblocks * nbins  (counts, then per-workgroup offsets inside each bin)
     uint2* blk_counts;           // nblocks: (visible splats, 16x16 tile overlaps) per counting workgroup
+    uint32_t* rects;             // n: packed bin rectangle of every rank (count pass -> scatter pass)
     uint32_t* bin_total;         // nbins (zeroed by the caller when n == 0)
     uint32_t* bin_start;         // nbins + 1
     uint32_t* seg_start;         // nbins + 1: first compositor work item of each bin; [nbins] = item count

@@ -39,6 +39,20 @@ __device__ __forceinline__ BinRect bin_rect(uint2 bb, const BinGrid& g)
     return r;
 }
 
+// bin rectangle of one rank in 4 bytes (x0 | x1<<8 | y0<<16 | y1<<24; bins per axis <= 256): the count pass
+// gathers the boxes once and leaves the rectangles in rank order, the scatter pass reads them coalesced
+__device__ __forceinline__ uint32_t pack_rect(const BinRect& r)
+{
+    return (r.x0 <= r.x1) ? ((uint32_t)r.x0 | ((uint32_t)r.x1 << 8) | ((uint32_t)r.y0 << 16) | ((uint32_t)r.y1 << 24)) : 1u;
+}
+__device__ __forceinline__ BinRect unpack_rect(uint32_t p)
+{
+    BinRect r;
+    r.x0 = (int)(p & 0xffu); r.x1 = (int)((p >> 8) & 0xffu); r.y0 = (int)((p >> 16) & 0xffu); r.y1 = (int)(p >> 24);
+    if (r.x0 > r.x1) { r.y0 = 1; r.y1 = 0; }
+    return r;
+}
+
 __device__ __forceinline__ uint32_t lanes_below64(uint64_t mask)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -55,7 +69,8 @@ constexpr int CNT_STEPS = (int)BIN_RANKS_PER_BLOCK / CNT_THREADS;  // 2
 
 __global__ __launch_bounds__(CNT_THREADS) void k_bin_count(const uint32_t* __restrict__ depth_index,
                                                            const uint2* __restrict__ bbox, uint32_t n, BinGrid g,
-                                                           uint32_t* __restrict__ table, uint2* __restrict__ blk_counts)
+                                                           uint32_t* __restrict__ table, uint2* __restrict__ blk_counts,
+                                                           uint32_t* __restrict__ rects)
 {
     extern __shared__ uint32_t s_cnt[];  // nbins
     __shared__ uint32_t s_red[2 * (CNT_THREADS / WAVE)];
@@ -78,6 +93,10 @@ __global__ __launch_bounds__(CNT_THREADS) void k_bin_count(const uint32_t* __res
     for (int st = 0; st < CNT_STEPS; st++) {
         const uint2 bb = bbs[st];
         const BinRect br = bin_rect(bb, g);
+        {
+            const uint32_t r = begin + st * CNT_THREADS + threadIdx.x;
+            if (r < n) rects[r] = pack_rect(br);
+        }
         if (br.x0 <= br.x1) {
             vis++;
             const int tx0 = max((int)(bb.x & 0xffff) / TILE, g.bx_lo * BIN_TILES);
@@ -244,7 +263,7 @@ constexpr int SCAT_STEPS_PER_WAVE = BIN_STEPS / SCAT_WAVES_PER_GROUP;  // 2
 static_assert(SCAT_GROUPS * BIN_STEPS * WAVE == (int)BIN_RANKS_PER_BLOCK, "scatter and count must cut the ranks alike");
 
 __global__ __launch_bounds__(SCAT_THREADS) void k_bin_scatter(const uint32_t* __restrict__ depth_index,
-                                                              const uint2* __restrict__ bbox, uint32_t n, BinGrid g,
+                                                              const uint32_t* __restrict__ rects, uint32_t n, BinGrid g,
                                                               const uint32_t* __restrict__ table,
                                                               const uint32_t* __restrict__ bin_start,
                                                               uint32_t* __restrict__ list, uint32_t capacity,
@@ -280,8 +299,8 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_bin_scatter(const uint32_t* __
     }
 #pragma unroll
     for (int k = 0; k < SCAT_STEPS_PER_WAVE; k++) {
-        if (idx[k] != 0xffffffffu) br[k] = bin_rect(bbox[idx[k]], g);
-        else { br[k].x0 = 1; br[k].x1 = 0; br[k].y0 = 1; br[k].y1 = 0; }
+        const uint32_t r = gbegin + (sub * SCAT_STEPS_PER_WAVE + k) * WAVE + lane;
+        br[k] = unpack_rect((r < n) ? rects[r] : 1u);
     }
     // phase 1: per-group counts, and every lane ORs its bit into the column/row lane sets of its box
     const uint32_t one = 1u << myshift;
@@ -335,18 +354,17 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
     if (nbins <= 0) return;
     const dim3 grid(b.nblocks), block(BIN_THREADS);
     const size_t lds = (size_t)((3 * nbins + 1) & ~1) * 4 + (size_t)SCAT_GROUPS * BIN_STEPS * (nbxb + g.nby) * 8;
-    // dynamic LDS above the 64 KiB default needs the attribute raised (4K: 8160 bins -> 130 KiB)
-    static size_t lds_allowed = 64 * 1024;
-    if (lds > lds_allowed) {
+    // dynamic LDS above the 64 KiB default needs the attribute raised (4K: 8160 bins -> ~146 KiB).  Set per call:
+    // the attribute belongs to the current device's copy of the kernel, and this is off the per-frame fast path
+    // (1080p needs 49 KiB).
+    if (lds > 60 * 1024) {
         const int want = (int)std::min<size_t>(lds + 1024, 160 * 1024 - 256);
-        if (hipFuncSetAttribute((const void*)k_bin_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_bin_count, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)k_bin_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess)
             (void)hipGetLastError();  // the launch below then reports the real failure
-        lds_allowed = (size_t)want;
     }
     if (n) {
         hipLaunchKernelGGL(k_bin_count, grid, dim3(CNT_THREADS), nbins * sizeof(uint32_t), s, b.depth_index, b.bbox, n, g, b.table,
-                           b.blk_counts);
+                           b.blk_counts, b.rects);
         hipLaunchKernelGGL(k_bin_scan, dim3((nbins + BIN_WAVES - 1) / BIN_WAVES), block, 0, s, b.table, b.bin_total, nbins,
                            b.nblocks);
     }
@@ -354,7 +372,7 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
                        b.max_items, b.capacity, (const uint2*)b.blk_counts, n ? b.nblocks : 0u, b.bin_start, b.seg_start, b.items,
                        b.overflow, b.visible, b.tile_entries, b.accum);
     if (n)
-        hipLaunchKernelGGL(k_bin_scatter, grid, dim3(SCAT_THREADS), lds, s, b.depth_index, b.bbox, n, g, (const uint32_t*)b.table,
+        hipLaunchKernelGGL(k_bin_scatter, grid, dim3(SCAT_THREADS), lds, s, b.depth_index, (const uint32_t*)b.rects, n, g, (const uint32_t*)b.table,
                            (const uint32_t*)b.bin_start, b.list, b.capacity, b.overflow);
 }
 
