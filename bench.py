@@ -175,7 +175,7 @@ def main():
 
     st = r.stats()
     frames = max(int(st["frames"]), 1)
-    ms = {k: st["sum_ms_" + k] / frames for k in ("project_key", "sort", "bin", "blend", "total")}
+    ms = {k: st["sum_ms_" + k] / frames for k in ("project_key", "sort", "bin", "blend", "combine", "total")}
     sf = max(int(st["sum_frames"]), 1)
     V, D, E = st["sum_visible"] / sf, st["sum_tile_entries"] / sf, st["sum_bin_entries"] / sf
     band_px = ((x1 - x0) if world > 1 else W) * H
@@ -190,13 +190,15 @@ def main():
         b_sort = 52.0 * N
         b_proj = 16.0 * N + 48.0 * V
         b_bin = 8.0 * D
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "blend_traffic.json")
+        traffic = valu = None
+        tpath = os.path.join(ROOT, "profiles", "blend_traffic.json")   # committed PMC measurement (scripts/gpu_pmc.sh)
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("hbm_bytes_per_launch")
+                valu = tj.get("valu_wave_instructions_per_launch")
             except Exception:
-                traffic = None
+                traffic = valu = None
         ach = b_blend / (ms["blend"] * 1e-3) / 1e9 if ms["blend"] > 0 else 0.0
         out = {
             "metric": "frames_per_sec", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -213,7 +215,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_blend", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_blend, "avg_launch_ms": ms["blend"],
-                         "note": "the compositor is VALU/LDS-bound, not HBM-bound (SURVEY 8(d) honest note)"},
+                         "note": "the compositor is VALU-bound, not HBM-bound (SURVEY 8(d) honest note); see valu"},
+            # secondary ceiling: VALU issue. peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction
+            # (tools/valu_peak.hip measures 0.96e12 v_fma_f32 wave-instr/s; v_exp_f32 is 3.3x slower)
+            "valu": None if not valu or not ms["blend"] else {
+                "wave_instr_per_launch": valu, "achieved_wave_instr_per_s": valu / (ms["blend"] * 1e-3),
+                "peak_wave_instr_per_s": 1024 * 2.4e9 / 2, "frac": valu / (ms["blend"] * 1e-3) / (1024 * 2.4e9 / 2)},
             "stage_roofline": {
                 "sort": {"bytes": b_sort, "ms": ms["sort"], "GBps": b_sort / (ms["sort"] * 1e-3) / 1e9 if ms["sort"] else 0,
                          "frac": b_sort / (ms["sort"] * 1e-3) / 1e9 / HBM_PEAK_GBS if ms["sort"] else 0},

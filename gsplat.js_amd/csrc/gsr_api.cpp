@@ -20,7 +20,7 @@ namespace {
 
 thread_local std::string g_create_error;
 
-enum Stage { EV_BEGIN = 0, EV_PROJECT, EV_SORT, EV_BIN, EV_BLEND, EV_COUNT };
+enum Stage { EV_BEGIN = 0, EV_PROJECT, EV_SORT, EV_BIN, EV_BLEND /* after k_blend */, EV_COMBINE /* after k_combine */, EV_COUNT };
 
 struct FrameState {  // small per-frame device words, (re)initialised by one memcpy per frame
     int32_t minmax[2];
@@ -251,8 +251,8 @@ int enqueue_frame(gsr_ctx* c, bool render)
         BlendBuffers bl{c->items, c->seg_start, c->bin_start, c->bin_list, c->rec, c->bbox, c->shcol, c->fb, c->partial,
                         &c->fstate->queue, c->seg_len, std::min<uint32_t>(c->max_items, getenv("GSR_BLEND_GRID") ? (uint32_t)atol(getenv("GSR_BLEND_GRID")) : 2048u), c->bin_capacity,
                         std::max(c->n, 1u)};
-        launch_blend(bl, g, c->opt.early_out_eps, s);
-        if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BLEND], s));
+        launch_blend(bl, g, c->opt.early_out_eps, s, timing ? c->ev[EV_BLEND] : nullptr);
+        if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_COMBINE], s));
     }
     HIP_TRY(c, hipGetLastError());
     if (timing) c->ev_pending++;
@@ -269,17 +269,18 @@ int finish_frame(gsr_ctx* c)
     while (c->ev_pending > 0) {
         hipEvent_t* ev = c->evring[c->ev_head];
         const bool render = c->ev_is_render[c->ev_head];
-        float a = 0, b = 0, d = 0, e = 0, t = 0;
+        float a = 0, b = 0, d = 0, e = 0, f = 0, t = 0;
         HIP_TRY(c, hipEventElapsedTime(&a, ev[EV_BEGIN], ev[EV_PROJECT]));
         HIP_TRY(c, hipEventElapsedTime(&b, ev[EV_PROJECT], ev[EV_SORT]));
         t = a + b;
         if (render) {
             HIP_TRY(c, hipEventElapsedTime(&d, ev[EV_SORT], ev[EV_BIN]));
             HIP_TRY(c, hipEventElapsedTime(&e, ev[EV_BIN], ev[EV_BLEND]));
-            HIP_TRY(c, hipEventElapsedTime(&t, ev[EV_BEGIN], ev[EV_BLEND]));
+            HIP_TRY(c, hipEventElapsedTime(&f, ev[EV_BLEND], ev[EV_COMBINE]));
+            HIP_TRY(c, hipEventElapsedTime(&t, ev[EV_BEGIN], ev[EV_COMBINE]));
         }
-        c->tm.ms_project_key = a; c->tm.ms_sort = b; c->tm.ms_bin = d; c->tm.ms_blend = e; c->tm.ms_total = t;
-        c->tm.sum_ms_project_key += a; c->tm.sum_ms_sort += b; c->tm.sum_ms_bin += d; c->tm.sum_ms_blend += e;
+        c->tm.ms_project_key = a; c->tm.ms_sort = b; c->tm.ms_bin = d; c->tm.ms_blend = e; c->tm.ms_combine = f; c->tm.ms_total = t;
+        c->tm.sum_ms_project_key += a; c->tm.sum_ms_sort += b; c->tm.sum_ms_bin += d; c->tm.sum_ms_blend += e; c->tm.sum_ms_combine += f;
         c->tm.sum_ms_total += t;
         c->tm.frames++;
         c->ev_head = (c->ev_head + 1) % gsr_ctx::EV_RING;

@@ -132,7 +132,8 @@ struct BlendBuffers {
     uint32_t capacity;          // entries the list can hold
     uint32_t nsplats;
 };
-void launch_blend(const BlendBuffers& b, const BinGrid& g, float early_out_eps, hipStream_t s);
+// `between` (may be null) is recorded after k_blend and before k_combine
+void launch_blend(const BlendBuffers& b, const BinGrid& g, float early_out_eps, hipStream_t s, hipEvent_t between);
 void launch_clear_fb(float4* fb, int32_t W, int32_t H, hipStream_t s);
 void launch_to_rgba8(const float4* fb, uint32_t* out, uint32_t npix, hipStream_t s);
 

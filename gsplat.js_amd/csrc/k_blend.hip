@@ -242,12 +242,13 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_combine(const uint32_t* __res
     }
 }
 
-void launch_blend(const BlendBuffers& b, const BinGrid& g, float early_out_eps, hipStream_t s)
+void launch_blend(const BlendBuffers& b, const BinGrid& g, float early_out_eps, hipStream_t s, hipEvent_t between)
 {
     const int nbins = (g.bx_hi - g.bx_lo) * g.nby;
     if (nbins <= 0) return;
     hipLaunchKernelGGL(k_blend, dim3(b.grid), dim3(BLEND_THREADS), 0, s, b.items, b.seg_start, b.bin_start, b.list, b.rec,
                        b.shcol, b.fb, b.partial, b.queue, g, early_out_eps, b.seg_len, b.capacity, b.nsplats);
+    if (between) (void)hipEventRecord(between, s);
     if (b.seg_len < 0x40000000u)
         hipLaunchKernelGGL(k_combine, dim3(nbins), dim3(BLEND_THREADS), 0, s, b.seg_start, (const float4*)b.partial, b.fb, g);
 }

@@ -91,7 +91,7 @@ export interface HIPRendererOptions {
     timing?: boolean;
 }
 export interface FrameStats {
-    msProjectKey: number; msSort: number; msBin: number; msBlend: number; msTotal: number;
+    msProjectKey: number; msSort: number; msBin: number; msBlend: number; msCombine: number; msTotal: number;
     visible: number; binEntries: number; tileEntries: number; n: number; frames: number;
 }
 export class HIPRenderer {

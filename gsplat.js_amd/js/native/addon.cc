@@ -354,11 +354,11 @@ napi_value GetTimings(napi_env env, napi_callback_info info)
         napi_create_double(env, v, &n);
         napi_set_named_property(env, o, k, n);
     };
-    put("msProjectKey", t.ms_project_key); put("msSort", t.ms_sort); put("msBin", t.ms_bin); put("msBlend", t.ms_blend);
+    put("msProjectKey", t.ms_project_key); put("msSort", t.ms_sort); put("msBin", t.ms_bin); put("msBlend", t.ms_blend); put("msCombine", t.ms_combine);
     put("msTotal", t.ms_total); put("visible", (double)t.visible); put("binEntries", (double)t.bin_entries);
     put("tileEntries", (double)t.tile_entries); put("n", t.n); put("frames", t.frames);
     put("sumMsProjectKey", t.sum_ms_project_key); put("sumMsSort", t.sum_ms_sort); put("sumMsBin", t.sum_ms_bin);
-    put("sumMsBlend", t.sum_ms_blend); put("sumMsTotal", t.sum_ms_total);
+    put("sumMsBlend", t.sum_ms_blend); put("sumMsCombine", t.sum_ms_combine); put("sumMsTotal", t.sum_ms_total);
     return o;
 }
 

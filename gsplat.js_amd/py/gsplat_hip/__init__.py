@@ -30,10 +30,11 @@ class GsrOptions(ctypes.Structure):
 
 class GsrTimings(ctypes.Structure):
     _fields_ = [("ms_project_key", ctypes.c_float), ("ms_sort", ctypes.c_float), ("ms_bin", ctypes.c_float),
-                ("ms_blend", ctypes.c_float), ("ms_total", ctypes.c_float), ("visible", ctypes.c_uint64),
+                ("ms_blend", ctypes.c_float), ("ms_combine", ctypes.c_float), ("ms_total", ctypes.c_float), ("visible", ctypes.c_uint64),
                 ("bin_entries", ctypes.c_uint64), ("tile_entries", ctypes.c_uint64), ("n", ctypes.c_uint32), ("frames", ctypes.c_uint32),
                 ("sum_ms_project_key", ctypes.c_double), ("sum_ms_sort", ctypes.c_double),
-                ("sum_ms_bin", ctypes.c_double), ("sum_ms_blend", ctypes.c_double), ("sum_ms_total", ctypes.c_double),
+                ("sum_ms_bin", ctypes.c_double), ("sum_ms_blend", ctypes.c_double), ("sum_ms_combine", ctypes.c_double),
+                ("sum_ms_total", ctypes.c_double),
                 ("sum_visible", ctypes.c_uint64), ("sum_bin_entries", ctypes.c_uint64),
                 ("sum_tile_entries", ctypes.c_uint64), ("sum_frames", ctypes.c_uint64)]
 

@@ -65,14 +65,15 @@ typedef struct gsr_timings {
     float ms_project_key; /* projection + depth key + min/max            */
     float ms_sort;        /* quantise + 2 radix passes -> depthIndex      */
     float ms_bin;         /* coarse bin count/scan/scatter                */
-    float ms_blend;       /* tile composite (the dominant kernel)         */
+    float ms_blend;       /* k_blend alone: tile composite, the dominant kernel */
+    float ms_combine;     /* k_combine: fold of the per-segment partials  */
     float ms_total;       /* first event -> last event                    */
     uint64_t visible;     /* V: splats with a non-empty screen bbox (within the band) */
     uint64_t bin_entries; /* entries in the coarse (32x32 px) bin lists   */
     uint64_t tile_entries;/* D: sum over visible splats of 16x16 tiles their bbox overlaps */
     uint32_t n;           /* splats                                       */
     uint32_t frames;      /* frames accumulated in the sums below         */
-    double sum_ms_project_key, sum_ms_sort, sum_ms_bin, sum_ms_blend, sum_ms_total;
+    double sum_ms_project_key, sum_ms_sort, sum_ms_bin, sum_ms_blend, sum_ms_combine, sum_ms_total;
     /* device-side sums over every frame rendered since gsr_reset_timings (valid after gsr_sync) */
     uint64_t sum_visible, sum_bin_entries, sum_tile_entries, sum_frames;
 } gsr_timings;
