@@ -150,7 +150,9 @@ def main():
                 r.convert_rgba8_async()
             link.torch_waits_for_renderer()
             xchg.exchange(fb)
-            link.renderer_waits_for_torch()
+            # the next frame may start as soon as this band has left the framebuffer: the all-gather and the
+            # assembly on torch's side overlap the next frame's projection, sort, binning and compositing
+            link.renderer_waits_for_event(xchg.copied)
 
     def fence():
         r.sync()

@@ -84,6 +84,11 @@ class StreamLink:
     def renderer_waits_for_torch(self):
         self.ext.wait_stream(self.torch.cuda.current_stream())
 
+    def renderer_waits_for_event(self, event):
+        """Narrower than renderer_waits_for_torch: the renderer's stream waits only for `event` (e.g. "my band has been
+        copied out of the framebuffer"), so the collective that follows on torch's side overlaps the next frame."""
+        self.ext.wait_event(event)
+
 
 class FrameExchange:
     """all-gather of per-rank band slabs into every rank's full frame."""
@@ -98,12 +103,16 @@ class FrameExchange:
         self._flat = torch.empty((world * height, sw, channels), dtype=dtype, device=device)
         self.gathered = self._flat.view(world, height, sw, channels)
         self.full = torch.empty((height, width, channels), dtype=dtype, device=device)
+        # recorded on the current stream right after the band has been copied into the slab (device tensors only)
+        self.copied = torch.cuda.Event() if str(device).startswith("cuda") else None
 
     def exchange(self, fb):
         """fb: [H, W, C] tensor whose columns edges[rank] hold this rank's band. Returns the full frame."""
         x0, x1 = self.edges[self.rank]
         if x1 > x0:
             self.slab[:, :x1 - x0].copy_(fb[:, x0:x1])
+        if self.copied is not None:
+            self.copied.record()        # from here on the producer may overwrite fb
         self.dist.all_gather_into_tensor(self._flat, self.slab)
         for q, (a, b) in enumerate(self.edges):
             if b > a:

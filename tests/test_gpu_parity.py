@@ -380,6 +380,8 @@ def test_stream_linked_rgba8_readout(gh, scenes):
         r.convert_rgba8_async()
         link.torch_waits_for_renderer()
         outs.append(fb8.clone())            # on torch's stream, ordered after the conversion
+        ev = torch.cuda.Event(); ev.record()
+        link.renderer_waits_for_event(ev)   # the next frame may overwrite fb8 only after the clone
     torch.cuda.synchronize()
     r.sync()
     assert np.array_equal(outs[1].cpu().numpy(), r.readPixels())
