@@ -127,6 +127,14 @@ export class Loader {
     static LoadFromFileAsync(file: string, scene: Scene, onProgress?: (p: number) => void): Promise<Scene>;
     static LoadSync(file: string, scene: Scene): Scene;
 }
+export class PLYLoader {
+    /** format: "" | "polycam"; useShs: also read the 45 f_rest_* floats; quantized PLY is not supported */
+    static LoadAsync(file: string, scene: Scene, onProgress?: (p: number, done?: boolean) => void, format?: string,
+                     useShs?: boolean, quantized?: boolean): Promise<Scene>;
+    static LoadFromFileAsync(file: string, scene: Scene, onProgress?: (p: number, done?: boolean) => void, format?: string,
+                             useShs?: boolean, quantized?: boolean): Promise<Scene>;
+    static LoadFromBytes(bytes: Uint8Array, scene: Scene, format?: string, useShs?: boolean, quantized?: boolean): Scene;
+}
 export class OrbitControls {
     minAngle: number; maxAngle: number; minZoom: number; maxZoom: number;
     orbitSpeed: number; panSpeed: number; zoomSpeed: number; dampening: number;

@@ -1,11 +1,12 @@
 "use strict";
 // Public API: the export list of src/index.ts:1-12.  WebGLRenderer is the HIP renderer under the name callers of
-// the reference already use.  (PLYLoader is outside the hot-path scope: SURVEY.md section 2, #14.)
+// the reference already use.
 const { HIPRenderer, sortHost } = require("./renderers/HIPRenderer");
 module.exports = {
     Camera: require("./cameras/Camera").Camera,
     Scene: require("./core/Scene").Scene,
     Loader: require("./loaders/Loader").Loader,
+    PLYLoader: require("./loaders/PLYLoader").PLYLoader,
     WebGLRenderer: HIPRenderer,
     HIPRenderer: HIPRenderer,
     OrbitControls: require("./controls/OrbitControls").OrbitControls,

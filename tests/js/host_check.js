@@ -112,6 +112,25 @@ if (mode === "pack") {                     // pack <splat> <outprefix> <W> <H> <
     for (let i = 0; samePixels && i < a1.length; i++) samePixels = a1[i] === a2[i];
     fs.writeFileSync(out + ".json", JSON.stringify({ same, samePixels, n: dev.vertexCount }));
     r.dispose();
+} else if (mode === "ply") {              // ply <file.ply> <outprefix>
+    const [file, out] = a;
+    const bytes = new Uint8Array(fs.readFileSync(file));
+    const dump = (tag, fmt, useShs) => {
+        const scene = new G.Scene();
+        G.PLYLoader.LoadFromBytes(bytes, scene, fmt, useShs);
+        writeBin(out + "." + tag + ".splat", scene.toSplatBytes());
+        writeBin(out + "." + tag + ".data.bin", scene.data);
+        if (useShs) for (let c = 0; c < 3; c++) writeBin(out + "." + tag + ".sh" + c + ".bin", scene.shs_rgb[c]);
+        return scene.vertexCount;
+    };
+    const n = dump("plain", "", false);
+    dump("polycam", "polycam", false);
+    dump("full", "", true);
+    let refused = false;
+    try { G.PLYLoader.LoadFromBytes(bytes, new G.Scene(), "", true, true); } catch (e) { refused = true; }
+    let badMagic = false;
+    try { G.PLYLoader.LoadFromBytes(new Uint8Array(64), new G.Scene()); } catch (e) { badMagic = /Invalid PLY/.test(e.message); }
+    fs.writeFileSync(out + ".json", JSON.stringify({ n, refused, badMagic }));
 } else if (mode === "nodevice") {
     try {
         new G.HIPRenderer({ width: 64, height: 64 });

@@ -87,6 +87,40 @@ def test_js_scene_sh_packing(tmp_path, oracle):
         assert np.array_equal(got[:want[c].size], want[c]) and not got[want[c].size:].any()
 
 
+def test_js_ply_loader(tmp_path, oracle):
+    # INRIA .ply -> .splat rows (+ SH floats), against a numpy restatement of PLYLoader.ts
+    from oracle import ply_oracle as P
+    n = 3000
+    ply = P.synth_ply(n, 17)
+    f = tmp_path / "s.ply"
+    f.write_bytes(ply)
+    out = str(tmp_path / "p")
+    run("ply", f, out)
+    meta = json.load(open(out + ".json"))
+    assert meta == {"n": n, "refused": True, "badMagic": True}
+
+    def check_rows(tag, want):
+        got = np.fromfile(out + "." + tag + ".splat", dtype=np.uint8).reshape(n, 32)
+        want = want.reshape(n, 32)
+        assert np.array_equal(got[:, 0:12], want[:, 0:12])                                    # positions
+        gs, ws = got[:, 12:24].copy().view(np.float32), want[:, 12:24].copy().view(np.float32)
+        assert np.all(np.abs(gs - ws) <= np.spacing(ws))                                      # exp: V8 vs libm, <= 1 ulp
+        assert np.array_equal(got[:, 24:27], want[:, 24:27])                                  # colour bytes
+        assert np.abs(got[:, 27].astype(int) - want[:, 27].astype(int)).max() <= 1            # sigmoid byte
+        assert np.abs(got[:, 28:32].astype(int) - want[:, 28:32].astype(int)).max() <= 1      # rotation bytes
+        assert (got[:, 28:32] == want[:, 28:32]).mean() > 0.99
+
+    check_rows("plain", P.rows_from_ply(ply))
+    check_rows("polycam", P.rows_from_ply(ply, "polycam"))
+    rows_full, sh = P.rows_and_sh_from_ply(ply)
+    check_rows("full", rows_full)
+    want_sh = oracle.scene_pack_sh(sh)          # bandsIndices (-1,-1,-1): every splat carries degree-3 SH
+    for c in range(3):
+        got = np.fromfile(out + ".full.sh%d.bin" % c, dtype=np.uint32)
+        assert np.array_equal(got[:want_sh[c].size], want_sh[c])
+    assert not np.array_equal(rows_full.reshape(n, 32)[:, 24:27], P.rows_from_ply(ply).reshape(n, 32)[:, 24:27])   # the precedence oddity is real
+
+
 def test_js_renderer_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
