@@ -5,7 +5,10 @@
   python bench.py --gpus N --steps K --warmup W        (N=1: plain process; N>1: torch.distributed.run)
 
 A step is one full frame (renderer.render(scene, camera)) at the next pose of a
-120-frame orbit.  Workload at every N: BASELINE.json configs[2] = C3, 1M synthetic
+120-frame orbit.  Frames are independent, so up to --frames-in-flight (default 3) of
+them are in flight on separate contexts/streams: the latency-bound sort/binning
+kernels of one frame fill the GPU while another frame composites.  Every one of the
+K timed frames is rendered completely inside the timed region.  Workload at every N: BASELINE.json configs[2] = C3, 1M synthetic
 gaussians at 1920x1080 (scene bytes resident in HBM before the timed region).
 N>1 splits ONE frame across ranks by screen-tile columns and all-gathers the
 framebuffer over RCCL: fixed total work, so `scaling` is "strong".
@@ -78,6 +81,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", choices=("rgba8", "f32"), default="rgba8",
                     help="N>1: framebuffer slab format of the per-frame all-gather (rgba8: what a display consumes)")
+    ap.add_argument("--frames-in-flight", type=int, default=3,
+                    help="independent frames rendered concurrently on separate contexts/streams (frame k uses context k mod F)")
     ap.add_argument("--equal-bands", action="store_true", help="N>1: equal-width bands instead of cost-balanced ones")
     args = ap.parse_args()
 
@@ -123,39 +128,47 @@ def main():
     if world > 1 and x1 <= x0:
         raise SystemExit("rank %d has an empty band (more ranks than 32-px bin columns)" % rank)
     band = (x0, x1) if world > 1 else None
-    r = gh.HIPRenderer(W, H, device=local_rank, early_out_eps=args.early_out_eps, band=band, timing=True)
-    r.render(scene, gh.orbit_camera(0, ORBIT_FRAMES, W, H, cfg["fx"]))  # uploads the scene, first frame
+    F = max(1, args.frames_in_flight)
+    rs = []
+    for _ in range(F):   # every context owns its buffers and its stream; frames are independent of each other
+        rr = gh.HIPRenderer(W, H, device=local_rank, early_out_eps=args.early_out_eps, band=band, timing=True)
+        rr.render(scene, gh.orbit_camera(0, ORBIT_FRAMES, W, H, cfg["fx"]))  # uploads the scene, first frame
+        rs.append(rr)
+    r = rs[0]
 
-    fb = xchg = link = None
+    fbs = links = xchg = None
     if world > 1:
         dev = "cuda:%d" % local_rank
         if args.exchange == "rgba8":
-            fb = bands.framebuffer8_tensor(torch, r, dev)
-            xchg = bands.FrameExchange(dist, torch, W, H, rank, world, fb.device, edges=edges, dtype=torch.uint8)
+            fbs = [bands.framebuffer8_tensor(torch, rr, dev) for rr in rs]
+            xchg = bands.FrameExchange(dist, torch, W, H, rank, world, fbs[0].device, edges=edges, dtype=torch.uint8)
         else:
-            fb = bands.framebuffer_tensor(torch, r, dev)
-            xchg = bands.FrameExchange(dist, torch, W, H, rank, world, fb.device, edges=edges)
-        link = bands.StreamLink(torch, r, dev)
+            fbs = [bands.framebuffer_tensor(torch, rr, dev) for rr in rs]
+            xchg = bands.FrameExchange(dist, torch, W, H, rank, world, fbs[0].device, edges=edges)
+        links = [bands.StreamLink(torch, rr, dev) for rr in rs]
 
     # Camera.update for the 120 poses is host JS/Python f64 work outside the device path: precomputed
     poses = [gh.orbit_camera(k, ORBIT_FRAMES, W, H, cfg["fx"]).f32() for k in range(ORBIT_FRAMES)]
 
     def step(k):
         v, p, vp = poses[k % ORBIT_FRAMES]
-        r.set_camera_arrays(v, p, vp, cfg["fx"], cfg["fx"])
-        r.render_async()
+        c = k % F
+        rr = rs[c]
+        rr.set_camera_arrays(v, p, vp, cfg["fx"], cfg["fx"])
+        rr.render_async()
         if world > 1:
             # device-side ordering only: torch's stream waits for the frame, the next frame waits for the slab copy
             if args.exchange == "rgba8":
-                r.convert_rgba8_async()
-            link.torch_waits_for_renderer()
-            xchg.exchange(fb)
-            # the next frame may start as soon as this band has left the framebuffer: the all-gather and the
-            # assembly on torch's side overlap the next frame's projection, sort, binning and compositing
-            link.renderer_waits_for_event(xchg.copied)
+                rr.convert_rgba8_async()
+            links[c].torch_waits_for_renderer()
+            xchg.exchange(fbs[c])
+            # this context's next frame may start as soon as this band has left the framebuffer: the all-gather and
+            # the assembly on torch's side overlap the following frames' projection, sort, binning and compositing
+            links[c].renderer_waits_for_event(xchg.copied)
 
     def fence():
-        r.sync()
+        for rr in rs:
+            rr.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -164,7 +177,8 @@ def main():
     for k in range(args.warmup):
         step(k)
     fence()
-    r.reset_stats()
+    for rr in rs:
+        rr.reset_stats()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k)
@@ -175,13 +189,30 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    st = r.stats()
+    sts = [rr.stats() for rr in rs]
+    st = {k: sum(x[k] for x in sts) for k in sts[0] if k.startswith("sum_") or k == "frames"}
     frames = max(int(st["frames"]), 1)
     ms = {k: st["sum_ms_" + k] / frames for k in ("project_key", "sort", "bin", "blend", "combine", "total")}
     sf = max(int(st["sum_frames"]), 1)
     V, D, E = st["sum_visible"] / sf, st["sum_tile_entries"] / sf, st["sum_bin_entries"] / sf
     band_px = ((x1 - x0) if world > 1 else W) * H
     band_edges_used = edges if world > 1 else None
+
+    # secondary, untimed leg: one frame in flight on one context -> per-frame latency and uncontended stage times
+    solo = None
+    if F > 1 and world == 1:
+        rs[0].reset_stats()
+        t1 = time.perf_counter()
+        for k in range(60):
+            v, p, vp = poses[k % ORBIT_FRAMES]
+            rs[0].set_camera_arrays(v, p, vp, cfg["fx"], cfg["fx"])
+            rs[0].render_async()
+        rs[0].sync()
+        dt = time.perf_counter() - t1
+        s1 = rs[0].stats()
+        f1 = max(int(s1["frames"]), 1)
+        solo = {"frames_per_sec": 60 / dt, "ms_per_frame": dt / 60 * 1e3,
+                "stage_ms": {k: s1["sum_ms_" + k] / f1 for k in ("project_key", "sort", "bin", "blend", "combine", "total")}}
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -202,6 +233,7 @@ def main():
             except Exception:
                 traffic = valu = None
         ach = b_blend / (ms["blend"] * 1e-3) / 1e9 if ms["blend"] > 0 else 0.0
+        sm = solo["stage_ms"] if solo else ms   # per-stage figures: uncontended times when several frames were in flight
         out = {
             "metric": "frames_per_sec", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
@@ -209,9 +241,9 @@ def main():
             "config": {"workload": "%s: %d synthetic gaussians (seed %d), %dx%d, 120-pose orbit, full render(scene,camera) "
                                    "= depth key + 17-bit sort + projection + binning + composite"
                                    % (args.config, N, cfg["seed"], W, H),
-                       "early_out_eps": args.early_out_eps, "parallelism": "tile-column bands x%d%s" % (world, "" if world == 1 else (", %s all-gather, %s edges" % (args.exchange, "equal" if args.equal_bands else "cost-balanced"))),
+                       "early_out_eps": args.early_out_eps, "frames_in_flight": F, "parallelism": "tile-column bands x%d%s" % (world, "" if world == 1 else (", %s all-gather, %s edges" % (args.exchange, "equal" if args.equal_bands else "cost-balanced"))),
                        "output": "RGBA f32 premultiplied, left in HBM"},
-            "sorted_splats_per_sec": N / ((ms["project_key"] + ms["sort"]) * 1e-3),
+            "sorted_splats_per_sec": N / ((sm["project_key"] + sm["sort"]) * 1e-3),
             "stage_ms": ms,
             "counts": {"N": N, "V": V, "D_tiles16": D, "bin_entries32": E, "P": band_px},
             "roofline": {"bound": "hbm", "kernel": "k_blend", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -224,21 +256,23 @@ def main():
                 "wave_instr_per_launch": valu, "achieved_wave_instr_per_s": valu / (ms["blend"] * 1e-3),
                 "peak_wave_instr_per_s": 1024 * 2.4e9 / 2, "frac": valu / (ms["blend"] * 1e-3) / (1024 * 2.4e9 / 2)},
             "stage_roofline": {
-                "sort": {"bytes": b_sort, "ms": ms["sort"], "GBps": b_sort / (ms["sort"] * 1e-3) / 1e9 if ms["sort"] else 0,
-                         "frac": b_sort / (ms["sort"] * 1e-3) / 1e9 / HBM_PEAK_GBS if ms["sort"] else 0},
-                "project_key": {"bytes": b_proj + 16.0 * N, "ms": ms["project_key"],
-                                "GBps": (b_proj + 16.0 * N) / (ms["project_key"] * 1e-3) / 1e9 if ms["project_key"] else 0},
-                "bin": {"bytes": b_bin, "ms": ms["bin"], "GBps": b_bin / (ms["bin"] * 1e-3) / 1e9 if ms["bin"] else 0},
+                "sort": {"bytes": b_sort, "ms": sm["sort"], "GBps": b_sort / (sm["sort"] * 1e-3) / 1e9 if sm["sort"] else 0,
+                         "frac": b_sort / (sm["sort"] * 1e-3) / 1e9 / HBM_PEAK_GBS if sm["sort"] else 0},
+                "project_key": {"bytes": b_proj + 16.0 * N, "ms": sm["project_key"],
+                                "GBps": (b_proj + 16.0 * N) / (sm["project_key"] * 1e-3) / 1e9 if sm["project_key"] else 0},
+                "bin": {"bytes": b_bin, "ms": sm["bin"], "GBps": b_bin / (sm["bin"] * 1e-3) / 1e9 if sm["bin"] else 0},
                 "frame": {"bytes": b_sort + b_proj + b_bin + b_blend, "ms": ms_step,
                           "frac": (b_sort + b_proj + b_bin + b_blend) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             },
+            "one_frame_in_flight": solo,
             "band_edges": band_edges_used,
             "device": r.device_info(),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(gh, cfg, scene.data[:8 * N], scene.positions)
         print(json.dumps(out))
-    r.dispose()
+    for rr in rs:
+        rr.dispose()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
