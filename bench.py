@@ -131,7 +131,7 @@ def main():
     F = max(1, args.frames_in_flight)
     rs = []
     for _ in range(F):   # every context owns its buffers and its stream; frames are independent of each other
-        rr = gh.HIPRenderer(W, H, device=local_rank, early_out_eps=args.early_out_eps, band=band, timing=True)
+        rr = gh.HIPRenderer(W, H, device=local_rank, early_out_eps=args.early_out_eps, band=band, timing=True, throughput=F > 1)
         rr.render(scene, gh.orbit_camera(0, ORBIT_FRAMES, W, H, cfg["fx"]))  # uploads the scene, first frame
         rs.append(rr)
     r = rs[0]

@@ -67,7 +67,7 @@ struct gsr_ctx {
     uint32_t* bin_rects = nullptr;
     float4* partial = nullptr;
     uint32_t bin_blocks = 0, bin_capacity = 0, bin_table_elems = 0, bin_nbins_alloc = 0, blk_counts_alloc = 0;
-    uint32_t max_items = 0, seg_len = 0;
+    uint32_t max_items = 0, seg_len = 0, blend_grid = 2048;
     // frame words
     FrameState* fstate = nullptr;       // device
     FrameState* fstate_init = nullptr;  // device, constant image copied into fstate every frame
@@ -144,7 +144,10 @@ BinGrid make_grid(const gsr_ctx* c)
 
 // Compositor work-item granularity: list entries per (bin, segment) item.  0x7fffff00 = one item per
 // bin, which early termination needs (a segment cannot see whether earlier ones saturated the bin).
-constexpr uint32_t SEG_LEN_EXACT = 512;
+constexpr uint32_t SEG_LEN_EXACT = 512;          // one frame at a time: short items, concurrency from the frame's own segments
+constexpr uint32_t SEG_LEN_THROUGHPUT = 2048;    // GSR_FLAG_THROUGHPUT: concurrency comes from the other frames in flight
+constexpr uint32_t BLEND_GRID_EXACT = 2048;      // persistent compositor workgroups (8 per CU requested, 6 resident)
+constexpr uint32_t BLEND_GRID_THROUGHPUT = 1280; // 5 per CU: leaves room for the other contexts' kernels
 constexpr uint32_t SEG_LEN_WHOLE_BIN = 0x7fffff00u;
 
 int alloc_bins(gsr_ctx* c)
@@ -175,7 +178,13 @@ int alloc_bins(gsr_ctx* c)
         if (int r = dev_alloc(c, &c->bin_list, c->bin_capacity)) return r;
         items_dirty = true;
     }
-    c->seg_len = c->opt.early_out_eps > 0.0f ? SEG_LEN_WHOLE_BIN : SEG_LEN_EXACT;
+    const bool throughput = (c->opt.flags & GSR_FLAG_THROUGHPUT) != 0;
+    c->seg_len = c->opt.early_out_eps > 0.0f ? SEG_LEN_WHOLE_BIN : throughput ? SEG_LEN_THROUGHPUT : SEG_LEN_EXACT;
+    c->blend_grid = throughput ? BLEND_GRID_THROUGHPUT : BLEND_GRID_EXACT;
+    if (const char* e = getenv("GSR_BLEND_GRID")) {  // tuning knob: persistent compositor workgroups
+        const long v = atol(e);
+        if (v >= 1) c->blend_grid = (uint32_t)v;
+    }
     if (const char* e = getenv("GSR_SEG_LEN")) {  // tuning knob: entries per compositor work item (multiple of 256)
         const long v = atol(e);
         if (v >= 256 && c->seg_len != SEG_LEN_WHOLE_BIN) c->seg_len = (uint32_t)(v / 256 * 256);
@@ -249,7 +258,7 @@ int enqueue_frame(gsr_ctx* c, bool render)
         launch_bin(bb, g, c->n, s);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BIN], s));
         BlendBuffers bl{c->items, c->seg_start, c->bin_start, c->bin_list, c->rec, c->bbox, c->shcol, c->fb, c->partial,
-                        &c->fstate->queue, c->seg_len, std::min<uint32_t>(c->max_items, getenv("GSR_BLEND_GRID") ? (uint32_t)atol(getenv("GSR_BLEND_GRID")) : 2048u), c->bin_capacity,
+                        &c->fstate->queue, c->seg_len, std::min<uint32_t>(c->max_items, c->blend_grid), c->bin_capacity,
                         std::max(c->n, 1u)};
         launch_blend(bl, g, c->opt.early_out_eps, s, timing ? c->ev[EV_BLEND] : nullptr);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_COMBINE], s));

@@ -8,9 +8,13 @@
 // its splat can touch; then every wave picks its tile's entries out of the chunk
 // with a wave64 ballot on its mask nibble (order preserving) and walks the set
 // bits, reading each record as an LDS broadcast and visiting only the flagged
-// quadrants.  No per-tile list is ever
-// materialised in HBM and nothing spills: the LDS footprint is fixed (11 KiB)
-// however long the list is.
+// quadrants.  No per-tile list is ever materialised in HBM and nothing spills:
+// the LDS footprint is fixed (13 KiB) however long the list is.
+//
+// Coordinates are bin-relative: staging folds the splat centre into the two
+// constants -dot(u, c - o), -dot(w, c - o) (o = centre of the bin's first pixel),
+// so a pixel costs vx = ux*px + (uy*py + ncu) with small exact integers px, py,
+// and the row terms are shared by the two quadrants of a row.
 //
 // Long lists (screen centre) are cut into segments that are composited
 // concurrently by different workgroups, each from (colour 0, transmittance 1);
@@ -44,9 +48,8 @@ __global__ __launch_bounds__(BLEND_THREADS, GSR_BLEND_MIN_WAVES) void k_blend(co
                                                          float4* __restrict__ partial, uint32_t* __restrict__ queue,
                                                          BinGrid g, float eps, uint32_t seg_len, uint32_t capacity, uint32_t nsplats)
 {
-    __shared__ float4 s_ra[CHUNK];   // cx, cy, ux, uy
-    __shared__ float4 s_rb[CHUNK];   // wx, wy, log2(opacity), blue
-    __shared__ float2 s_rc[CHUNK];   // red, green (one ds_read_b64 into an aligned register pair)
+    // [0]: ux, uy, -dot(u, c - bin origin), wx   [1]: wy, -dot(w, c - bin origin), log2(opacity), blue   [2]: red, green
+    __shared__ float4 s_rec[3][CHUNK];   // one address register serves the three reads of an entry
     __shared__ uint32_t s_mask[CHUNK];
     __shared__ uint32_t s_done;
     __shared__ uint32_t s_item;
@@ -74,8 +77,10 @@ __global__ __launch_bounds__(BLEND_THREADS, GSR_BLEND_MIN_WAVES) void k_blend(co
         const int by = bin / nbxb, bxl = bin - by * nbxb;
         const int binX0 = (g.bx_lo + bxl) * BIN_PX, binY0 = by * BIN_PX;
         const int X0 = binX0 + (wave & 1) * TILE, Y0 = binY0 + (wave >> 1) * TILE;
-        const float pxf0 = (float)(X0 + lx) + 0.5f, pxf1 = (float)(X0 + lx + 8) + 0.5f;
-        const float pyf0 = (float)(Y0 + ly) + 0.5f, pyf1 = (float)(Y0 + ly + 8) + 0.5f;
+        // pixel centres relative to the centre of the bin's first pixel: small exact integers
+        const float pxf0 = (float)((wave & 1) * TILE + lx), pxf1 = pxf0 + 8.0f;
+        const float pyf0 = (float)((wave >> 1) * TILE + ly), pyf1 = pyf0 + 8.0f;
+        const float bx0c = (float)binX0 + 0.5f, by0c = (float)binY0 + 0.5f;
 
         float T00 = 1.f, T10 = 1.f, T01 = 1.f, T11 = 1.f;  // Tij: pixel (x+8i, y+8j); 1 - alpha
         float r00 = 0.f, r10 = 0.f, r01 = 0.f, r11 = 0.f;
@@ -132,9 +137,11 @@ __global__ __launch_bounds__(BLEND_THREADS, GSR_BLEND_MIN_WAVES) void k_blend(co
                     const float4 sc = shcol[i];
                     cr = sc.x; cg = sc.y; cb = sc.z;
                 }
-                s_ra[threadIdx.x] = ra;
-                s_rb[threadIdx.x] = make_float4(rb.x, rb.y, rb.z, cb);
-                s_rc[threadIdx.x] = make_float2(cr, cg);
+                const float cxr = ra.x - bx0c, cyr = ra.y - by0c;
+                const float ncu = -__builtin_fmaf(ra.w, cyr, ra.z * cxr), ncw = -__builtin_fmaf(rb.y, cyr, rb.x * cxr);
+                s_rec[0][threadIdx.x] = make_float4(ra.z, ra.w, ncu, rb.x);
+                s_rec[1][threadIdx.x] = make_float4(rb.y, ncw, rb.z, cb);
+                *reinterpret_cast<float2*>(&s_rec[2][threadIdx.x]) = make_float2(cr, cg);
             }
             s_mask[threadIdx.x] = mask;
             __syncthreads();
@@ -148,35 +155,34 @@ __global__ __launch_bounds__(BLEND_THREADS, GSR_BLEND_MIN_WAVES) void k_blend(co
                         const int j = __builtin_ctzll(bal);
                         bal &= bal - 1;
                         const uint32_t qm = __builtin_amdgcn_readlane(mine, j);  // wave-uniform quadrant mask
-                        const float4 ra = s_ra[c0 + j];
-                        const float4 rb = s_rb[c0 + j];
-                        const float2 rc = s_rc[c0 + j];
+                        const float4 ra = s_rec[0][c0 + j];
+                        const float4 rb = s_rec[1][c0 + j];
+                        const float2 rc = *reinterpret_cast<const float2*>(&s_rec[2][c0 + j]);
+                        const float ux = ra.x, uy = ra.y, ncu = ra.z, wx = ra.w, wy = rb.x, ncw = rb.y, la = rb.z;
                         const float cr = rc.x, cg = rc.y, cb = rb.w;
-                        const float dx0 = pxf0 - ra.x, dx1 = pxf1 - ra.x;
-                        const float dy0 = pyf0 - ra.y, dy1 = pyf1 - ra.y;
-                        const float uy0 = ra.w * dy0, uy1 = ra.w * dy1;
-                        const float wy0 = rb.y * dy0, wy1 = rb.y * dy1;
+                        // vPosition = (ux*px + (uy*py - dot(u,c)), wx*px + (wy*py - dot(w,c))), all bin-relative:
+                        // the row terms are shared by the two quadrants of a row
+                        const float ur0 = __builtin_fmaf(uy, pyf0, ncu), ur1 = __builtin_fmaf(uy, pyf1, ncu);
+                        const float wr0 = __builtin_fmaf(wy, pyf0, ncw), wr1 = __builtin_fmaf(wy, pyf1, ncw);
                         // frag.glsl.ts:15  if (A < -4.0) discard;   (A = -q)
                         // frag.glsl.ts:16-20  B = clamp(exp(A) * opacity, 0, 1)  (never clamps: exp(A) <= 1, opacity <= 1)
                         // blend: dst += (1 - dst.a) * (B*rgb, B)
-#define GSR_QUAD(BIT, DX, UY, WY, T, R, G, B_)                                                        \
-    if (qm & (BIT)) {                                                                                 \
-        const float vx_ = __builtin_fmaf(ra.z, (DX), (UY)), vy_ = __builtin_fmaf(rb.x, (DX), (WY));   \
-        const float q_ = __builtin_fmaf(vy_, vy_, vx_ * vx_);                                         \
-        const bool in_ = q_ <= 4.0f;                                                                  \
-        if (__ballot(in_) != 0ull) {                                                                  \
-            const float e_ = in_ ? __builtin_amdgcn_exp2f(__builtin_fmaf(q_, -LOG2E, rb.z)) : 0.0f;   \
-            const float w_ = (T) * e_;                                                                \
-            (T) = (T) - w_;                                                                           \
-            (R) = __builtin_fmaf(w_, cr, (R));                                                        \
-            (G) = __builtin_fmaf(w_, cg, (G));                                                        \
-            (B_) = __builtin_fmaf(w_, cb, (B_));                                                      \
-        }                                                                                             \
+#define GSR_QUAD(BIT, PX, UR, WR, T, R, G, B_)                                                     \
+    if (qm & (BIT)) {                                                                              \
+        const float vx_ = __builtin_fmaf(ux, (PX), (UR)), vy_ = __builtin_fmaf(wx, (PX), (WR));    \
+        const float q_ = __builtin_fmaf(vy_, vy_, vx_ * vx_);                                      \
+        if (q_ <= 4.0f) {                                                                          \
+            const float w_ = (T) * __builtin_amdgcn_exp2f(__builtin_fmaf(q_, -LOG2E, la));         \
+            (T) = (T) - w_;                                                                        \
+            (R) = __builtin_fmaf(w_, cr, (R));                                                     \
+            (G) = __builtin_fmaf(w_, cg, (G));                                                     \
+            (B_) = __builtin_fmaf(w_, cb, (B_));                                                   \
+        }                                                                                          \
     }
-                        GSR_QUAD(1u, dx0, uy0, wy0, T00, r00, g00, b00)
-                        GSR_QUAD(2u, dx1, uy0, wy0, T10, r10, g10, b10)
-                        GSR_QUAD(4u, dx0, uy1, wy1, T01, r01, g01, b01)
-                        GSR_QUAD(8u, dx1, uy1, wy1, T11, r11, g11, b11)
+                        GSR_QUAD(1u, pxf0, ur0, wr0, T00, r00, g00, b00)
+                        GSR_QUAD(2u, pxf1, ur0, wr0, T10, r10, g10, b10)
+                        GSR_QUAD(4u, pxf0, ur1, wr1, T01, r01, g01, b01)
+                        GSR_QUAD(8u, pxf1, ur1, wr1, T11, r11, g11, b11)
 #undef GSR_QUAD
                     }
                     if (eps > 0.0f) {

@@ -89,6 +89,8 @@ export interface HIPRendererOptions {
     /** multi-GPU: composite only pixel columns [x0, x1) */
     band?: [number, number];
     timing?: boolean;
+    /** several renderers keep frames in flight on one device (GSR_FLAG_THROUGHPUT): longer compositor work items */
+    throughput?: boolean;
 }
 export interface FrameStats {
     msProjectKey: number; msSort: number; msBin: number; msBlend: number; msCombine: number; msTotal: number;

@@ -78,7 +78,7 @@ bool get_f64(napi_env env, napi_value v, double* out) { return napi_get_value_do
 
 napi_value undefined(napi_env env) { napi_value u; napi_get_undefined(env, &u); return u; }
 
-// create({device,width,height,earlyOutEps,bandX0,bandX1,timing}) -> handle
+// create({device,width,height,earlyOutEps,bandX0,bandX1,timing,throughput}) -> handle
 napi_value Create(napi_env env, napi_callback_info info)
 {
     napi_value argv[1];
@@ -100,7 +100,7 @@ napi_value Create(napi_env env, napi_callback_info info)
     o.early_out_eps = (float)num("earlyOutEps", 0);
     o.band_x0 = (int32_t)num("bandX0", 0);
     o.band_x1 = (int32_t)num("bandX1", 0);
-    o.flags = num("timing", 0) != 0 ? GSR_FLAG_TIMING : 0;
+    o.flags = (num("timing", 0) != 0 ? GSR_FLAG_TIMING : 0) | (num("throughput", 0) != 0 ? GSR_FLAG_THROUGHPUT : 0);
     gsr_ctx* ctx = nullptr;
     const int rc = gsr_create(&ctx, &o);
     if (rc != GSR_OK) return throw_gsr(env, nullptr, rc, "gsr_create");

@@ -25,7 +25,8 @@ function loadNative() {
 class HIPRenderer {
     // new HIPRenderer(canvasLike | options | null, shaderPasses | null)
     //   canvasLike: anything with numeric width/height (stands in for the HTMLCanvasElement of WebGLRenderer.ts:23)
-    //   options: { width, height, device, earlyOutEps, band: [x0, x1], timing }
+    //   options: { width, height, device, earlyOutEps, band: [x0, x1], timing, throughput }
+    //   (throughput: several renderers keep frames in flight on one device; see GSR_FLAG_THROUGHPUT)
     constructor(target, optionalShaderPasses) {
         const o = target || {};
         this._n = loadNative();
@@ -33,7 +34,7 @@ class HIPRenderer {
         this.height = o.height || 1080;
         const band = o.band || [0, 0];
         this._h = this._n.create({ device: o.device || 0, width: this.width, height: this.height,
-                                   earlyOutEps: o.earlyOutEps || 0, bandX0: band[0], bandX1: band[1], timing: o.timing ? 1 : 0 });
+                                   earlyOutEps: o.earlyOutEps || 0, bandX0: band[0], bandX1: band[1], timing: o.timing ? 1 : 0, throughput: o.throughput ? 1 : 0 });
         const passes = optionalShaderPasses || [];
         if (!optionalShaderPasses) passes.push(new FadeInPass());
         let activeScene = null, activeCamera = null, initialized = false, vertexCount = 0;

@@ -20,6 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libgsplat_hip.so"))
 
 GSR_FLAG_TIMING = 1
+GSR_FLAG_THROUGHPUT = 2
 
 
 class GsrOptions(ctypes.Structure):
@@ -219,11 +220,12 @@ class Scene:
 class HIPRenderer:
     """renderer.render(scene, camera) on an MI355X (WebGLRenderer.ts:241-296)."""
 
-    def __init__(self, width=1920, height=1080, device=0, early_out_eps=0.0, band=None, timing=False, lib_path=None):
+    def __init__(self, width=1920, height=1080, device=0, early_out_eps=0.0, band=None, timing=False, lib_path=None,
+                 throughput=False):
         self._L = load_library(lib_path)
         self._ctx = ctypes.c_void_p()
         opt = GsrOptions(device, width, height, early_out_eps, band[0] if band else 0, band[1] if band else 0,
-                         GSR_FLAG_TIMING if timing else 0)
+                         (GSR_FLAG_TIMING if timing else 0) | (GSR_FLAG_THROUGHPUT if throughput else 0))
         rc = self._L.gsr_create(ctypes.byref(self._ctx), ctypes.byref(opt))
         if rc:
             raise GsplatError("gsr_create failed (%d): %s" % (rc, self._L.gsr_last_error(None).decode()))

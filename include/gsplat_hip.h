@@ -58,6 +58,11 @@ typedef struct gsr_options {
 } gsr_options;
 
 #define GSR_FLAG_TIMING 1   /* record HIP events around every stage (gsr_get_timings) */
+#define GSR_FLAG_THROUGHPUT 2 /* the caller keeps several frames in flight on this device (one
+                               context per frame): the compositor then uses longer work items
+                               (2048 list entries instead of 512) and 5 instead of 8 persistent
+                               workgroups per CU, because the other contexts' kernels, not extra
+                               segments of this frame, fill the GPU.  Same pixels either way. */
 
 /* Per-stage device times of the last completed gsr_render / gsr_sort, measured
  * with HIP events on the context's stream, plus the frame's list sizes. */

@@ -618,10 +618,15 @@ void orc_render(uint32_t n, const uint32_t *depth_index, const float *raw, const
                     if (A < -4.0) continue;
                     B = exp(A) * opacity;
                 } else {
-                    float dx = ((float)x + 0.5f) - rc[0];
-                    float dy = ((float)y + 0.5f) - rc[1];
-                    float vx = fmaf(rc[2], dx, rc[3] * dy);
-                    float vy = fmaf(rc[4], dx, rc[5] * dy);
+                    /* k_blend's expression: coordinates relative to the centre of the first pixel of
+                     * the 32x32 bin that holds (x, y); the centre is folded into ncu / ncw */
+                    int bx0 = (x / 32) * 32, by0 = (y / 32) * 32;
+                    float cxr = rc[0] - ((float)bx0 + 0.5f), cyr = rc[1] - ((float)by0 + 0.5f);
+                    float ncu = -fmaf(rc[3], cyr, rc[2] * cxr);
+                    float ncw = -fmaf(rc[5], cyr, rc[4] * cxr);
+                    float pxl = (float)(x - bx0), pyl = (float)(y - by0);
+                    float vx = fmaf(rc[2], pxl, fmaf(rc[3], pyl, ncu));
+                    float vy = fmaf(rc[4], pxl, fmaf(rc[5], pyl, ncw));
                     float q = fmaf(vy, vy, vx * vx);
                     if (q > 4.0f) continue;
                     B = exp(-(double)q) * opacity;

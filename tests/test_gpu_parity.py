@@ -108,8 +108,8 @@ def test_projection_bit_exact(gh, oracle, scenes, name, k):
     r.dispose()
 
 
-def _render_pair(gh, oracle, data, pos, cam, W, H, eps=0.0, band=None):
-    r = gh.HIPRenderer(W, H, early_out_eps=eps, band=band)
+def _render_pair(gh, oracle, data, pos, cam, W, H, eps=0.0, band=None, throughput=False):
+    r = gh.HIPRenderer(W, H, early_out_eps=eps, band=band, throughput=throughput)
     r.set_raw_scene(data, pos)
     r.set_camera(cam)
     r.render_async(); r.sync()
@@ -135,6 +135,18 @@ def test_image_parity_exact_mode(gh, oracle, scenes, name, k):
     assert err <= TOL_EXACT, err
     o8 = np.floor(np.clip(oimg.astype(np.float64), 0, 1) * 255.0 + 0.5).astype(np.int32)
     assert np.abs(img8.astype(np.int32) - o8).max() <= 1
+
+
+def test_image_parity_throughput_flag(gh, oracle, scenes):
+    # GSR_FLAG_THROUGHPUT changes only how a bin's list is cut into work items (2048 instead of 512 entries)
+    cfg = gh.synth.CONFIGS["C2"]
+    rows, data, pos = scenes("C2")
+    cam = _camera(gh, 13, cfg)
+    img, img8, di, st, oimg, odi, V, D = _render_pair(gh, oracle, data, pos, cam, cfg["width"], cfg["height"], throughput=True)
+    assert np.array_equal(di, odi)
+    assert st["visible"] == V and st["tile_entries"] == D
+    err = np.abs(img.astype(np.float64) - oimg.astype(np.float64)).max()
+    assert err <= TOL_EXACT, err
 
 
 def test_image_parity_early_out(gh, oracle, scenes):
