@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="independent frames rendered concurrently on separate contexts/streams (frame k uses context k mod F)")
     ap.add_argument("--equal-bands", action="store_true", help="N>1: equal-width bands instead of cost-balanced ones")
+    ap.add_argument("--emulate-rank", default=None, metavar="Q/G",
+                    help="single GPU only: render just the band rank Q of G would own (no exchange) -> per-rank device time of a G-GPU run")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -113,21 +115,28 @@ def main():
     # tile-column bands: whole 32-px bins per rank.  Equal-width bands are badly unbalanced for centre-heavy scenes
     # (a frame is as slow as its slowest band), so the edges come from a calibration frame's per-column list entries.
     from gsplat_hip import bands
-    edges = bands.band_edges(W, world)
-    if world > 1 and not args.equal_bands:
+    emu = None
+    if args.emulate_rank:
+        if world > 1:
+            raise SystemExit("--emulate-rank is a single-GPU diagnostic")
+        emu = tuple(int(x) for x in args.emulate_rank.split("/"))
+    eworld = emu[1] if emu else world
+    edges = bands.band_edges(W, eworld)
+    if eworld > 1 and not args.equal_bands:
         cal = gh.HIPRenderer(W, H, device=local_rank)
         cost = np.zeros(-(-W // 32))
         for k in (0, 30, 60, 90):
             cal.render(scene, gh.orbit_camera(k, ORBIT_FRAMES, W, H, cfg["fx"]))
             cost += cal.bin_totals().sum(axis=0) + 0.25 * 32 * H    # list entries + a per-pixel output term
         cal.dispose()
-        got = [bands.balanced_edges(W, world, cost)]
-        dist.broadcast_object_list(got, src=0)    # every rank uses rank 0's edges
+        got = [bands.balanced_edges(W, eworld, cost)]
+        if world > 1:
+            dist.broadcast_object_list(got, src=0)    # every rank uses rank 0's edges
         edges = got[0]
-    x0, x1 = edges[rank]
+    x0, x1 = edges[emu[0] if emu else rank]
     if world > 1 and x1 <= x0:
         raise SystemExit("rank %d has an empty band (more ranks than 32-px bin columns)" % rank)
-    band = (x0, x1) if world > 1 else None
+    band = (x0, x1) if eworld > 1 else None
     F = max(1, args.frames_in_flight)
     rs = []
     for _ in range(F):   # every context owns its buffers and its stream; frames are independent of each other
@@ -157,14 +166,15 @@ def main():
         rr.set_camera_arrays(v, p, vp, cfg["fx"], cfg["fx"])
         rr.render_async()
         if world > 1:
-            # device-side ordering only: torch's stream waits for the frame, the next frame waits for the slab copy
+            # device-side ordering only (no host round trip): the collective and the de-slab on torch's stream overlap the
+            # following frames' projection, sort, binning and compositing on the renderers' streams
             if args.exchange == "rgba8":
-                rr.convert_rgba8_async()
-            links[c].torch_waits_for_renderer()
-            xchg.exchange(fbs[c])
-            # this context's next frame may start as soon as this band has left the framebuffer: the all-gather and
-            # the assembly on torch's side overlap the following frames' projection, sort, binning and compositing
-            links[c].renderer_waits_for_event(xchg.copied)
+                xchg.exchange_native(rr, links[c])
+            else:
+                links[c].torch_waits_for_renderer()
+                xchg.exchange(fbs[c])
+                # this context's next frame may start as soon as this band has left the framebuffer
+                links[c].renderer_waits_for_event(xchg.copied)
 
     def fence():
         for rr in rs:
@@ -195,24 +205,29 @@ def main():
     ms = {k: st["sum_ms_" + k] / frames for k in ("project_key", "sort", "bin", "blend", "combine", "total")}
     sf = max(int(st["sum_frames"]), 1)
     V, D, E = st["sum_visible"] / sf, st["sum_tile_entries"] / sf, st["sum_bin_entries"] / sf
-    band_px = ((x1 - x0) if world > 1 else W) * H
-    band_edges_used = edges if world > 1 else None
+    band_px = ((x1 - x0) if eworld > 1 else W) * H
+    band_edges_used = edges if eworld > 1 else None
 
-    # secondary, untimed leg: one frame in flight on one context -> per-frame latency and uncontended stage times
+    # secondary leg outside the timed region: ONE frame in flight on a context tuned for that (no GSR_FLAG_THROUGHPUT)
+    # -> per-frame latency and uncontended stage times
     solo = None
     if F > 1 and world == 1:
-        rs[0].reset_stats()
+        sr = gh.HIPRenderer(W, H, device=local_rank, early_out_eps=args.early_out_eps, timing=True)
+        for k in range(4):
+            sr.render(scene, gh.orbit_camera(k, ORBIT_FRAMES, W, H, cfg["fx"]))
+        sr.reset_stats()
         t1 = time.perf_counter()
         for k in range(60):
             v, p, vp = poses[k % ORBIT_FRAMES]
-            rs[0].set_camera_arrays(v, p, vp, cfg["fx"], cfg["fx"])
-            rs[0].render_async()
-        rs[0].sync()
+            sr.set_camera_arrays(v, p, vp, cfg["fx"], cfg["fx"])
+            sr.render_async()
+        sr.sync()
         dt = time.perf_counter() - t1
-        s1 = rs[0].stats()
+        s1 = sr.stats()
         f1 = max(int(s1["frames"]), 1)
         solo = {"frames_per_sec": 60 / dt, "ms_per_frame": dt / 60 * 1e3,
                 "stage_ms": {k: s1["sum_ms_" + k] / f1 for k in ("project_key", "sort", "bin", "blend", "combine", "total")}}
+        sr.dispose()
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -241,7 +256,7 @@ def main():
             "config": {"workload": "%s: %d synthetic gaussians (seed %d), %dx%d, 120-pose orbit, full render(scene,camera) "
                                    "= depth key + 17-bit sort + projection + binning + composite"
                                    % (args.config, N, cfg["seed"], W, H),
-                       "early_out_eps": args.early_out_eps, "frames_in_flight": F, "parallelism": "tile-column bands x%d%s" % (world, "" if world == 1 else (", %s all-gather, %s edges" % (args.exchange, "equal" if args.equal_bands else "cost-balanced"))),
+                       "early_out_eps": args.early_out_eps, "frames_in_flight": F, "emulated_rank": args.emulate_rank, "parallelism": "tile-column bands x%d%s" % (world, "" if world == 1 else (", %s all-gather, %s edges" % (args.exchange, "equal" if args.equal_bands else "cost-balanced"))),
                        "output": "RGBA f32 premultiplied, left in HBM"},
             "sorted_splats_per_sec": N / ((sm["project_key"] + sm["sort"]) * 1e-3),
             "stage_ms": ms,
@@ -249,6 +264,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_blend", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_blend, "avg_launch_ms": ms["blend"],
+                         "one_frame_in_flight": None if not solo else {
+                             "avg_launch_ms": solo["stage_ms"]["blend"],
+                             "achieved": b_blend / (solo["stage_ms"]["blend"] * 1e-3) / 1e9,
+                             "frac": b_blend / (solo["stage_ms"]["blend"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          "note": "the compositor is VALU-bound, not HBM-bound (SURVEY 8(d) honest note); see valu"},
             # secondary ceiling: VALU issue. peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction
             # (tools/valu_peak.hip measures 0.96e12 v_fma_f32 wave-instr/s; v_exp_f32 is 3.3x slower)

@@ -839,6 +839,37 @@ int gsr_convert_rgba8_async(gsr_ctx* c)
 
 void* gsr_framebuffer8_device_ptr(gsr_ctx* c) { return c ? (void*)c->fb8 : nullptr; }
 
+int gsr_pack_band_rgba8_async(gsr_ctx* c, void* slab, int32_t slab_width_px)
+{
+    if (!c) return GSR_ERR_ARG;
+    if (!slab || !c->fb) return fail(c, GSR_ERR_ARG, "gsr_pack_band_rgba8_async: no slab / nothing rendered yet");
+    const BinGrid g = make_grid(c);
+    const int x0 = g.bx_lo * BIN_PX, x1 = std::min(g.bx_hi * BIN_PX, c->W);
+    if (slab_width_px < x1 - x0) return fail(c, GSR_ERR_ARG, "gsr_pack_band_rgba8_async: slab narrower than the band");
+    HIP_TRY(c, hipSetDevice(c->device));
+    launch_pack_band_rgba8(c->fb, (uint32_t*)slab, c->W, c->H, x0, x1, slab_width_px, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_unpack_slabs_rgba8_async(gsr_ctx* c, const void* gathered, void* image, int32_t slab_width_px, int32_t world,
+                                 const int32_t* x0, const int32_t* x1, void* stream)
+{
+    if (!c) return GSR_ERR_ARG;
+    if (!gathered || !image || !x0 || !x1 || world < 1 || world > MAX_SLABS)
+        return fail(c, GSR_ERR_ARG, "gsr_unpack_slabs_rgba8_async: bad argument (1 <= world <= 16)");
+    SlabEdges e{};
+    for (int q = 0; q < world; q++) {
+        if (x0[q] < 0 || x1[q] > c->W || x1[q] - x0[q] > slab_width_px)
+            return fail(c, GSR_ERR_ARG, "gsr_unpack_slabs_rgba8_async: band outside the image or wider than the slab");
+        e.x0[q] = x0[q]; e.x1[q] = x1[q];
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    launch_unpack_slabs_rgba8((const uint32_t*)gathered, (uint32_t*)image, c->W, c->H, slab_width_px, world, e, (hipStream_t)stream);
+    HIP_TRY(c, hipGetLastError());
+    return GSR_OK;
+}
+
 void* gsr_framebuffer_device_ptr(gsr_ctx* c) { return c ? (void*)c->fb : nullptr; }
 void* gsr_stream_handle(gsr_ctx* c) { return c ? (void*)c->stream : nullptr; }
 

@@ -137,4 +137,11 @@ void launch_blend(const BlendBuffers& b, const BinGrid& g, float early_out_eps, 
 void launch_clear_fb(float4* fb, int32_t W, int32_t H, hipStream_t s);
 void launch_to_rgba8(const float4* fb, uint32_t* out, uint32_t npix, hipStream_t s);
 
+// multi-GPU exchange helpers (RGBA8 slabs of the all-gather)
+constexpr int MAX_SLABS = 16;
+struct SlabEdges { int32_t x0[MAX_SLABS], x1[MAX_SLABS]; };
+void launch_pack_band_rgba8(const float4* fb, uint32_t* slab, int W, int H, int x0, int x1, int slab_w, hipStream_t s);
+void launch_unpack_slabs_rgba8(const uint32_t* gathered, uint32_t* image, int W, int H, int slab_w, int world,
+                               const SlabEdges& e, hipStream_t s);
+
 }  // namespace gsr

@@ -219,7 +219,9 @@ __global__ __launch_bounds__(BLEND_THREADS, GSR_BLEND_MIN_WAVES) void k_blend(co
     }
 }
 
-// Fold the per-segment partials of every multi-segment bin, front to back.
+// Fold the per-segment partials of every multi-segment bin, front to back.  A thread folds its four
+// pixels as four independent chains and the segment loop is unrolled, so 16 loads are in flight per
+// thread: the kernel is a latency-bound read of the partials (85 MB on C3 with 512-entry segments).
 __global__ __launch_bounds__(BLEND_THREADS) void k_combine(const uint32_t* __restrict__ seg_start,
                                                            const float4* __restrict__ partial, float4* __restrict__ fb,
                                                            BinGrid g)
@@ -232,19 +234,25 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_combine(const uint32_t* __res
     const int by = bin / nbxb, bxl = bin - by * nbxb;
     const int X0 = (g.bx_lo + bxl) * BIN_PX + (wave & 1) * TILE, Y0 = by * BIN_PX + (wave >> 1) * TILE;
     const int lx = lane & 7, ly = lane >> 3;
+    const float4* p = partial + (size_t)s0 * BIN_PIXELS + wave * (TILE * TILE) + lane;
+    float r[4] = {0.f, 0.f, 0.f, 0.f}, gg[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f}, T[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll 4
+    for (uint32_t k = 0; k < nseg; k++) {
+        float4 v[4];
+#pragma unroll
+        for (int slot = 0; slot < 4; slot++) v[slot] = p[(size_t)k * BIN_PIXELS + slot * 64];
+#pragma unroll
+        for (int slot = 0; slot < 4; slot++) {
+            r[slot] = __builtin_fmaf(T[slot], v[slot].x, r[slot]);
+            gg[slot] = __builtin_fmaf(T[slot], v[slot].y, gg[slot]);
+            b[slot] = __builtin_fmaf(T[slot], v[slot].z, b[slot]);
+            T[slot] = T[slot] * v[slot].w;
+        }
+    }
 #pragma unroll
     for (int slot = 0; slot < 4; slot++) {
-        const float4* p = partial + (size_t)s0 * BIN_PIXELS + wave * (TILE * TILE) + slot * 64 + lane;
-        float r = 0.f, gg = 0.f, b = 0.f, T = 1.f;
-        for (uint32_t k = 0; k < nseg; k++) {
-            const float4 v = p[(size_t)k * BIN_PIXELS];
-            r = __builtin_fmaf(T, v.x, r);
-            gg = __builtin_fmaf(T, v.y, gg);
-            b = __builtin_fmaf(T, v.z, b);
-            T = T * v.w;
-        }
         const int x = X0 + lx + 8 * (slot & 1), y = Y0 + ly + 8 * (slot >> 1);
-        if (x < g.W && y < g.H) fb[(size_t)y * g.W + x] = make_float4(r, gg, b, 1.0f - T);
+        if (x < g.W && y < g.H) fb[(size_t)y * g.W + x] = make_float4(r[slot], gg[slot], b[slot], 1.0f - T[slot]);
     }
 }
 
@@ -272,17 +280,56 @@ void launch_clear_fb(float4* fb, int32_t W, int32_t H, hipStream_t s)
     hipLaunchKernelGGL(k_clear_fb, dim3((npix + 255) / 256), dim3(256), 0, s, fb, npix);
 }
 
+__device__ __forceinline__ uint32_t to_rgba8(float4 v)
+{
+    auto q = [](float x) -> uint32_t {
+        x = fminf(fmaxf(x, 0.0f), 1.0f);
+        return (uint32_t)(x * 255.0f + 0.5f);
+    };
+    return q(v.x) | (q(v.y) << 8) | (q(v.z) << 16) | (q(v.w) << 24);
+}
+
 // round(clamp(x, 0, 1) * 255) per channel (Appendix A of SURVEY.md: output framebuffer contract)
 __global__ void k_to_rgba8(const float4* __restrict__ fb, uint32_t* __restrict__ out, uint32_t npix)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix) return;
-    const float4 v = fb[i];
-    auto q = [](float x) -> uint32_t {
-        x = fminf(fmaxf(x, 0.0f), 1.0f);
-        return (uint32_t)(x * 255.0f + 0.5f);
-    };
-    out[i] = q(v.x) | (q(v.y) << 8) | (q(v.z) << 16) | (q(v.w) << 24);
+    out[i] = to_rgba8(fb[i]);
+}
+
+// Multi-GPU exchange, sender side: the band's columns [x0, x1) as RGBA8 straight into the all-gather slab
+// ([H][slab_w] pixels), one pass over the band instead of a whole-frame conversion plus a strided copy.
+__global__ void k_pack_band_rgba8(const float4* __restrict__ fb, uint32_t* __restrict__ slab, int W, int H, int x0, int x1,
+                                  int slab_w)
+{
+    const int x = x0 + blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= x1) return;
+    slab[(size_t)y * slab_w + (x - x0)] = to_rgba8(fb[(size_t)y * W + x]);
+}
+
+void launch_pack_band_rgba8(const float4* fb, uint32_t* slab, int W, int H, int x0, int x1, int slab_w, hipStream_t s)
+{
+    if (x1 <= x0 || H <= 0) return;
+    hipLaunchKernelGGL(k_pack_band_rgba8, dim3((x1 - x0 + 255) / 256, H), dim3(256), 0, s, fb, slab, W, H, x0, x1, slab_w);
+}
+
+// Receiver side: the gathered slabs [world][H][slab_w] -> one row-major [H][W] image.
+__global__ void k_unpack_slabs_rgba8(const uint32_t* __restrict__ gathered, uint32_t* __restrict__ image, int W, int H,
+                                     int slab_w, int world, SlabEdges e)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    uint32_t v = 0;
+    for (int q = 0; q < world; q++)
+        if (x >= e.x0[q] && x < e.x1[q]) v = gathered[((size_t)q * H + y) * slab_w + (x - e.x0[q])];
+    image[(size_t)y * W + x] = v;
+}
+
+void launch_unpack_slabs_rgba8(const uint32_t* gathered, uint32_t* image, int W, int H, int slab_w, int world,
+                               const SlabEdges& e, hipStream_t s)
+{
+    if (W <= 0 || H <= 0) return;
+    hipLaunchKernelGGL(k_unpack_slabs_rgba8, dim3((W + 255) / 256, H), dim3(256), 0, s, gathered, image, W, H, slab_w, world, e);
 }
 
 void launch_to_rgba8(const float4* fb, uint32_t* out, uint32_t npix, hipStream_t s)

@@ -53,6 +53,7 @@ EXPORTS = [
     "gsr_sort", "gsr_render", "gsr_render_async", "gsr_sync", "gsr_read_depth_index", "gsr_read_pixels_rgba32f",
     "gsr_read_pixels_rgba8", "gsr_get_timings", "gsr_reset_timings", "gsr_read_keys", "gsr_read_records",
     "gsr_read_bin_totals", "gsr_convert_rgba8_async", "gsr_framebuffer8_device_ptr",
+    "gsr_pack_band_rgba8_async", "gsr_unpack_slabs_rgba8_async",
     "gsr_framebuffer_device_ptr", "gsr_stream_handle", "gsr_device_info", "gsplat_sort_host",
 ]
 
@@ -93,6 +94,9 @@ def load_library(path=None):
     L.gsr_read_records.argtypes = [vp, vp, vp]
     L.gsr_read_bin_totals.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
     L.gsr_convert_rgba8_async.argtypes = [vp]
+    L.gsr_pack_band_rgba8_async.argtypes = [vp, vp, ctypes.c_int32]
+    L.gsr_unpack_slabs_rgba8_async.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
+                                               ctypes.POINTER(ctypes.c_int32), vp]
     L.gsr_framebuffer8_device_ptr.argtypes = [vp]
     L.gsr_framebuffer8_device_ptr.restype = vp
     L.gsr_framebuffer_device_ptr.argtypes = [vp]
@@ -414,6 +418,18 @@ class HIPRenderer:
 
     def convert_rgba8_async(self):
         self._check(self._L.gsr_convert_rgba8_async(self._ctx))
+
+    def pack_band_rgba8_async(self, slab_ptr, slab_width_px):
+        """This context's band as RGBA8 into the all-gather slab (device pointer), on the renderer's stream."""
+        self._check(self._L.gsr_pack_band_rgba8_async(self._ctx, ctypes.c_void_p(slab_ptr), slab_width_px))
+
+    def unpack_slabs_rgba8_async(self, gathered_ptr, image_ptr, slab_width_px, edges, stream_handle):
+        """Gathered slabs [world][H][slab_w] -> row-major image, on `stream_handle` (the collective's stream)."""
+        world = len(edges)
+        x0 = (ctypes.c_int32 * world)(*[int(a) for a, _ in edges])
+        x1 = (ctypes.c_int32 * world)(*[int(b) for _, b in edges])
+        self._check(self._L.gsr_unpack_slabs_rgba8_async(self._ctx, ctypes.c_void_p(gathered_ptr), ctypes.c_void_p(image_ptr),
+                                                         slab_width_px, world, x0, x1, ctypes.c_void_p(stream_handle)))
 
     def framebuffer8_ptr(self):
         return self._L.gsr_framebuffer8_device_ptr(self._ctx)

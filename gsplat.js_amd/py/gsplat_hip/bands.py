@@ -91,7 +91,12 @@ class StreamLink:
 
 
 class FrameExchange:
-    """all-gather of per-rank band slabs into every rank's full frame."""
+    """all-gather of per-rank band slabs into every rank's full frame.
+
+    Two ways to use it: `exchange(fb)` works on any torch tensor (CPU/gloo in the tests, f32 or u8);
+    `exchange_native(renderer, link)` is the GPU RGBA8 path: the library packs the band straight into the slab
+    (gsr_pack_band_rgba8_async) and de-slabs the gathered buffer with one kernel (gsr_unpack_slabs_rgba8_async),
+    so a frame costs one collective and no torch copy kernels."""
 
     def __init__(self, dist, torch, width, height, rank, world, device, channels=4, edges=None, dtype=None):
         self.dist, self.rank, self.world = dist, rank, world
@@ -105,6 +110,25 @@ class FrameExchange:
         self.full = torch.empty((height, width, channels), dtype=dtype, device=device)
         # recorded on the current stream right after the band has been copied into the slab (device tensors only)
         self.copied = torch.cuda.Event() if str(device).startswith("cuda") else None
+        self.gathered_ev = None
+
+    def exchange_native(self, renderer, link):
+        """RGBA8 exchange of the frame `renderer` has enqueued.  Device-side ordering only:
+        pack on the renderer's stream -> torch's stream waits -> all-gather -> de-slab on torch's stream.
+        The slab is reused by the next call, so the next pack waits for this all-gather (event `gathered`)."""
+        torch = link.torch
+        sw = self.slab.shape[1]
+        if self.gathered_ev is None:
+            self.gathered_ev = torch.cuda.Event()
+        else:
+            link.renderer_waits_for_event(self.gathered_ev)     # previous collective has read the slab
+        renderer.pack_band_rgba8_async(self.slab.data_ptr(), sw)
+        link.torch_waits_for_renderer()
+        self.dist.all_gather_into_tensor(self._flat, self.slab)
+        self.gathered_ev.record()
+        renderer.unpack_slabs_rgba8_async(self._flat.data_ptr(), self.full.data_ptr(), sw, self.edges,
+                                          torch.cuda.current_stream().cuda_stream)
+        return self.full
 
     def exchange(self, fb):
         """fb: [H, W, C] tensor whose columns edges[rank] hold this rank's band. Returns the full frame."""

@@ -148,6 +148,15 @@ int gsr_read_bin_totals(gsr_ctx *ctx, uint32_t *out /* nbx*nby */, int32_t *nbx,
 /* Enqueue the f32 -> RGBA8 conversion of the framebuffer on the context's stream (result: gsr_framebuffer8_device_ptr). */
 int gsr_convert_rgba8_async(gsr_ctx *ctx);
 void *gsr_framebuffer8_device_ptr(gsr_ctx *ctx); /* uint8[h][w][4] on the device */
+/* Sender side of the framebuffer all-gather: convert this context's band columns to RGBA8 and
+ * write them into `slab` (device memory, `height` rows of `slab_width_px` pixels, >= band width), on the
+ * context's stream.  One pass over the band; replaces gsr_convert_rgba8_async + a strided copy. */
+int gsr_pack_band_rgba8_async(gsr_ctx *ctx, void *slab, int32_t slab_width_px);
+/* Receiver side: de-slab the gathered buffer [world][height][slab_width_px] (RGBA8) into the row-major
+ * [height][width] `image`; rank q's columns are [x0[q], x1[q]).  Runs on `stream` (a hipStream_t: the stream
+ * the collective was issued on, e.g. torch's current stream), device = the context's.  world <= 16. */
+int gsr_unpack_slabs_rgba8_async(gsr_ctx *ctx, const void *gathered, void *image, int32_t slab_width_px, int32_t world,
+                                 const int32_t *x0, const int32_t *x1, void *stream);
 
 /* ---- device interop (torch / RCCL plumbing in the harness) ---- */
 void *gsr_framebuffer_device_ptr(gsr_ctx *ctx); /* float4[h][w] on the device */

@@ -405,6 +405,58 @@ def test_stream_linked_rgba8_readout(gh, scenes):
     r.dispose()
 
 
+def test_native_slab_exchange_single_device(gh, scenes):
+    # the N>1 RGBA8 exchange of bench.py with the collective replaced by a local stand-in: three "ranks" (contexts with
+    # cost-balanced, unequal bands) pack their bands into slabs, a fake all-gather stacks them, one kernel de-slabs;
+    # the result must be the whole-frame RGBA8 image bit for bit
+    import torch
+    from gsplat_hip import bands
+    cfg = gh.synth.CONFIGS["C1"]
+    rows, data, pos = scenes("C1")
+    W, H = cfg["width"], cfg["height"]
+    cam = _camera(gh, 21, cfg)
+    whole = gh.HIPRenderer(W, H)
+    whole.set_raw_scene(data, pos); whole.set_camera(cam); whole.render_async(); whole.sync()
+    cost = whole.bin_totals().sum(axis=0) + 8.0 * H
+    world = 3
+    edges = bands.balanced_edges(W, world, cost)
+    assert edges[0][0] == 0 and edges[-1][1] == W and len({b - a for a, b in edges}) > 1
+    stacked = {}
+
+    class FakeDist:      # stands in for torch.distributed: "gathers" what the other ranks packed earlier
+        def __init__(self, rank): self.rank = rank
+        def all_gather_into_tensor(self, flat, slab):
+            stacked[self.rank] = slab.clone()
+            if len(stacked) == world:
+                flat.copy_(torch.cat([stacked[q] for q in range(world)], dim=0))
+
+    rs = []
+    for q in range(world):
+        r = gh.HIPRenderer(W, H, band=edges[q])
+        r.set_raw_scene(data, pos)
+        rs.append((r, bands.StreamLink(torch, r, "cuda:0"),
+                   bands.FrameExchange(FakeDist(q), torch, W, H, q, world, torch.device("cuda:0"), edges=edges, dtype=torch.uint8)))
+    for k in (21, 64):       # the second frame goes through the slab-reuse event path
+        c = _camera(gh, k, cfg)
+        whole.set_camera(c); whole.render_async(); whole.sync()
+        stacked.clear()
+        outs = []
+        for r, link, x in rs:
+            r.set_camera(c)
+            r.render_async()
+            outs.append(x.exchange_native(r, link))
+        torch.cuda.synchronize()
+        assert np.array_equal(outs[-1].cpu().numpy(), whole.readPixels())     # the last "rank" saw all three slabs
+    # errors: slab narrower than the band, too many ranks
+    with pytest.raises(gh.GsplatError):
+        rs[0][0].pack_band_rgba8_async(outs[0].data_ptr(), 1)
+    with pytest.raises(gh.GsplatError):
+        rs[0][0].unpack_slabs_rgba8_async(outs[0].data_ptr(), outs[0].data_ptr(), 64, [(0, 32)] * 17, 0)
+    for r, _, _ in rs:
+        r.dispose()
+    whole.dispose()
+
+
 def test_on_device_scene_build_and_transforms(gh, oracle):
     # Scene.setData / translate / rotate / scale / limitBox as kernels, bit-exact with the
     # f64 restatement of the JavaScript (which tests/test_js_host.py pins against the JS implementation itself)
