@@ -29,6 +29,7 @@ struct FrameState {  // small per-frame device words, (re)initialised by one mem
     uint64_t visible;
     uint64_t tile_entries;
     uint32_t digit_total[RADIX_LO_BINS + RADIX_HI_BINS];
+    uint32_t sorted_count;  // entries of depth_index: n, or the band's survivors (SortBuffers::count)
 };
 
 }  // namespace
@@ -68,6 +69,7 @@ struct gsr_ctx {
     float4* partial = nullptr;
     uint32_t bin_blocks = 0, bin_capacity = 0, bin_table_elems = 0, bin_nbins_alloc = 0, blk_counts_alloc = 0;
     uint32_t max_items = 0, seg_len = 0, blend_grid = 2048;
+    bool sort_culled = false;  // the last sort kept only the band's survivors (depth_index / keys are partial)
     // frame words
     FrameState* fstate = nullptr;       // device
     FrameState* fstate_init = nullptr;  // device, constant image copied into fstate every frame
@@ -140,6 +142,12 @@ BinGrid make_grid(const gsr_ctx* c)
         g.bx_lo = 0; g.bx_hi = g.nbx;
     }
     return g;
+}
+
+bool band_is_partial(const gsr_ctx* c)
+{
+    const BinGrid g = make_grid(c);
+    return g.bx_lo > 0 || g.bx_hi < g.nbx;
 }
 
 // Compositor work-item granularity: list entries per (bin, segment) item.  0x7fffff00 = one item per
@@ -243,8 +251,13 @@ int enqueue_frame(gsr_ctx* c, bool render)
     }
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_PROJECT], s));
     if (c->n) {
+        // band mode (a context that composites only part of the screen): sort and bin only the splats whose box
+        // touches the band; the full depthIndex is produced on demand (gsr_read_depth_index)
+        const bool cull = render && band_is_partial(c);
         SortBuffers sb{c->depth, c->fstate->minmax, c->keys, c->keys_tmp, c->idx_tmp, c->depth_index,
-                       c->block_hist, c->fstate->digit_total, c->sort_kpb, c->sort_blocks};
+                       c->block_hist, c->fstate->digit_total, cull ? c->bbox : nullptr, &c->fstate->sorted_count,
+                       c->sort_kpb, c->sort_blocks};
+        c->sort_culled = cull;
         launch_sort(sb, c->n, s);
     }
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_SORT], s));
@@ -252,7 +265,7 @@ int enqueue_frame(gsr_ctx* c, bool render)
         const BinGrid g = make_grid(c);
         const int nbins = (g.bx_hi - g.bx_lo) * g.nby;
         if (!c->n) HIP_TRY(c, hipMemsetAsync(c->bin_total, 0, sizeof(uint32_t) * nbins, s));
-        BinBuffers bb{c->depth_index, c->bbox, c->bin_table, c->blk_counts, c->bin_rects, c->bin_total, c->bin_start, c->seg_start,
+        BinBuffers bb{c->depth_index, &c->fstate->sorted_count, c->bbox, c->bin_table, c->blk_counts, c->bin_rects, c->bin_total, c->bin_start, c->seg_start,
                       c->items, c->bin_list, &c->fstate->overflow, &c->fstate->visible, &c->fstate->tile_entries,
                       c->accum, c->bin_capacity, c->max_items, c->seg_len, c->bin_blocks};
         launch_bin(bb, g, c->n, s);
@@ -727,6 +740,10 @@ int gsr_read_depth_index(gsr_ctx* c, uint32_t* out)
     if (!c || !out) return c ? fail(c, GSR_ERR_ARG, "out is NULL") : GSR_ERR_ARG;
     if (!c->have_sort) return fail(c, GSR_ERR_ARG, "no sort has run yet");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->sort_culled) {  // the band's frame sorted only its survivors: the caller wants the whole permutation
+        if (int r = enqueue_frame(c, false)) return r;
+        if (int r = finish_frame(c)) return r;
+    }
     HIP_TRY(c, hipMemcpyAsync(out, c->depth_index, (size_t)c->n * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return GSR_OK;
@@ -776,6 +793,10 @@ int gsr_read_keys(gsr_ctx* c, uint32_t* keys, int32_t* minmax)
     if (!c) return GSR_ERR_ARG;
     if (!c->have_sort) return fail(c, GSR_ERR_ARG, "no sort has run yet");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->sort_culled) {
+        if (int r = enqueue_frame(c, false)) return r;
+        if (int r = finish_frame(c)) return r;
+    }
     if (keys) HIP_TRY(c, hipMemcpyAsync(keys, c->keys, (size_t)c->n * 4, hipMemcpyDeviceToHost, c->stream));
     if (minmax) HIP_TRY(c, hipMemcpyAsync(minmax, c->fstate->minmax, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

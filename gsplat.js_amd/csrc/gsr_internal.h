@@ -84,6 +84,8 @@ struct SortBuffers {
     uint32_t* depth_index;     // n   result
     uint32_t* block_hist;      // nblocks * RADIX_HI_BINS
     uint32_t* digit_total;     // RADIX_LO_BINS + RADIX_HI_BINS
+    const uint2* cull_bbox;    // band mode: boxes of the projection (empty box = absent from the sort); null = sort all n
+    uint32_t* count;           // out: keys the first pass kept (n, or the band's survivors) = entries of depth_index
     uint32_t keys_per_block;
     uint32_t nblocks;
 };
@@ -95,7 +97,8 @@ struct BinGrid {
     int32_t W, H;
 };
 struct BinBuffers {
-    const uint32_t* depth_index; // n
+    const uint32_t* depth_index; // *count entries
+    const uint32_t* count;       // ranks to bin (SortBuffers::count)
     const uint2* bbox;           // n
     uint32_t* table;             // nblocks * nbins  (counts, then per-workgroup offsets inside each bin)
     uint2* blk_counts;           // nblocks: (visible splats, 16x16 tile overlaps) per counting workgroup

@@ -68,10 +68,11 @@ constexpr int CNT_THREADS = 1024;
 constexpr int CNT_STEPS = (int)BIN_RANKS_PER_BLOCK / CNT_THREADS;  // 2
 
 __global__ __launch_bounds__(CNT_THREADS) void k_bin_count(const uint32_t* __restrict__ depth_index,
-                                                           const uint2* __restrict__ bbox, uint32_t n, BinGrid g,
-                                                           uint32_t* __restrict__ table, uint2* __restrict__ blk_counts,
-                                                           uint32_t* __restrict__ rects)
+                                                           const uint2* __restrict__ bbox, const uint32_t* __restrict__ count,
+                                                           BinGrid g, uint32_t* __restrict__ table,
+                                                           uint2* __restrict__ blk_counts, uint32_t* __restrict__ rects)
 {
+    const uint32_t n = *count;  // ranks the sort produced (all splats, or the band's survivors)
     extern __shared__ uint32_t s_cnt[];  // nbins
     __shared__ uint32_t s_red[2 * (CNT_THREADS / WAVE)];
     const int nbxb = g.bx_hi - g.bx_lo, nbins = nbxb * g.nby;
@@ -263,13 +264,15 @@ constexpr int SCAT_STEPS_PER_WAVE = BIN_STEPS / SCAT_WAVES_PER_GROUP;  // 2
 static_assert(SCAT_GROUPS * BIN_STEPS * WAVE == (int)BIN_RANKS_PER_BLOCK, "scatter and count must cut the ranks alike");
 
 __global__ __launch_bounds__(SCAT_THREADS) void k_bin_scatter(const uint32_t* __restrict__ depth_index,
-                                                              const uint32_t* __restrict__ rects, uint32_t n, BinGrid g,
+                                                              const uint32_t* __restrict__ rects,
+                                                              const uint32_t* __restrict__ count, BinGrid g,
                                                               const uint32_t* __restrict__ table,
                                                               const uint32_t* __restrict__ bin_start,
                                                               uint32_t* __restrict__ list, uint32_t capacity,
                                                               uint32_t* __restrict__ overflow)
 {
     extern __shared__ uint32_t s_mem[];
+    const uint32_t n = *count;
     const int nbxb = g.bx_hi - g.bx_lo, nbins = nbxb * g.nby;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int group = wave / SCAT_WAVES_PER_GROUP, sub = wave % SCAT_WAVES_PER_GROUP;
@@ -363,7 +366,7 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
             (void)hipGetLastError();  // the launch below then reports the real failure
     }
     if (n) {
-        hipLaunchKernelGGL(k_bin_count, grid, dim3(CNT_THREADS), nbins * sizeof(uint32_t), s, b.depth_index, b.bbox, n, g, b.table,
+        hipLaunchKernelGGL(k_bin_count, grid, dim3(CNT_THREADS), nbins * sizeof(uint32_t), s, b.depth_index, b.bbox, b.count, g, b.table,
                            b.blk_counts, b.rects);
         hipLaunchKernelGGL(k_bin_scan, dim3((nbins + BIN_WAVES - 1) / BIN_WAVES), block, 0, s, b.table, b.bin_total, nbins,
                            b.nblocks);
@@ -372,7 +375,7 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
                        b.max_items, b.capacity, (const uint2*)b.blk_counts, n ? b.nblocks : 0u, b.bin_start, b.seg_start, b.items,
                        b.overflow, b.visible, b.tile_entries, b.accum);
     if (n)
-        hipLaunchKernelGGL(k_bin_scatter, grid, dim3(SCAT_THREADS), lds, s, b.depth_index, (const uint32_t*)b.rects, n, g, (const uint32_t*)b.table,
+        hipLaunchKernelGGL(k_bin_scatter, grid, dim3(SCAT_THREADS), lds, s, b.depth_index, (const uint32_t*)b.rects, b.count, g, (const uint32_t*)b.table,
                            (const uint32_t*)b.bin_start, b.list, b.capacity, b.overflow);
 }
 

@@ -40,12 +40,17 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t digit, bool valid)
 // ---------------------------------------------------------------------------
 // A2: q = (uint32)((float)(uint32)(depth - minDepth) * depthInv), plus the
 // workgroup histogram of the pass-1 digit.
+//
+// Band mode (multi-GPU, `bbox` != null): a splat whose projected box is empty for this context's band (culled, or
+// outside the band) gets the key 0xffffffff = "absent".  The first scatter drops absent keys, so everything after
+// it -- second radix pass, binning -- runs on the survivors only; their order is the restriction of the global
+// order, so the band's pixels are unchanged.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(SORT_THREADS) void k_quantise_hist(const int32_t* __restrict__ depth,
                                                                 const int32_t* __restrict__ minmax, uint32_t n,
-                                                                uint32_t keys_per_block, uint32_t* __restrict__ keys,
-                                                                uint32_t* __restrict__ block_hist,
-                                                                uint32_t* __restrict__ digit_total)
+                                                                uint32_t keys_per_block, const uint2* __restrict__ bbox,
+                                                                uint32_t* __restrict__ keys,
+                                                                uint32_t* __restrict__ block_hist)
 {
     __shared__ uint32_t h_lo[RADIX_LO_BINS];
     for (int d = threadIdx.x; d < RADIX_LO_BINS; d += SORT_THREADS) h_lo[d] = 0;
@@ -63,17 +68,23 @@ __global__ __launch_bounds__(SORT_THREADS) void k_quantise_hist(const int32_t* _
         const uint32_t rel = (uint32_t)depth[i] - (uint32_t)minDepth;
         uint32_t q = degenerate ? 0u : (uint32_t)((float)rel * depthInv);
         q = min(q, DEPTH_RANGE);
+        if (bbox) {
+            const uint32_t bx = bbox[i].x;
+            if ((bx & 0xffffu) > (bx >> 16)) q = 0xffffffffu;  // empty box: absent from this band's frame
+        }
         keys[i] = q;
-        atomicAdd(&h_lo[q & (RADIX_LO_BINS - 1)], 1u);
+        if (q != 0xffffffffu) atomicAdd(&h_lo[q & (RADIX_LO_BINS - 1)], 1u);
     }
     __syncthreads();
     for (int d = threadIdx.x; d < RADIX_LO_BINS; d += SORT_THREADS) block_hist[(size_t)blockIdx.x * RADIX_LO_BINS + d] = h_lo[d];
 }
 
 // Workgroup histogram of the pass-2 digit over the pass-1 output order.
-__global__ __launch_bounds__(SORT_THREADS) void k_hist_hi(const uint32_t* __restrict__ keys, uint32_t n,
+// (*count = keys the first pass kept: n, or the survivors in band mode)
+__global__ __launch_bounds__(SORT_THREADS) void k_hist_hi(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ count,
                                                           uint32_t keys_per_block, uint32_t* __restrict__ block_hist)
 {
+    const uint32_t n = *count;
     __shared__ uint32_t h[RADIX_HI_BINS];
     for (int d = threadIdx.x; d < RADIX_HI_BINS; d += SORT_THREADS) h[d] = 0;
     __syncthreads();
@@ -135,12 +146,16 @@ constexpr int SCAT_MAX_STEPS = 4;  // keys_per_block <= SCAT_THREADS * SCAT_MAX_
 
 template <int BITS, int SHIFT, bool FIRST>
 __global__ __launch_bounds__(SCAT_THREADS) void k_scatter(const uint32_t* __restrict__ keys_in,
-                                                          const uint32_t* __restrict__ idx_in, uint32_t n,
+                                                          const uint32_t* __restrict__ idx_in, uint32_t n_in,
+                                                          uint32_t* __restrict__ count,
                                                           uint32_t keys_per_block, const uint32_t* __restrict__ base,
                                                           const uint32_t* __restrict__ total,
                                                           uint32_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out)
 {
     constexpr int BINS = 1 << BITS;
+    // the first pass reads all n_in keys (absent ones are skipped) and publishes how many it kept;
+    // the second pass runs on that many
+    const uint32_t n = FIRST ? n_in : *count;
     __shared__ uint32_t cnt[SCAT_WAVES][BINS];
     __shared__ uint32_t dstart[BINS];          // keys with a smaller digit, all workgroups
     __shared__ uint32_t wsum[BINS / WAVE];
@@ -180,6 +195,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter(const uint32_t* __rest
         uint32_t run = incl - tot;
         for (int w = 0; w < wave; w++) run += wsum[w];
         dstart[threadIdx.x] = run;
+        if (FIRST && blockIdx.x == 0 && threadIdx.x == BINS - 1) *count = run + tot;
     }
     __syncthreads();
     // phase 2: cnt[w][d] <- first destination of digit d for this workgroup + counts of earlier waves
@@ -226,18 +242,19 @@ void launch_sort(const SortBuffers& b, uint32_t n, hipStream_t s)
     const dim3 grid(b.nblocks), block(SORT_THREADS);
     uint32_t* total_lo = b.digit_total;
     uint32_t* total_hi = b.digit_total + RADIX_LO_BINS;
-    hipLaunchKernelGGL(k_quantise_hist, grid, block, 0, s, b.depth, b.minmax, n, b.keys_per_block, b.keys, b.block_hist,
-                       b.digit_total);
+    hipLaunchKernelGGL(k_quantise_hist, grid, block, 0, s, b.depth, b.minmax, n, b.keys_per_block, b.cull_bbox, b.keys,
+                       b.block_hist);
     hipLaunchKernelGGL(k_digit_scan, dim3(RADIX_LO_BINS / SORT_WAVES), block, 0, s, b.block_hist, total_lo, RADIX_LO_BINS,
                        b.nblocks);
     hipLaunchKernelGGL((k_scatter<RADIX_LO_BITS, 0, true>), grid, dim3(SCAT_THREADS), 0, s, (const uint32_t*)b.keys,
-                       (const uint32_t*)nullptr, n, b.keys_per_block, (const uint32_t*)b.block_hist,
+                       (const uint32_t*)nullptr, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
                        (const uint32_t*)total_lo, b.keys_tmp, b.idx_tmp);
-    hipLaunchKernelGGL(k_hist_hi, grid, block, 0, s, (const uint32_t*)b.keys_tmp, n, b.keys_per_block, b.block_hist);
+    hipLaunchKernelGGL(k_hist_hi, grid, block, 0, s, (const uint32_t*)b.keys_tmp, (const uint32_t*)b.count, b.keys_per_block,
+                       b.block_hist);
     hipLaunchKernelGGL(k_digit_scan, dim3(RADIX_HI_BINS / SORT_WAVES), block, 0, s, b.block_hist, total_hi, RADIX_HI_BINS,
                        b.nblocks);
     hipLaunchKernelGGL((k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, false>), grid, dim3(SCAT_THREADS), 0, s, (const uint32_t*)b.keys_tmp,
-                       (const uint32_t*)b.idx_tmp, n, b.keys_per_block, (const uint32_t*)b.block_hist,
+                       (const uint32_t*)b.idx_tmp, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
                        (const uint32_t*)total_hi, (uint32_t*)nullptr, b.depth_index);
 }
 

@@ -182,7 +182,11 @@ def test_band_split_equals_full_frame(gh, oracle, scenes):
     parts = np.zeros_like(full)
     edges = [0, 192, 320, 512, W]
     for x0, x1 in zip(edges[:-1], edges[1:]):
-        part = _render_pair(gh, oracle, data, pos, cam, W, H, band=(x0, x1))[0]
+        part, _, di, st, _, odi, V, _ = _render_pair(gh, oracle, data, pos, cam, W, H, band=(x0, x1))
+        # a band context sorts and bins only the splats whose box touches the band (survivors); the whole
+        # permutation is still available on demand and is the reference's
+        assert np.array_equal(di, odi)
+        assert 0 < st["visible"] < V
         assert not part[:, :x0].any() and not part[:, x1:].any()
         parts[:, x0:x1] = part[:, x0:x1]
     assert np.array_equal(parts, full)
