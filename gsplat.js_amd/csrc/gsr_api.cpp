@@ -30,6 +30,7 @@ struct FrameState {  // small per-frame device words, (re)initialised by one mem
     uint64_t tile_entries;
     uint32_t digit_total[RADIX_LO_BINS + RADIX_HI_BINS];
     uint32_t sorted_count;  // entries of depth_index: n, or the band's survivors (SortBuffers::count)
+    uint32_t seg_len;       // the frame's compositor segment length (k_bin_finalize -> k_blend)
 };
 
 }  // namespace
@@ -69,6 +70,7 @@ struct gsr_ctx {
     float4* partial = nullptr;
     uint32_t bin_blocks = 0, bin_capacity = 0, bin_table_elems = 0, bin_nbins_alloc = 0, blk_counts_alloc = 0;
     uint32_t max_items = 0, seg_len = 0, blend_grid = 2048;
+    uint32_t seg_target_items = 5000;
     bool sort_culled = false;  // the last sort kept only the band's survivors (depth_index / keys are partial)
     // frame words
     FrameState* fstate = nullptr;       // device
@@ -189,6 +191,10 @@ int alloc_bins(gsr_ctx* c)
     const bool throughput = (c->opt.flags & GSR_FLAG_THROUGHPUT) != 0;
     c->seg_len = c->opt.early_out_eps > 0.0f ? SEG_LEN_WHOLE_BIN : throughput ? SEG_LEN_THROUGHPUT : SEG_LEN_EXACT;
     c->blend_grid = throughput ? BLEND_GRID_THROUGHPUT : BLEND_GRID_EXACT;
+    if (const char* e = getenv("GSR_SEG_TARGET")) {  // tuning knob: full segments a frame is cut into at least
+        const long v = atol(e);
+        if (v >= 1) c->seg_target_items = (uint32_t)v;
+    }
     if (const char* e = getenv("GSR_BLEND_GRID")) {  // tuning knob: persistent compositor workgroups
         const long v = atol(e);
         if (v >= 1) c->blend_grid = (uint32_t)v;
@@ -267,11 +273,11 @@ int enqueue_frame(gsr_ctx* c, bool render)
         if (!c->n) HIP_TRY(c, hipMemsetAsync(c->bin_total, 0, sizeof(uint32_t) * nbins, s));
         BinBuffers bb{c->depth_index, &c->fstate->sorted_count, c->bbox, c->bin_table, c->blk_counts, c->bin_rects, c->bin_total, c->bin_start, c->seg_start,
                       c->items, c->bin_list, &c->fstate->overflow, &c->fstate->visible, &c->fstate->tile_entries,
-                      c->accum, c->bin_capacity, c->max_items, c->seg_len, c->bin_blocks};
+                      c->accum, c->bin_capacity, c->max_items, c->seg_len, &c->fstate->seg_len, c->seg_target_items, c->bin_blocks};
         launch_bin(bb, g, c->n, s);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BIN], s));
         BlendBuffers bl{c->items, c->seg_start, c->bin_start, c->bin_list, c->rec, c->bbox, c->shcol, c->fb, c->partial,
-                        &c->fstate->queue, c->seg_len, std::min<uint32_t>(c->max_items, c->blend_grid), c->bin_capacity,
+                        &c->fstate->queue, c->seg_len, &c->fstate->seg_len, std::min<uint32_t>(c->max_items, c->blend_grid), c->bin_capacity,
                         std::max(c->n, 1u)};
         launch_blend(bl, g, c->opt.early_out_eps, s, timing ? c->ev[EV_BLEND] : nullptr);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_COMBINE], s));

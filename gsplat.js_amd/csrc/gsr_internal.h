@@ -90,6 +90,8 @@ struct SortBuffers {
     uint32_t nblocks;
 };
 void launch_sort(const SortBuffers& b, uint32_t n, hipStream_t s);
+// column scan (k_sort.hip), shared with the binning
+void launch_column_scan(uint32_t* table, uint32_t* total, int ncols, uint32_t nrows, hipStream_t s);
 
 struct BinGrid {
     int32_t nbx, nby;          // bins across / down the whole image
@@ -114,7 +116,10 @@ struct BinBuffers {
     uint64_t* accum;             // [5] running sums over frames: visible, bin entries, tile entries, frames; [4] = entries the last frame needs
     uint32_t capacity;
     uint32_t max_items;
-    uint32_t seg_len;            // list entries per compositor work item (multiple of 256)
+    uint32_t seg_len;            // minimum list entries per compositor work item (multiple of 256); k_bin_finalize
+                                 // raises it for long lists and publishes the frame's value in *seg_len_dev
+    uint32_t* seg_len_dev;
+    uint32_t seg_target_items;   // full segments the frame should be cut into at least (long lists -> longer segments)
     uint32_t nblocks;
 };
 void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s);
@@ -130,7 +135,8 @@ struct BlendBuffers {
     float4* fb;
     float4* partial;            // max_items * 1024 float4: per-segment (colour, transmittance), slot = seg_start[bin] + segment
     uint32_t* queue;            // device-wide work-item counter, zero at frame start
-    uint32_t seg_len;           // >= 0x40000000: one item per bin (early termination mode)
+    uint32_t seg_len;           // host's minimum; >= 0x40000000: one item per bin (early termination mode)
+    const uint32_t* seg_len_dev; // the frame's segment length (k_bin_finalize)
     uint32_t grid;              // persistent workgroups launched
     uint32_t capacity;          // entries the list can hold
     uint32_t nsplats;

@@ -21,7 +21,6 @@
 namespace gsr {
 
 constexpr int BIN_THREADS = 256;
-constexpr int BIN_WAVES = BIN_THREADS / WAVE;
 constexpr int BIN_STEPS = 8;                                  // 64-rank steps per wave
 constexpr uint32_t BIN_RANKS_PER_BLOCK = BIN_THREADS * BIN_STEPS;  // 2048
 
@@ -66,17 +65,21 @@ __device__ __forceinline__ uint32_t lanes_below64(uint64_t mask)
 // ---------------------------------------------------------------------------
 constexpr int CNT_THREADS = 1024;
 constexpr int CNT_STEPS = (int)BIN_RANKS_PER_BLOCK / CNT_THREADS;  // 2
+constexpr int CNT_MAX_BINS = 12288;  // LDS counters per workgroup (48 KiB); larger grids are cut into row slices (blockIdx.y)
 
 __global__ __launch_bounds__(CNT_THREADS) void k_bin_count(const uint32_t* __restrict__ depth_index,
                                                            const uint2* __restrict__ bbox, const uint32_t* __restrict__ count,
-                                                           BinGrid g, uint32_t* __restrict__ table,
+                                                           BinGrid g, int slice_rows, uint32_t* __restrict__ table,
                                                            uint2* __restrict__ blk_counts, uint32_t* __restrict__ rects)
 {
     const uint32_t n = *count;  // ranks the sort produced (all splats, or the band's survivors)
-    extern __shared__ uint32_t s_cnt[];  // nbins
+    extern __shared__ uint32_t s_cnt[];  // this slice's bins
     __shared__ uint32_t s_red[2 * (CNT_THREADS / WAVE)];
     const int nbxb = g.bx_hi - g.bx_lo, nbins = nbxb * g.nby;
-    for (int b = threadIdx.x; b < nbins; b += CNT_THREADS) s_cnt[b] = 0;
+    const int y_lo = blockIdx.y * slice_rows, y_hi = min(y_lo + slice_rows, g.nby);  // bin rows of this slice
+    const int nb_s = (y_hi - y_lo) * nbxb;
+    const bool first = blockIdx.y == 0;  // slice 0 also leaves the rectangles and the frame counters
+    for (int b = threadIdx.x; b < nb_s; b += CNT_THREADS) s_cnt[b] = 0;
     __syncthreads();
     const uint32_t begin = blockIdx.x * BIN_RANKS_PER_BLOCK;
     uint32_t vis = 0, tiles = 0;
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(CNT_THREADS) void k_bin_count(const uint32_t* __res
     for (int st = 0; st < CNT_STEPS; st++) {
         const uint2 bb = bbs[st];
         const BinRect br = bin_rect(bb, g);
-        {
+        if (first) {
             const uint32_t r = begin + st * CNT_THREADS + threadIdx.x;
             if (r < n) rects[r] = pack_rect(br);
         }
@@ -103,8 +106,8 @@ __global__ __launch_bounds__(CNT_THREADS) void k_bin_count(const uint32_t* __res
             const int tx0 = max((int)(bb.x & 0xffff) / TILE, g.bx_lo * BIN_TILES);
             const int tx1 = min((int)(bb.x >> 16) / TILE, g.bx_hi * BIN_TILES - 1);
             tiles += (uint32_t)((tx1 - tx0 + 1) * ((int)(bb.y >> 16) / TILE - (int)(bb.y & 0xffff) / TILE + 1));
-            for (int y = br.y0; y <= br.y1; y++)
-                for (int x = br.x0; x <= br.x1; x++) atomicAdd(&s_cnt[y * nbxb + x], 1u);
+            for (int y = max(br.y0, y_lo); y <= min(br.y1, y_hi - 1); y++)
+                for (int x = br.x0; x <= br.x1; x++) atomicAdd(&s_cnt[(y - y_lo) * nbxb + x], 1u);
         }
     }
 #pragma unroll
@@ -115,50 +118,15 @@ __global__ __launch_bounds__(CNT_THREADS) void k_bin_count(const uint32_t* __res
     constexpr int NW = CNT_THREADS / WAVE;
     if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6] = vis; s_red[NW + (threadIdx.x >> 6)] = tiles; }
     __syncthreads();
-    for (int b = threadIdx.x; b < nbins; b += CNT_THREADS) table[(size_t)blockIdx.x * nbins + b] = s_cnt[b];
-    if (threadIdx.x == 0) {
+    for (int b = threadIdx.x; b < nb_s; b += CNT_THREADS) table[(size_t)blockIdx.x * nbins + y_lo * nbxb + b] = s_cnt[b];
+    if (first && threadIdx.x == 0) {
         uint32_t v = 0, t = 0;
         for (int w = 0; w < NW; w++) { v += s_red[w]; t += s_red[NW + w]; }
         blk_counts[blockIdx.x] = make_uint2(v, t);
     }
 }
 
-// ---------------------------------------------------------------------------
-// scan: one wave per bin: table[block][bin] <- entries of earlier workgroups in this bin;
-// bin_total[bin] = the bin's entry count.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(BIN_THREADS) void k_bin_scan(uint32_t* __restrict__ table, uint32_t* __restrict__ bin_total,
-                                                          int nbins, uint32_t nblocks)
-{
-    const int lane = threadIdx.x & 63;
-    const int bin = blockIdx.x * BIN_WAVES + (threadIdx.x >> 6);
-    if (bin >= nbins) return;
-    // One wave per column: lane l takes rows l, l+64, ...  The strided loads of a batch are issued together
-    // (independent), then scanned; doing them one at a time made this kernel a chain of L2 round trips.
-    constexpr int BATCH = 8;
-    uint32_t run = 0;
-    for (uint32_t b0 = 0; b0 < nblocks; b0 += BATCH * WAVE) {
-        uint32_t v[BATCH];
-#pragma unroll
-        for (int k = 0; k < BATCH; k++) {
-            const uint32_t b = b0 + k * WAVE + lane;
-            v[k] = (b < nblocks) ? table[(size_t)b * nbins + bin] : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < BATCH; k++) {
-            const uint32_t b = b0 + k * WAVE + lane;
-            uint32_t incl = v[k];
-#pragma unroll
-            for (int off = 1; off < WAVE; off <<= 1) {
-                const uint32_t t = __shfl_up(incl, off);
-                if (lane >= off) incl += t;
-            }
-            if (b < nblocks) table[(size_t)b * nbins + bin] = run + incl - v[k];
-            run += __shfl(incl, WAVE - 1);
-        }
-    }
-    if (lane == 0) bin_total[bin] = run;
-}
+// (the scan of table[block][bin] down the blocks, and bin_total[], is launch_column_scan of k_sort.hip)
 
 // ---------------------------------------------------------------------------
 // finalize (one workgroup): bin_start = exclusive scan of bin_total; the compositor's work items
@@ -167,86 +135,131 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_scan(uint32_t* __restrict__
 constexpr int FIN_THREADS = 1024;
 constexpr int FIN_WAVES = FIN_THREADS / WAVE;
 
-struct U3 { uint32_t a, b, c; };
+// exclusive scan of N independent u32 streams over the workgroup's FIN_THREADS threads; totals in *tot
+template <int N> struct UN { uint32_t v[N]; };
 
-// exclusive scan of three independent u32 streams over the workgroup's FIN_THREADS threads; totals in *tot
-__device__ __forceinline__ U3 block_exclusive_scan3(U3 v, uint32_t (*s_w)[FIN_WAVES], U3* tot)
+template <int N>
+__device__ __forceinline__ UN<N> block_exclusive_scan(UN<N> x, uint32_t (*s_w)[FIN_WAVES], UN<N>* tot)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    U3 inc = v;
+    UN<N> inc = x;
 #pragma unroll
     for (int off = 1; off < WAVE; off <<= 1) {
-        const uint32_t ta = __shfl_up(inc.a, off), tb = __shfl_up(inc.b, off), tc = __shfl_up(inc.c, off);
-        if (lane >= off) { inc.a += ta; inc.b += tb; inc.c += tc; }
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const uint32_t t = __shfl_up(inc.v[k], off);
+            if (lane >= off) inc.v[k] += t;
+        }
     }
-    if (lane == WAVE - 1) { s_w[0][wave] = inc.a; s_w[1][wave] = inc.b; s_w[2][wave] = inc.c; }
+    if (lane == WAVE - 1) {
+#pragma unroll
+        for (int k = 0; k < N; k++) s_w[k][wave] = inc.v[k];
+    }
     __syncthreads();
-    U3 base = {0, 0, 0}, total = {0, 0, 0};
+    UN<N> base, total;
+#pragma unroll
+    for (int k = 0; k < N; k++) { base.v[k] = 0; total.v[k] = 0; }
 #pragma unroll
     for (int w = 0; w < FIN_WAVES; w++) {
-        const uint32_t xa = s_w[0][w], xb = s_w[1][w], xc = s_w[2][w];
-        if (w < wave) { base.a += xa; base.b += xb; base.c += xc; }
-        total.a += xa; total.b += xb; total.c += xc;
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const uint32_t t = s_w[k][w];
+            if (w < wave) base.v[k] += t;
+            total.v[k] += t;
+        }
     }
     __syncthreads();
     *tot = total;
-    return U3{base.a + inc.a - v.a, base.b + inc.b - v.b, base.c + inc.c - v.c};
+    UN<N> ex;
+#pragma unroll
+    for (int k = 0; k < N; k++) ex.v[k] = base.v[k] + inc.v[k] - x.v[k];
+    return ex;
 }
 
+// Long lists raise the segment length: the compositor needs a few thousand work items to fill the chip, not one
+// per 512 entries; every extra segment costs a 16 KiB partial written by k_blend and read by k_combine.
+constexpr uint32_t SEG_LEN_MAX = 8192;
+
+// size class of a bin's last (partial) segment of r entries: 1: >= 1/2 segment, 2: >= 1/4, 3: the rest (and empty bins)
+__device__ __forceinline__ int partial_class(uint32_t r, uint32_t seg_len) { return r >= seg_len / 2 ? 1 : r >= seg_len / 4 ? 2 : 3; }
+
 __global__ __launch_bounds__(FIN_THREADS) void k_bin_finalize(const uint32_t* __restrict__ bin_total, int nbins,
-                                                              uint32_t seg_len, uint32_t max_items, uint32_t capacity,
+                                                              uint32_t seg_len_min, uint32_t seg_target_items,
+                                                              uint32_t* __restrict__ seg_len_out, uint32_t max_items, uint32_t capacity,
                                                               const uint2* __restrict__ blk_counts, uint32_t nblocks,
                                                               uint32_t* __restrict__ bin_start,
                                                               uint32_t* __restrict__ seg_start, uint32_t* __restrict__ items,
                                                               uint32_t* __restrict__ overflow, uint64_t* __restrict__ visible,
                                                               uint64_t* __restrict__ tile_entries, uint64_t* __restrict__ accum)
 {
-    __shared__ uint32_t s_w[3][FIN_WAVES];
+    __shared__ uint32_t s_w[5][FIN_WAVES];
     const int per = (nbins + FIN_THREADS - 1) / FIN_THREADS;
     const int b0 = threadIdx.x * per, b1 = min(b0 + per, nbins);
-    // Items are emitted heaviest first: every full segment (seg_len entries) before every partial or
-    // empty one, so the compositor's queue hands out the long items while the chip is still full.
-    U3 mine = {0, 0, 0};  // entries, segments, full segments of this thread's bins
+    UN<1> ent = {{0}}, ent_tot;
+    for (int b = b0; b < b1; b++) ent.v[0] += bin_total[b];
+    block_exclusive_scan<1>(ent, s_w, &ent_tot);
+    // segment length of this frame (a multiple of 256; the whole-bin sentinel of early termination passes through)
+    uint32_t seg_len = seg_len_min;
+    if (seg_len_min < 0x40000000u)
+        seg_len = min(max(ent_tot.v[0] / seg_target_items / 256u * 256u, seg_len_min), max(SEG_LEN_MAX, seg_len_min));
+    // Items are emitted heaviest first -- every full segment, then the bins' last segments by size class --
+    // so the compositor's queue hands out the long items while the chip is still full and only short
+    // ones are left for the tail.  Streams: entries, segments, full segments, class-1 and class-2 partials.
+    UN<5> mine = {{0, 0, 0, 0, 0}};
     for (int b = b0; b < b1; b++) {
         const uint32_t c = bin_total[b];
-        mine.a += c;
-        mine.b += max(1u, (c + seg_len - 1) / seg_len);
-        mine.c += c / seg_len;
+        const uint32_t nf = c / seg_len, r = c - nf * seg_len;
+        mine.v[0] += c;
+        mine.v[1] += nf + ((r || !nf) ? 1u : 0u);
+        mine.v[2] += nf;
+        if (r || !nf) {
+            const int cl = partial_class(r, seg_len);
+            mine.v[3] += cl == 1;
+            mine.v[4] += cl == 2;
+        }
     }
-    U3 tot;
-    const U3 ex3 = block_exclusive_scan3(mine, s_w, &tot);
-    uint32_t ex = ex3.a, sx = ex3.b, fx = ex3.c;
-    uint32_t px = tot.c + (sx - fx);  // partial/empty items follow all full ones
+    UN<5> tot;
+    const UN<5> ex5 = block_exclusive_scan<5>(mine, s_w, &tot);
+    uint32_t ex = ex5.v[0], sx = ex5.v[1], fx = ex5.v[2];
+    uint32_t p1 = tot.v[2] + ex5.v[3];                                        // class 1 follows all full items
+    uint32_t p2 = tot.v[2] + tot.v[3] + ex5.v[4];                             // then class 2
+    uint32_t p3 = tot.v[2] + tot.v[3] + tot.v[4] + (sx - fx - ex5.v[3] - ex5.v[4]);  // then the rest
     // A frame whose lists do not fit (entries > capacity or items > max_items) must not be composited:
     // it publishes no work items at all (every index the compositor derives stays in range), raises the
     // overflow word, and the host regrows the buffers and renders the frame again (gsr_sync).
-    const bool fits = tot.a <= capacity && tot.b <= max_items;
+    const bool fits = tot.v[0] <= capacity && tot.v[1] <= max_items;
     for (int b = b0; b < b1; b++) {
         const uint32_t c = bin_total[b];
-        const uint32_t ns = max(1u, (c + seg_len - 1) / seg_len);
-        const uint32_t nf = c / seg_len;
+        const uint32_t nf = c / seg_len, r = c - nf * seg_len;
+        const bool part = r || !nf;
         bin_start[b] = fits ? ex : 0u;
         seg_start[b] = fits ? sx : 0u;
-        if (fits)
-            for (uint32_t k = 0; k < ns; k++) items[(k < nf) ? fx + k : px + (k - nf)] = (uint32_t)b | (k << 16);
+        if (fits) {
+            for (uint32_t k = 0; k < nf; k++) items[fx + k] = (uint32_t)b | (k << 16);
+            if (part) {
+                const int cl = partial_class(r, seg_len);
+                uint32_t& pos = cl == 1 ? p1 : cl == 2 ? p2 : p3;
+                items[pos++] = (uint32_t)b | (nf << 16);
+            }
+        }
         ex += c;
-        sx += ns;
+        sx += nf + (part ? 1u : 0u);
         fx += nf;
-        px += ns - nf;
     }
     // frame counters
-    U3 cnt = {0, 0, 0};
-    for (uint32_t b = threadIdx.x; b < nblocks; b += FIN_THREADS) { cnt.a += blk_counts[b].x; cnt.b += blk_counts[b].y; }
-    U3 ctot;
-    block_exclusive_scan3(cnt, s_w, &ctot);
+    UN<2> cnt = {{0, 0}};
+    for (uint32_t b = threadIdx.x; b < nblocks; b += FIN_THREADS) { cnt.v[0] += blk_counts[b].x; cnt.v[1] += blk_counts[b].y; }
+    UN<2> ctot;
+    block_exclusive_scan<2>(cnt, s_w, &ctot);
     if (threadIdx.x == 0) {
-        bin_start[nbins] = fits ? tot.a : 0u;
-        seg_start[nbins] = fits ? tot.b : 0u;
-        if (!fits) atomicOr(overflow, tot.a > capacity ? 1u : 2u);
-        accum[4] = tot.a;  // entries this frame needs (the host sizes the regrowth from it)
-        *visible = ctot.a;
-        *tile_entries = ctot.b;
-        accum[0] += ctot.a; accum[1] += tot.a; accum[2] += ctot.b; accum[3] += 1;
+        *seg_len_out = seg_len;
+        bin_start[nbins] = fits ? tot.v[0] : 0u;
+        seg_start[nbins] = fits ? tot.v[1] : 0u;
+        if (!fits) atomicOr(overflow, tot.v[0] > capacity ? 1u : 2u);
+        accum[4] = tot.v[0];  // entries this frame needs (the host sizes the regrowth from it)
+        *visible = ctot.v[0];
+        *tile_entries = ctot.v[1];
+        accum[0] += ctot.v[0]; accum[1] += tot.v[0]; accum[2] += ctot.v[1]; accum[3] += 1;
     }
 }
 
@@ -262,10 +275,35 @@ constexpr int SCAT_GROUPS = 4;                       // rank groups per workgrou
 constexpr int SCAT_WAVES_PER_GROUP = 4;
 constexpr int SCAT_STEPS_PER_WAVE = BIN_STEPS / SCAT_WAVES_PER_GROUP;  // 2
 static_assert(SCAT_GROUPS * BIN_STEPS * WAVE == (int)BIN_RANKS_PER_BLOCK, "scatter and count must cut the ranks alike");
+// Framebuffers above 4K: the LDS tables (12 B per bin + the lane sets) outgrow a CU's 160 KiB, so the bin grid is cut
+// into the fewest sub-grids that fit and blockIdx.y picks the sub-grid.  Every sub-grid workgroup reads the same
+// 2048 rectangles and places the entries of its own bins.  Up to 4K (8160 bins, 146 KiB) there is one sub-grid:
+// cutting earlier was measured slower (C4: 0.50 -> 0.66 ms for the binning), the per-workgroup fixed work dominates.
+constexpr size_t SCAT_LDS_BUDGET = 150 * 1024;
+
+struct BinSlices { int32_t sx, sy, w, h; };  // sx x sy sub-grids of w x h bins (the last ones may be smaller)
+
+inline size_t scatter_lds_bytes(int w, int h)
+{
+    return (size_t)((3 * w * h + 1) & ~1) * 4 + (size_t)SCAT_GROUPS * BIN_STEPS * (w + h) * 8;
+}
+
+inline BinSlices make_slices(int nbxb, int nby)
+{
+    for (int t = 1;; t++)
+        for (int sx = 1; sx <= t; sx++) {
+            if (t % sx) continue;
+            BinSlices sl;
+            sl.sx = sx; sl.sy = t / sx;
+            sl.w = (nbxb + sl.sx - 1) / sl.sx;
+            sl.h = (nby + sl.sy - 1) / sl.sy;
+            if (scatter_lds_bytes(sl.w, sl.h) <= SCAT_LDS_BUDGET) return sl;
+        }
+}
 
 __global__ __launch_bounds__(SCAT_THREADS) void k_bin_scatter(const uint32_t* __restrict__ depth_index,
                                                               const uint32_t* __restrict__ rects,
-                                                              const uint32_t* __restrict__ count, BinGrid g,
+                                                              const uint32_t* __restrict__ count, BinGrid g, BinSlices sl,
                                                               const uint32_t* __restrict__ table,
                                                               const uint32_t* __restrict__ bin_start,
                                                               uint32_t* __restrict__ list, uint32_t capacity,
@@ -276,22 +314,27 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_bin_scatter(const uint32_t* __
     const int nbxb = g.bx_hi - g.bx_lo, nbins = nbxb * g.nby;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int group = wave / SCAT_WAVES_PER_GROUP, sub = wave % SCAT_WAVES_PER_GROUP;
-    // LDS: base[nbins] (u32: the workgroup's first slot in each bin), pair[2][nbins] (two 16-bit per-group
+    // this workgroup's sub-grid: bin columns [sx0, sx1), rows [sy0, sy1) of the band
+    const int sx0 = (int)(blockIdx.y % sl.sx) * sl.w, sx1 = min(sx0 + sl.w, nbxb);
+    const int sy0 = (int)(blockIdx.y / sl.sx) * sl.h, sy1 = min(sy0 + sl.h, g.nby);
+    const int sw = sx1 - sx0, sh = sy1 - sy0, nb_s = sw * sh;
+    // LDS: base[nb_s] (u32: the workgroup's first slot in each bin), pair[2][nb_s] (two 16-bit per-group
     // counts/offsets per word: groups 0|1 and 2|3; a group holds 512 ranks, so 16 bits suffice), then the
-    // lane sets: per group, per step: [nbxb] column words + [nby] row words.
+    // lane sets: per group, per step: [sw] column words + [sh] row words.  Sized for a full sl.w x sl.h sub-grid.
+    const int cap_s = sl.w * sl.h;
     uint32_t* base = s_mem;
-    uint32_t* pair = s_mem + nbins;
-    const int nmask = nbxb + g.nby;
-    unsigned long long* masks = reinterpret_cast<unsigned long long*>(s_mem + ((3 * nbins + 1) & ~1));
+    uint32_t* pair = s_mem + cap_s;
+    const int nmask = sl.w + sl.h;
+    unsigned long long* masks = reinterpret_cast<unsigned long long*>(s_mem + ((3 * cap_s + 1) & ~1));
     unsigned long long* gmask = masks + (size_t)group * BIN_STEPS * nmask;   // step s of my group: gmask + s*nmask
-    uint32_t* mypair = pair + (size_t)(group >> 1) * nbins;
+    uint32_t* mypair = pair + (size_t)(group >> 1) * cap_s;
     const int myshift = (group & 1) * 16;
 
-    for (int b = threadIdx.x; b < 2 * nbins; b += SCAT_THREADS) pair[b] = 0;
+    for (int b = threadIdx.x; b < 2 * cap_s; b += SCAT_THREADS) pair[b] = 0;
     for (int b = threadIdx.x; b < SCAT_GROUPS * BIN_STEPS * nmask; b += SCAT_THREADS) masks[b] = 0;
     __syncthreads();
 
-    // this wave's 2 steps of 64 consecutive ranks
+    // this wave's 2 steps of 64 consecutive ranks; rectangles clipped to the sub-grid, in sub-grid coordinates
     const uint32_t gbegin = blockIdx.x * BIN_RANKS_PER_BLOCK + group * (BIN_STEPS * WAVE);
     uint32_t idx[SCAT_STEPS_PER_WAVE];
     BinRect br[SCAT_STEPS_PER_WAVE];
@@ -303,7 +346,13 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_bin_scatter(const uint32_t* __
 #pragma unroll
     for (int k = 0; k < SCAT_STEPS_PER_WAVE; k++) {
         const uint32_t r = gbegin + (sub * SCAT_STEPS_PER_WAVE + k) * WAVE + lane;
-        br[k] = unpack_rect((r < n) ? rects[r] : 1u);
+        BinRect b = unpack_rect((r < n) ? rects[r] : 1u);
+        if (b.x0 <= b.x1) {
+            b.x0 = max(b.x0, sx0) - sx0; b.x1 = min(b.x1, sx1 - 1) - sx0;
+            b.y0 = max(b.y0, sy0) - sy0; b.y1 = min(b.y1, sy1 - 1) - sy0;
+            if (b.x0 > b.x1 || b.y0 > b.y1) { b.x0 = 1; b.x1 = 0; b.y0 = 1; b.y1 = 0; }
+        }
+        br[k] = b;
     }
     // phase 1: per-group counts, and every lane ORs its bit into the column/row lane sets of its box
     const uint32_t one = 1u << myshift;
@@ -312,21 +361,23 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_bin_scatter(const uint32_t* __
     for (int k = 0; k < SCAT_STEPS_PER_WAVE; k++) {
         const BinRect b = br[k];
         unsigned long long* colm = gmask + (sub * SCAT_STEPS_PER_WAVE + k) * nmask;
-        unsigned long long* rowm = colm + nbxb;
+        unsigned long long* rowm = colm + sl.w;
         for (int x = b.x0; x <= b.x1; x++) atomicOr(&colm[x], mybit);
         for (int y = b.y0; y <= b.y1; y++) {
             if (b.x0 <= b.x1) atomicOr(&rowm[y], mybit);
-            for (int x = b.x0; x <= b.x1; x++) atomicAdd(&mypair[y * nbxb + x], one);
+            for (int x = b.x0; x <= b.x1; x++) atomicAdd(&mypair[y * sw + x], one);
         }
     }
     __syncthreads();
     // phase 2: counts -> offsets of each group inside the workgroup's run; workgroup base from the table
-    for (int b = threadIdx.x; b < nbins; b += SCAT_THREADS) {
-        base[b] = bin_start[b] + table[(size_t)blockIdx.x * nbins + b];
-        const uint32_t c01 = pair[b], c23 = pair[nbins + b];
+    for (int b = threadIdx.x; b < nb_s; b += SCAT_THREADS) {
+        const int ly = b / sw, lx = b - ly * sw;
+        const int gb = (sy0 + ly) * nbxb + sx0 + lx;  // the bin's index in the band
+        base[b] = bin_start[gb] + table[(size_t)blockIdx.x * nbins + gb];
+        const uint32_t c01 = pair[b], c23 = pair[cap_s + b];
         const uint32_t o1 = c01 & 0xffffu, o2 = o1 + (c01 >> 16), o3 = o2 + (c23 & 0xffffu);
         pair[b] = o1 << 16;                // group 0: 0, group 1: o1
-        pair[nbins + b] = o2 | (o3 << 16); // group 2: o2, group 3: o3
+        pair[cap_s + b] = o2 | (o3 << 16); // group 2: o2, group 3: o3
     }
     __syncthreads();
     // phase 3: slots.  The set of lanes of step s covering bin (X,Y) is col[s][X] & row[s][Y]; a splat's slot is
@@ -340,10 +391,10 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_bin_scatter(const uint32_t* __
         const uint32_t myidx = idx[k];
         for (int y = b.y0; y <= b.y1; y++) {
             for (int x = b.x0; x <= b.x1; x++) {
-                uint32_t dst = base[y * nbxb + x] + ((mypair[y * nbxb + x] >> myshift) & 0xffffu);
+                uint32_t dst = base[y * sw + x] + ((mypair[y * sw + x] >> myshift) & 0xffffu);
                 for (int e = 0; e < st; e++)  // entries the earlier steps of this group put into the bin
-                    dst += (uint32_t)__popcll(gmask[e * nmask + x] & gmask[e * nmask + nbxb + y]);
-                dst += lanes_below64(gmask[st * nmask + x] & gmask[st * nmask + nbxb + y]);
+                    dst += (uint32_t)__popcll(gmask[e * nmask + x] & gmask[e * nmask + sl.w + y]);
+                dst += lanes_below64(gmask[st * nmask + x] & gmask[st * nmask + sl.w + y]);
                 if (dst < capacity) list[dst] = myidx;
                 else atomicOr(overflow, 1u);
             }
@@ -355,9 +406,9 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
 {
     const int nbxb = g.bx_hi - g.bx_lo, nbins = nbxb * g.nby;
     if (nbins <= 0) return;
-    const dim3 grid(b.nblocks), block(BIN_THREADS);
-    const size_t lds = (size_t)((3 * nbins + 1) & ~1) * 4 + (size_t)SCAT_GROUPS * BIN_STEPS * (nbxb + g.nby) * 8;
-    // dynamic LDS above the 64 KiB default needs the attribute raised (4K: 8160 bins -> ~146 KiB).  Set per call:
+    const BinSlices sl = make_slices(nbxb, g.nby);
+    const size_t lds = scatter_lds_bytes(sl.w, sl.h);
+    // dynamic LDS above the 64 KiB default needs the attribute raised (4K: 8160 bins -> 146 KiB).  Set per call:
     // the attribute belongs to the current device's copy of the kernel, and this is off the per-frame fast path
     // (1080p needs 49 KiB).
     if (lds > 60 * 1024) {
@@ -365,18 +416,22 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
         if (hipFuncSetAttribute((const void*)k_bin_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess)
             (void)hipGetLastError();  // the launch below then reports the real failure
     }
+    // the count pass keeps one counter per bin in LDS and is cut into row slices only beyond 12288 bins (above 4K)
+    const int cnt_slices = (nbins + CNT_MAX_BINS - 1) / CNT_MAX_BINS;
+    const int cnt_rows = (g.nby + cnt_slices - 1) / cnt_slices;
     if (n) {
-        hipLaunchKernelGGL(k_bin_count, grid, dim3(CNT_THREADS), nbins * sizeof(uint32_t), s, b.depth_index, b.bbox, b.count, g, b.table,
+        hipLaunchKernelGGL(k_bin_count, dim3(b.nblocks, (g.nby + cnt_rows - 1) / cnt_rows), dim3(CNT_THREADS),
+                           (size_t)cnt_rows * nbxb * sizeof(uint32_t), s, b.depth_index, b.bbox, b.count, g, cnt_rows, b.table,
                            b.blk_counts, b.rects);
-        hipLaunchKernelGGL(k_bin_scan, dim3((nbins + BIN_WAVES - 1) / BIN_WAVES), block, 0, s, b.table, b.bin_total, nbins,
-                           b.nblocks);
+        launch_column_scan(b.table, b.bin_total, nbins, b.nblocks, s);
     }
     hipLaunchKernelGGL(k_bin_finalize, dim3(1), dim3(FIN_THREADS), 0, s, (const uint32_t*)b.bin_total, nbins, b.seg_len,
-                       b.max_items, b.capacity, (const uint2*)b.blk_counts, n ? b.nblocks : 0u, b.bin_start, b.seg_start, b.items,
-                       b.overflow, b.visible, b.tile_entries, b.accum);
+                       b.seg_target_items, b.seg_len_dev, b.max_items, b.capacity, (const uint2*)b.blk_counts, n ? b.nblocks : 0u,
+                       b.bin_start, b.seg_start, b.items, b.overflow, b.visible, b.tile_entries, b.accum);
     if (n)
-        hipLaunchKernelGGL(k_bin_scatter, grid, dim3(SCAT_THREADS), lds, s, b.depth_index, (const uint32_t*)b.rects, b.count, g, (const uint32_t*)b.table,
-                           (const uint32_t*)b.bin_start, b.list, b.capacity, b.overflow);
+        hipLaunchKernelGGL(k_bin_scatter, dim3(b.nblocks, sl.sx * sl.sy), dim3(SCAT_THREADS), lds, s, b.depth_index,
+                           (const uint32_t*)b.rects, b.count, g, sl, (const uint32_t*)b.table, (const uint32_t*)b.bin_start, b.list,
+                           b.capacity, b.overflow);
 }
 
 }  // namespace gsr

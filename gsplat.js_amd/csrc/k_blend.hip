@@ -46,8 +46,10 @@ __global__ __launch_bounds__(BLEND_THREADS, GSR_BLEND_MIN_WAVES) void k_blend(co
                                                          const Record* __restrict__ rec,
                                                          const float4* __restrict__ shcol, float4* __restrict__ fb,
                                                          float4* __restrict__ partial, uint32_t* __restrict__ queue,
-                                                         BinGrid g, float eps, uint32_t seg_len, uint32_t capacity, uint32_t nsplats)
+                                                         BinGrid g, float eps, const uint32_t* __restrict__ seg_len_dev, uint32_t capacity,
+                                                         uint32_t nsplats)
 {
+    const uint32_t seg_len = *seg_len_dev;  // this frame's list entries per work item (k_bin_finalize)
     // [0]: ux, uy, -dot(u, c - bin origin), wx   [1]: wy, -dot(w, c - bin origin), log2(opacity), blue   [2]: red, green
     __shared__ float4 s_rec[3][CHUNK];   // one address register serves the three reads of an entry
     __shared__ uint32_t s_mask[CHUNK];
@@ -261,7 +263,7 @@ void launch_blend(const BlendBuffers& b, const BinGrid& g, float early_out_eps, 
     const int nbins = (g.bx_hi - g.bx_lo) * g.nby;
     if (nbins <= 0) return;
     hipLaunchKernelGGL(k_blend, dim3(b.grid), dim3(BLEND_THREADS), 0, s, b.items, b.seg_start, b.bin_start, b.list, b.rec,
-                       b.shcol, b.fb, b.partial, b.queue, g, early_out_eps, b.seg_len, b.capacity, b.nsplats);
+                       b.shcol, b.fb, b.partial, b.queue, g, early_out_eps, b.seg_len_dev, b.capacity, b.nsplats);
     if (between) (void)hipEventRecord(between, s);
     if (b.seg_len < 0x40000000u)
         hipLaunchKernelGGL(k_combine, dim3(nbins), dim3(BLEND_THREADS), 0, s, b.seg_start, (const float4*)b.partial, b.fb, g);

@@ -15,7 +15,6 @@
 namespace gsr {
 
 constexpr int SORT_THREADS = 256;
-constexpr int SORT_WAVES = SORT_THREADS / WAVE;
 
 __device__ __forceinline__ uint32_t lanes_below(uint64_t mask)
 {
@@ -96,41 +95,71 @@ __global__ __launch_bounds__(SORT_THREADS) void k_hist_hi(const uint32_t* __rest
 }
 
 // ---------------------------------------------------------------------------
-// One wave per digit d: block_hist[b][d] <- keys with digit d in workgroups before b; total[d] = all of them.
-// In place over block_hist (block-major so the histogram and scatter kernels touch it coalesced; this small
-// kernel takes the strided accesses).  No global atomics anywhere in the sort.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(SORT_THREADS) void k_digit_scan(uint32_t* __restrict__ block_hist,
-                                                             uint32_t* __restrict__ total, int nbins, uint32_t nblocks)
+// Column scan shared by the radix sort (digit histograms) and the binning (bin counts):
+// exclusive prefix down the rows of a row-major table[nrows][ncols], in place, per column;
+// total[col] = column sum.
+//
+// A workgroup owns 16 adjacent columns and every row:
+// thread = (row slot, column), 64 row slots x 16 columns, each slot a contiguous range of rows, so a
+// wave instruction touches four 64-byte row segments instead of 64 scattered words (the one-wave-per-
+// column form reads a whole cache line per word: at 4K / 5 M splats that was 80 MB of table read as
+// ~1.3 GB).  Two sweeps: sum the slot's rows, exchange the 64 slot sums through LDS, then rewrite the
+// rows with running prefixes.  Loads are issued in independent batches.
+constexpr int CS_THREADS = 1024;
+constexpr int CS_COLS = 16;
+constexpr int CS_SLOTS = CS_THREADS / CS_COLS;  // 64
+constexpr int CS_BATCH = 8;
+
+__global__ __launch_bounds__(CS_THREADS) void k_column_scan(uint32_t* __restrict__ table, uint32_t* __restrict__ total,
+                                                            int ncols, uint32_t nrows)
 {
-    const int lane = threadIdx.x & 63;
-    const int d = blockIdx.x * SORT_WAVES + (threadIdx.x >> 6);
-    if (d >= nbins) return;
-    // One wave per column: lane l takes rows l, l+64, ...  The strided loads of a batch are issued together
-    // (independent), then scanned; doing them one at a time made this kernel a chain of L2 round trips.
-    constexpr int BATCH = 8;
-    uint32_t run = 0;
-    for (uint32_t b0 = 0; b0 < nblocks; b0 += BATCH * WAVE) {
-        uint32_t v[BATCH];
+    __shared__ uint32_t s_sum[CS_SLOTS][CS_COLS];
+    const int c = threadIdx.x & (CS_COLS - 1);
+    const int slot = threadIdx.x / CS_COLS;
+    const int col = blockIdx.x * CS_COLS + c;
+    const bool ok = col < ncols;
+    const uint32_t per = (nrows + CS_SLOTS - 1) / CS_SLOTS;
+    const uint32_t r0 = min((uint32_t)slot * per, nrows), r1 = min(r0 + per, nrows);
+    uint32_t* p = table + (size_t)r0 * ncols + (ok ? col : 0);
+
+    uint32_t sum = 0;
+    if (ok) {
+        for (uint32_t r = r0; r < r1; r += CS_BATCH) {
+            uint32_t v[CS_BATCH];
 #pragma unroll
-        for (int k = 0; k < BATCH; k++) {
-            const uint32_t b = b0 + k * WAVE + lane;
-            v[k] = (b < nblocks) ? block_hist[(size_t)b * nbins + d] : 0u;
-        }
+            for (int k = 0; k < CS_BATCH; k++) v[k] = (r + k < r1) ? p[(size_t)(r - r0 + k) * ncols] : 0u;
 #pragma unroll
-        for (int k = 0; k < BATCH; k++) {
-            const uint32_t b = b0 + k * WAVE + lane;
-            uint32_t incl = v[k];
-#pragma unroll
-            for (int off = 1; off < WAVE; off <<= 1) {
-                const uint32_t t = __shfl_up(incl, off);
-                if (lane >= off) incl += t;
-            }
-            if (b < nblocks) block_hist[(size_t)b * nbins + d] = run + incl - v[k];
-            run += __shfl(incl, WAVE - 1);
+            for (int k = 0; k < CS_BATCH; k++) sum += v[k];
         }
     }
-    if (lane == 0) total[d] = run;
+    s_sum[slot][c] = sum;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll 8
+    for (int k = 0; k < CS_SLOTS; k++) {
+        const uint32_t v = s_sum[k][c];
+        base += (k < slot) ? v : 0u;
+        tot += v;
+    }
+    if (ok) {
+        uint32_t run = base;
+        for (uint32_t r = r0; r < r1; r += CS_BATCH) {
+            uint32_t v[CS_BATCH];
+#pragma unroll
+            for (int k = 0; k < CS_BATCH; k++) v[k] = (r + k < r1) ? p[(size_t)(r - r0 + k) * ncols] : 0u;
+#pragma unroll
+            for (int k = 0; k < CS_BATCH; k++) {
+                if (r + k < r1) p[(size_t)(r - r0 + k) * ncols] = run;
+                run += v[k];
+            }
+        }
+        if (slot == 0) total[col] = tot;
+    }
+}
+
+void launch_column_scan(uint32_t* table, uint32_t* total, int ncols, uint32_t nrows, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_column_scan, dim3((ncols + CS_COLS - 1) / CS_COLS), dim3(CS_THREADS), 0, s, table, total, ncols, nrows);
 }
 
 // ---------------------------------------------------------------------------
@@ -244,15 +273,13 @@ void launch_sort(const SortBuffers& b, uint32_t n, hipStream_t s)
     uint32_t* total_hi = b.digit_total + RADIX_LO_BINS;
     hipLaunchKernelGGL(k_quantise_hist, grid, block, 0, s, b.depth, b.minmax, n, b.keys_per_block, b.cull_bbox, b.keys,
                        b.block_hist);
-    hipLaunchKernelGGL(k_digit_scan, dim3(RADIX_LO_BINS / SORT_WAVES), block, 0, s, b.block_hist, total_lo, RADIX_LO_BINS,
-                       b.nblocks);
+    launch_column_scan(b.block_hist, total_lo, RADIX_LO_BINS, b.nblocks, s);
     hipLaunchKernelGGL((k_scatter<RADIX_LO_BITS, 0, true>), grid, dim3(SCAT_THREADS), 0, s, (const uint32_t*)b.keys,
                        (const uint32_t*)nullptr, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
                        (const uint32_t*)total_lo, b.keys_tmp, b.idx_tmp);
     hipLaunchKernelGGL(k_hist_hi, grid, block, 0, s, (const uint32_t*)b.keys_tmp, (const uint32_t*)b.count, b.keys_per_block,
                        b.block_hist);
-    hipLaunchKernelGGL(k_digit_scan, dim3(RADIX_HI_BINS / SORT_WAVES), block, 0, s, b.block_hist, total_hi, RADIX_HI_BINS,
-                       b.nblocks);
+    launch_column_scan(b.block_hist, total_hi, RADIX_HI_BINS, b.nblocks, s);
     hipLaunchKernelGGL((k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, false>), grid, dim3(SCAT_THREADS), 0, s, (const uint32_t*)b.keys_tmp,
                        (const uint32_t*)b.idx_tmp, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
                        (const uint32_t*)total_hi, (uint32_t*)nullptr, b.depth_index);

@@ -172,6 +172,26 @@ def test_image_odd_size_and_empty_scene(gh, oracle, scenes):
     r.dispose()
 
 
+def test_large_framebuffer_sliced_binning(gh, oracle, scenes):
+    # above 4K the bin grid (192 x 101 bins here) no longer fits one workgroup's LDS: the count pass runs in row
+    # slices and the scatter pass in 64x36-bin sub-grids; same image, same permutation
+    W, H = 6144, 3216
+    rows, data, pos = scenes(30000, 33)
+    cam = gh.orbit_camera(17, width=W, height=H, fx=3600.0)
+    img, img8, di, st, oimg, odi, V, D = _render_pair(gh, oracle, data, pos, cam, W, H)
+    assert np.array_equal(di, odi)
+    assert st["visible"] == V and st["tile_entries"] == D
+    err = np.abs(img.astype(np.float64) - oimg.astype(np.float64)).max()
+    assert err <= TOL_EXACT, err
+    # the largest framebuffer the ABI accepts renders too (256 x 256 bins)
+    r = gh.HIPRenderer(8192, 8192)
+    r.set_raw_scene(data, pos)
+    r.set_camera(gh.orbit_camera(17, width=8192, height=8192, fx=4800.0))
+    r.render_async(); r.sync()
+    assert r.stats()["visible"] > 0 and r.bin_totals().shape == (256, 256)
+    r.dispose()
+
+
 def test_band_split_equals_full_frame(gh, oracle, scenes):
     # multi-GPU partition: the union of the tile-column bands is the full frame, bit for bit
     cfg = gh.synth.CONFIGS["C1"]
