@@ -238,15 +238,16 @@ def main():
         b_sort = 52.0 * N
         b_proj = 16.0 * N + 48.0 * V
         b_bin = 8.0 * D
-        traffic = valu = None
+        traffic = valu = traffic_solo = None
         tpath = os.path.join(ROOT, "profiles", "blend_traffic.json")   # committed PMC measurement (scripts/gpu_pmc.sh)
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.config == "C3" and eworld == 1 and args.early_out_eps == 0.0:
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get("hbm_bytes_per_launch")
-                valu = tj.get("valu_wave_instructions_per_launch")
+                sel = tj["frames_in_flight" if F > 1 else "one_frame"]
+                traffic, valu = sel["hbm_bytes_per_launch"], sel["valu_wave_instructions_per_launch"]
+                traffic_solo = tj["one_frame"]["hbm_bytes_per_launch"]
             except Exception:
-                traffic = valu = None
+                traffic = valu = traffic_solo = None
         ach = b_blend / (ms["blend"] * 1e-3) / 1e9 if ms["blend"] > 0 else 0.0
         sm = solo["stage_ms"] if solo else ms   # per-stage figures: uncontended times when several frames were in flight
         out = {
@@ -267,13 +268,17 @@ def main():
                          "one_frame_in_flight": None if not solo else {
                              "avg_launch_ms": solo["stage_ms"]["blend"],
                              "achieved": b_blend / (solo["stage_ms"]["blend"] * 1e-3) / 1e9,
-                             "frac": b_blend / (solo["stage_ms"]["blend"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                         "note": "the compositor is VALU-bound, not HBM-bound (SURVEY 8(d) honest note); see valu"},
+                             "frac": b_blend / (solo["stage_ms"]["blend"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "traffic": traffic_solo},
+                         "note": "the compositor is bound by VALU issue and wave stalls (barriers, LDS reads), not by HBM "
+                                 "(SURVEY 8(d) honest note); see valu and DESIGN.md section 8"},
             # secondary ceiling: VALU issue. peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction
             # (tools/valu_peak.hip measures 0.96e12 v_fma_f32 wave-instr/s; v_exp_f32 is 3.3x slower)
-            "valu": None if not valu or not ms["blend"] else {
-                "wave_instr_per_launch": valu, "achieved_wave_instr_per_s": valu / (ms["blend"] * 1e-3),
-                "peak_wave_instr_per_s": 1024 * 2.4e9 / 2, "frac": valu / (ms["blend"] * 1e-3) / (1024 * 2.4e9 / 2)},
+            "valu": None if not valu else (lambda t_ms, v: {
+                "wave_instr_per_launch": v, "launch_ms": t_ms, "achieved_wave_instr_per_s": v / (t_ms * 1e-3),
+                "peak_wave_instr_per_s": 1024 * 2.4e9 / 2, "frac": v / (t_ms * 1e-3) / (1024 * 2.4e9 / 2),
+                "note": "one frame in flight (kernels of several frames overlap in the timed region)" if solo else ""})(
+                    sm["blend"], tj["one_frame"]["valu_wave_instructions_per_launch"] if solo else valu),
             "stage_roofline": {
                 "sort": {"bytes": b_sort, "ms": sm["sort"], "GBps": b_sort / (sm["sort"] * 1e-3) / 1e9 if sm["sort"] else 0,
                          "frac": b_sort / (sm["sort"] * 1e-3) / 1e9 / HBM_PEAK_GBS if sm["sort"] else 0},

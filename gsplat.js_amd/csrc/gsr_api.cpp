@@ -273,7 +273,7 @@ int enqueue_frame(gsr_ctx* c, bool render)
         if (!c->n) HIP_TRY(c, hipMemsetAsync(c->bin_total, 0, sizeof(uint32_t) * nbins, s));
         BinBuffers bb{c->depth_index, &c->fstate->sorted_count, c->bbox, c->bin_table, c->blk_counts, c->bin_rects, c->bin_total, c->bin_start, c->seg_start,
                       c->items, c->bin_list, &c->fstate->overflow, &c->fstate->visible, &c->fstate->tile_entries,
-                      c->accum, c->bin_capacity, c->max_items, c->seg_len, &c->fstate->seg_len, c->seg_target_items, c->bin_blocks};
+                      c->accum, c->bin_capacity, c->max_items, c->seg_len, &c->fstate->seg_len, (c->opt.flags & GSR_FLAG_THROUGHPUT) ? 0 : 1, c->seg_target_items, c->bin_blocks};
         launch_bin(bb, g, c->n, s);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BIN], s));
         BlendBuffers bl{c->items, c->seg_start, c->bin_start, c->bin_list, c->rec, c->bbox, c->shcol, c->fb, c->partial,

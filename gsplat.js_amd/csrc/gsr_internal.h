@@ -119,6 +119,7 @@ struct BinBuffers {
     uint32_t seg_len;            // minimum list entries per compositor work item (multiple of 256); k_bin_finalize
                                  // raises it for long lists and publishes the frame's value in *seg_len_dev
     uint32_t* seg_len_dev;
+    int32_t items_by_size;       // order the bins' last segments by size class (one frame at a time) or leave them in raster order
     uint32_t seg_target_items;   // full segments the frame should be cut into at least (long lists -> longer segments)
     uint32_t nblocks;
 };

@@ -153,22 +153,6 @@ __global__ __launch_bounds__(BLEND_THREADS, GSR_BLEND_MIN_WAVES) void k_blend(co
                 for (uint32_t c0 = 0; c0 < cnt; c0 += WAVE) {
                     const uint32_t mine = (s_mask[c0 + lane] >> (wave * 4)) & 15u;  // entry (c0+lane) vs my tile
                     uint64_t bal = __ballot(mine != 0u);
-                    while (bal) {
-                        const int j = __builtin_ctzll(bal);
-                        bal &= bal - 1;
-                        const uint32_t qm = __builtin_amdgcn_readlane(mine, j);  // wave-uniform quadrant mask
-                        const float4 ra = s_rec[0][c0 + j];
-                        const float4 rb = s_rec[1][c0 + j];
-                        const float2 rc = *reinterpret_cast<const float2*>(&s_rec[2][c0 + j]);
-                        const float ux = ra.x, uy = ra.y, ncu = ra.z, wx = ra.w, wy = rb.x, ncw = rb.y, la = rb.z;
-                        const float cr = rc.x, cg = rc.y, cb = rb.w;
-                        // vPosition = (ux*px + (uy*py - dot(u,c)), wx*px + (wy*py - dot(w,c))), all bin-relative:
-                        // the row terms are shared by the two quadrants of a row
-                        const float ur0 = __builtin_fmaf(uy, pyf0, ncu), ur1 = __builtin_fmaf(uy, pyf1, ncu);
-                        const float wr0 = __builtin_fmaf(wy, pyf0, ncw), wr1 = __builtin_fmaf(wy, pyf1, ncw);
-                        // frag.glsl.ts:15  if (A < -4.0) discard;   (A = -q)
-                        // frag.glsl.ts:16-20  B = clamp(exp(A) * opacity, 0, 1)  (never clamps: exp(A) <= 1, opacity <= 1)
-                        // blend: dst += (1 - dst.a) * (B*rgb, B)
 #define GSR_QUAD(BIT, PX, UR, WR, T, R, G, B_)                                                     \
     if (qm & (BIT)) {                                                                              \
         const float vx_ = __builtin_fmaf(ux, (PX), (UR)), vy_ = __builtin_fmaf(wx, (PX), (WR));    \
@@ -181,12 +165,67 @@ __global__ __launch_bounds__(BLEND_THREADS, GSR_BLEND_MIN_WAVES) void k_blend(co
             (B_) = __builtin_fmaf(w_, cb, (B_));                                                   \
         }                                                                                          \
     }
-                        GSR_QUAD(1u, pxf0, ur0, wr0, T00, r00, g00, b00)
-                        GSR_QUAD(2u, pxf1, ur0, wr0, T10, r10, g10, b10)
-                        GSR_QUAD(4u, pxf0, ur1, wr1, T01, r01, g01, b01)
-                        GSR_QUAD(8u, pxf1, ur1, wr1, T11, r11, g11, b11)
-#undef GSR_QUAD
+                    // vPosition = (ux*px + (uy*py - dot(u,c)), wx*px + (wy*py - dot(w,c))), all bin-relative:
+                    // the row terms are shared by the two quadrants of a row
+                    // frag.glsl.ts:15  if (A < -4.0) discard;   (A = -q)
+                    // frag.glsl.ts:16-20  B = clamp(exp(A) * opacity, 0, 1)  (never clamps: exp(A) <= 1, opacity <= 1)
+                    // blend: dst += (1 - dst.a) * (B*rgb, B)
+#define GSR_ENTRY(RA, RB, RC, QM)                                                                              \
+    {                                                                                                          \
+        const uint32_t qm = (QM);                                                                              \
+        const float ux = RA.x, uy = RA.y, ncu = RA.z, wx = RA.w, wy = RB.x, ncw = RB.y, la = RB.z;             \
+        const float cr = RC.x, cg = RC.y, cb = RB.w;                                                           \
+        const float ur0 = __builtin_fmaf(uy, pyf0, ncu), ur1 = __builtin_fmaf(uy, pyf1, ncu);                  \
+        const float wr0 = __builtin_fmaf(wy, pyf0, ncw), wr1 = __builtin_fmaf(wy, pyf1, ncw);                  \
+        GSR_QUAD(1u, pxf0, ur0, wr0, T00, r00, g00, b00)                                                       \
+        GSR_QUAD(2u, pxf1, ur0, wr0, T10, r10, g10, b10)                                                       \
+        GSR_QUAD(4u, pxf0, ur1, wr1, T01, r01, g01, b01)                                                       \
+        GSR_QUAD(8u, pxf1, ur1, wr1, T11, r11, g11, b11)                                                       \
+    }
+#define GSR_FETCH(RA, RB, RC, QM, J)                                                 \
+    RA = s_rec[0][c0 + (J)];                                                          \
+    RB = s_rec[1][c0 + (J)];                                                          \
+    RC = *reinterpret_cast<const float2*>(&s_rec[2][c0 + (J)]);                       \
+    QM = __builtin_amdgcn_readlane(mine, (J));  /* wave-uniform quadrant mask */
+#ifdef GSR_LDS_PIPE
+                    // two register sets: the LDS reads of the next entry are in flight while this one is composited.
+                    // The reads are unconditional (the last entry is re-read) so that one lgkmcnt value fits every path.
+                    if (bal) {
+                        float4 ra0, rb0, ra1, rb1;
+                        float2 rc0, rc1;
+                        uint32_t qm0, qm1;
+                        int j = __builtin_ctzll(bal);
+                        bal &= bal - 1;
+                        GSR_FETCH(ra0, rb0, rc0, qm0, j)
+                        for (;;) {
+                            const bool more1 = bal != 0ull;
+                            j = more1 ? __builtin_ctzll(bal) : j;
+                            bal &= bal - 1;
+                            GSR_FETCH(ra1, rb1, rc1, qm1, j)
+                            GSR_ENTRY(ra0, rb0, rc0, qm0)
+                            if (!more1) break;
+                            const bool more0 = bal != 0ull;
+                            j = more0 ? __builtin_ctzll(bal) : j;
+                            bal &= bal - 1;
+                            GSR_FETCH(ra0, rb0, rc0, qm0, j)
+                            GSR_ENTRY(ra1, rb1, rc1, qm1)
+                            if (!more0) break;
+                        }
                     }
+#else
+                    while (bal) {
+                        const int j = __builtin_ctzll(bal);
+                        bal &= bal - 1;
+                        float4 ra, rb;
+                        float2 rc;
+                        uint32_t qm1;
+                        GSR_FETCH(ra, rb, rc, qm1, j)
+                        GSR_ENTRY(ra, rb, rc, qm1)
+                    }
+#endif
+#undef GSR_FETCH
+#undef GSR_ENTRY
+#undef GSR_QUAD
                     if (eps > 0.0f) {
                         const float tmax = fmaxf(fmaxf(T00, T10), fmaxf(T01, T11));
                         if (__ballot(tmax >= eps) == 0ull) {
