@@ -187,32 +187,6 @@ __global__ __launch_bounds__(BLEND_THREADS, GSR_BLEND_MIN_WAVES) void k_blend(co
     RB = s_rec[1][c0 + (J)];                                                          \
     RC = *reinterpret_cast<const float2*>(&s_rec[2][c0 + (J)]);                       \
     QM = __builtin_amdgcn_readlane(mine, (J));  /* wave-uniform quadrant mask */
-#ifdef GSR_LDS_PIPE
-                    // two register sets: the LDS reads of the next entry are in flight while this one is composited.
-                    // The reads are unconditional (the last entry is re-read) so that one lgkmcnt value fits every path.
-                    if (bal) {
-                        float4 ra0, rb0, ra1, rb1;
-                        float2 rc0, rc1;
-                        uint32_t qm0, qm1;
-                        int j = __builtin_ctzll(bal);
-                        bal &= bal - 1;
-                        GSR_FETCH(ra0, rb0, rc0, qm0, j)
-                        for (;;) {
-                            const bool more1 = bal != 0ull;
-                            j = more1 ? __builtin_ctzll(bal) : j;
-                            bal &= bal - 1;
-                            GSR_FETCH(ra1, rb1, rc1, qm1, j)
-                            GSR_ENTRY(ra0, rb0, rc0, qm0)
-                            if (!more1) break;
-                            const bool more0 = bal != 0ull;
-                            j = more0 ? __builtin_ctzll(bal) : j;
-                            bal &= bal - 1;
-                            GSR_FETCH(ra0, rb0, rc0, qm0, j)
-                            GSR_ENTRY(ra1, rb1, rc1, qm1)
-                            if (!more0) break;
-                        }
-                    }
-#else
                     while (bal) {
                         const int j = __builtin_ctzll(bal);
                         bal &= bal - 1;
@@ -222,7 +196,6 @@ __global__ __launch_bounds__(BLEND_THREADS, GSR_BLEND_MIN_WAVES) void k_blend(co
                         GSR_FETCH(ra, rb, rc, qm1, j)
                         GSR_ENTRY(ra, rb, rc, qm1)
                     }
-#endif
 #undef GSR_FETCH
 #undef GSR_ENTRY
 #undef GSR_QUAD
