@@ -272,11 +272,12 @@ def main():
                              "traffic": traffic_solo},
                          "note": "the compositor is bound by VALU issue and wave stalls (barriers, LDS reads), not by HBM "
                                  "(SURVEY 8(d) honest note); see valu and DESIGN.md section 8"},
-            # secondary ceiling: VALU issue. peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction
-            # (tools/valu_peak.hip measures 0.96e12 v_fma_f32 wave-instr/s; v_exp_f32 is 3.3x slower)
+            # secondary ceiling: VALU issue.  peak = what tools/valu_peak.hip sustains on this chip for the compositor's
+            # own instruction mix (11 VALU of a covered quadrant incl. v_exp_f32 and v_pk_fma_f32, operands in VGPRs,
+            # 8 waves/SIMD): 0.667e12 wave-instr/s (profiles/r01_valu_peak_mi355x.txt); plain v_fma_f32 sustains 0.623e12
             "valu": None if not valu else (lambda t_ms, v: {
                 "wave_instr_per_launch": v, "launch_ms": t_ms, "achieved_wave_instr_per_s": v / (t_ms * 1e-3),
-                "peak_wave_instr_per_s": 1024 * 2.4e9 / 2, "frac": v / (t_ms * 1e-3) / (1024 * 2.4e9 / 2),
+                "peak_wave_instr_per_s": 0.667e12, "frac": v / (t_ms * 1e-3) / 0.667e12,
                 "note": "one frame in flight (kernels of several frames overlap in the timed region)" if solo else ""})(
                     sm["blend"], tj["one_frame"]["valu_wave_instructions_per_launch"] if solo else valu),
             "stage_roofline": {
