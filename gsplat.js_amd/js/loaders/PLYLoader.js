@@ -8,7 +8,10 @@
 // useShs = true: rows + 48 SH floats per splat (_ParseFullPLYBufferFast, :578-712), reproduced as written, including
 //   its two oddities: the colour byte is 0.5 + SH_C0 * f_dc * 255 (precedence as in the source) and the slot of
 //   f_rest_39 is filled from f_rest_38.  Scene.bandsIndices stays (-1,-1,-1): every splat is SH degree 3.
-// The quantized-PLY variant with codebooks (_ParseQPLYBuffer, :893-1196) is not implemented.
+// quantized = true (with useShs): the codebook-compressed variant (_ParseQPLYBuffer, :893-1196): four vertex elements
+//   vertex_0..vertex_3 (splats with 0, 1, 2, 3 SH bands), positions as half floats, every other property a one-byte
+//   index into a 256-entry codebook (half floats, stored [256][codebooks] after the vertex data); yields the rows, 48 SH
+//   floats for every splat of vertex_1..3 (unused tail zero) and Scene.bandsIndices = last index with 0 / 1 / 2 bands.
 const fs = require("fs");
 const { Scene } = require("../core/Scene");
 const { Quaternion } = require("../math/Quaternion");
@@ -28,9 +31,12 @@ class PLYLoader {
     }
     static LoadFromBytes(bytes, scene, format, useShs, quantized) {
         if (bytes[0] !== 112 || bytes[1] !== 108 || bytes[2] !== 121 || bytes[3] !== 10) throw new Error("Invalid PLY file");
-        if (quantized) throw new Error("quantized PLY (codebooks) is not supported by this loader");
         const ab = bytes.buffer.slice(bytes.byteOffset, bytes.byteOffset + bytes.byteLength);
-        if (useShs) {
+        if (useShs && quantized) {
+            const parsed = PLYLoader._parseQuantized(ab);
+            scene.bandsIndices = parsed[2];   // before setData, like PLYLoader.ts:85
+            scene.setData(new Uint8Array(parsed[0]), new Float32Array(parsed[1]));
+        } else if (useShs) {
             const parsed = PLYLoader._parseFull(PLYLoader._parseHeader(ab), ab);
             scene.setData(new Uint8Array(parsed[0]), new Float32Array(parsed[1]));
         } else {
@@ -145,6 +151,95 @@ class PLYLoader {
             for (let j = 0; j < 45; j++) sh[3 + j] = f("f_rest_" + restOrder[j], i);
         }
         return [rows, shs];
+    }
+
+    // utils.ts:52-71 decodeFloat16 for one value (the reference stores the result in a Float32Array: exact)
+    static _halfToFloat(bits) {
+        const exponent = (bits & 0x7c00) >> 10, fraction = bits & 0x03ff;
+        const sign = (bits & 0x8000) ? -1 : 1;
+        if (exponent === 0) return sign * 6.103515625e-5 * (fraction / 0x400);
+        if (exponent === 0x1f) return fraction ? NaN : sign * Infinity;
+        return sign * Math.pow(2, exponent - 15) * (1 + fraction / 0x400);
+    }
+
+    // PLYLoader.ts:893-1196
+    static _parseQuantized(ab) {
+        const text = Buffer.from(ab, 0, Math.min(ab.byteLength, 10240)).toString("utf8");
+        const marker = "end_header\n";
+        const end = text.indexOf(marker);
+        if (end < 0) throw new Error("Unable to read .ply file header");
+        const cbStart = text.indexOf("element codebook_centers 256\n");
+        const counts = [], starts = [];
+        const re = /element vertex_(\d+) (\d+)/g;
+        for (let m = re.exec(text); m; m = re.exec(text)) { counts.push(parseInt(m[2])); starts.push(m.index); }
+        if (counts.length !== 4 || cbStart < 0) throw new Error("not a quantized PLY: expected vertex_0..vertex_3 and codebook_centers");
+        const extents = [[0, starts[1]], [starts[1], starts[2]], [starts[2], starts[3]], [starts[3], cbStart]];
+        const props = [], rowSize = [];
+        let dataBytes = 0, total = 0;
+        for (let e = 0; e < 4; e++) {
+            const byName = {};
+            let off = 0;
+            for (const line of text.slice(extents[e][0], extents[e][1]).split("\n")) {
+                if (!line.startsWith("property ")) continue;
+                const parts = line.split(" ");
+                if (!TYPE_SIZE[parts[1]]) throw new Error("Unsupported property type: " + parts[1]);
+                byName[parts[2]] = off;
+                off += TYPE_SIZE[parts[1]];
+            }
+            props.push(byName); rowSize.push(off);
+            dataBytes += counts[e] * off; total += counts[e];
+        }
+        // codebooks: [256][nb] half floats right after the vertex data
+        const cbNames = [];
+        for (const line of text.slice(cbStart, end).split("\n")) if (line.startsWith("property ")) cbNames.push(line.split(" ")[2]);
+        const nb = cbNames.length;
+        const cbView = new DataView(ab, dataBytes + end + marker.length, nb * 2 * 256);
+        const cb = {};
+        for (let j = 0; j < nb; j++) {
+            const t = new Float32Array(256);
+            for (let i = 0; i < 256; i++) t[i] = PLYLoader._halfToFloat(cbView.getUint16(i * nb * 2 + j * 2, true));
+            cb[cbNames[j]] = t;
+        }
+        const view = new DataView(ab, end + marker.length, dataBytes);
+        const rows = new ArrayBuffer(Scene.RowLength * total);
+        const shs = new ArrayBuffer(192 * (counts[1] + counts[2] + counts[3]));
+        const strideLut = [3, 8, 15];
+        const rest0 = props[1]["f_rest_0"];   // the reference takes this offset from vertex_1 for every element (:1053)
+        let writeOff = 0, readOff = 0, shOff = 0;
+        for (let e = 0; e < 4; e++) {
+            const pr = props[e], rs = rowSize[e];
+            const shStride = e > 0 ? strideLut[e - 1] : 0;
+            let nRest = 0;
+            for (const name in pr) if (name.startsWith("f_rest")) nRest++;
+            const u8 = (name, v) => view.getUint8(readOff + pr[name] + v * rs);
+            for (let v = 0; v < counts[e]; v++) {
+                const position = new Float32Array(rows, writeOff + v * Scene.RowLength, 3);
+                const scale = new Float32Array(rows, writeOff + v * Scene.RowLength + 12, 3);
+                const rgba = new Uint8ClampedArray(rows, writeOff + v * Scene.RowLength + 24, 4);
+                const rot = new Uint8ClampedArray(rows, writeOff + v * Scene.RowLength + 28, 4);
+                for (let k = 0; k < 3; k++) position[k] = PLYLoader._halfToFloat(view.getUint16(readOff + pr["xyz"[k]] + v * rs, true));
+                for (let k = 0; k < 3; k++) scale[k] = Math.exp(cb["scaling"][u8("scale_" + k, v)]);
+                PLYLoader._writeRotation(rot, new Quaternion(cb["rotation_im"][u8("rot_1", v)], cb["rotation_im"][u8("rot_2", v)],
+                                                             cb["rotation_im"][u8("rot_3", v)], cb["rotation_re"][u8("rot_0", v)]));
+                for (let k = 0; k < 3; k++) rgba[k] = (0.5 + SH_C0 * cb["features_dc"][u8("f_dc_" + k, v)]) * 255;
+                rgba[3] = (1 / (1 + Math.exp(-cb["opacity"][u8("opacity", v)]))) * 255;
+                if (e > 0) {
+                    const sh = new Float32Array(shs, shOff + v * 192, 48);
+                    for (let k = 0; k < 3; k++) sh[k] = cb["features_dc"][u8("f_dc_" + k, v)];
+                    // output slot 3 + m holds coefficient floor(m/3) of channel m % 3; the file is channel-major (:1146-1153)
+                    for (let m = 0; m < nRest; m++) {
+                        const coef = Math.floor(m / 3);
+                        const idx = view.getUint8(readOff + rest0 + coef + shStride * (m % 3) + v * rs);
+                        sh[3 + m] = cb["features_rest_" + coef][idx];
+                    }
+                }
+            }
+            writeOff += counts[e] * Scene.RowLength;
+            readOff += counts[e] * rs;
+            if (e > 0) shOff += counts[e] * 192;
+        }
+        const ind0 = counts[0] - 1, ind1 = ind0 + counts[1], ind2 = ind1 + counts[2];
+        return [rows, shs, new Int32Array([ind0, ind1, ind2])];
     }
 }
 module.exports = { PLYLoader };

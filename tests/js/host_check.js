@@ -131,6 +131,19 @@ if (mode === "pack") {                     // pack <splat> <outprefix> <W> <H> <
     let badMagic = false;
     try { G.PLYLoader.LoadFromBytes(new Uint8Array(64), new G.Scene()); } catch (e) { badMagic = /Invalid PLY/.test(e.message); }
     fs.writeFileSync(out + ".json", JSON.stringify({ n, refused, badMagic }));
+} else if (mode === "qply") {             // qply <file.ply> <outprefix>: the codebook-quantized variant
+    const [file, out] = a;
+    const bytes = new Uint8Array(fs.readFileSync(file));
+    const ab = bytes.buffer.slice(bytes.byteOffset, bytes.byteOffset + bytes.byteLength);
+    const parsed = G.PLYLoader._parseQuantized(ab);
+    writeBin(out + ".rows.bin", new Uint8Array(parsed[0]));
+    writeBin(out + ".shs.bin", new Float32Array(parsed[1]));
+    const scene = new G.Scene();
+    G.PLYLoader.LoadFromBytes(bytes, scene, "", true, true);
+    for (let c = 0; c < 3; c++) writeBin(out + ".sh" + c + ".bin", scene.shs_rgb[c]);
+    writeBin(out + ".splat", scene.toSplatBytes());
+    fs.writeFileSync(out + ".json", JSON.stringify({ n: scene.vertexCount, bands: Array.from(scene.bandsIndices), parsedBands: Array.from(parsed[2]),
+                                                     shHeight: scene.shHeight }));
 } else if (mode === "nodevice") {
     try {
         new G.HIPRenderer({ width: 64, height: 64 });

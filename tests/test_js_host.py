@@ -121,6 +121,42 @@ def test_js_ply_loader(tmp_path, oracle):
     assert not np.array_equal(rows_full.reshape(n, 32)[:, 24:27], P.rows_from_ply(ply).reshape(n, 32)[:, 24:27])   # the precedence oddity is real
 
 
+def test_js_quantized_ply_loader(tmp_path, oracle):
+    # SURVEY 8(f) rank 4, codebook variant (PLYLoader.ts:893-1196): four vertex elements with 0..3 SH bands, half
+    # positions, one-byte codebook indices; rows, SH floats and bandsIndices against the numpy restatement
+    from oracle import ply_oracle as P
+    counts = [700, 500, 300, 400]
+    ply = P.synth_qply(counts, 23)
+    f = tmp_path / "q.ply"
+    f.write_bytes(ply)
+    out = str(tmp_path / "q")
+    run("qply", f, out)
+    n = sum(counts)
+    want_rows, want_sh, want_bands = P.rows_sh_from_qply(ply)
+    meta = json.load(open(out + ".json"))
+    assert meta["n"] == n and meta["bands"] == list(want_bands) == [699, 1199, 1499] and meta["parsedBands"] == meta["bands"]
+    got = np.fromfile(out + ".rows.bin", dtype=np.uint8).reshape(n, 32)
+    want = want_rows.reshape(n, 32)
+    assert np.array_equal(got[:, 0:12], want[:, 0:12])                                    # half positions, exact
+    gs, ws = got[:, 12:24].copy().view(np.float32), want[:, 12:24].copy().view(np.float32)
+    assert np.all(np.abs(gs - ws) <= np.spacing(ws))                                      # exp: V8 vs libm, <= 1 ulp
+    assert np.array_equal(got[:, 24:27], want[:, 24:27])
+    assert np.abs(got[:, 27].astype(int) - want[:, 27].astype(int)).max() <= 1
+    assert np.abs(got[:, 28:32].astype(int) - want[:, 28:32].astype(int)).max() <= 1
+    got_sh = np.fromfile(out + ".shs.bin", dtype=np.float32)
+    assert got_sh.size == 48 * (n - counts[0]) and np.array_equal(got_sh.view(np.uint32), want_sh.view(np.uint32))
+    sh2 = got_sh.reshape(-1, 48)
+    assert not sh2[:counts[1], 12:].any() and sh2[:counts[1], 3:12].any()                 # one band: 9 higher coefficients, rest zero
+    assert not sh2[counts[1]:counts[1] + counts[2], 27:].any()                           # two bands: 24
+    assert sh2[counts[1] + counts[2]:, 27:].any()                                         # three bands: all 45
+    # and through Scene.setData: the three half textures hold exactly the SH-carrying splats (i > bandsIndices[0])
+    want_tex = oracle.scene_pack_sh(want_sh)
+    for c in range(3):
+        tex = np.fromfile(out + ".sh%d.bin" % c, dtype=np.uint32)
+        assert np.array_equal(tex[:want_tex[c].size], want_tex[c]) and not tex[want_tex[c].size:].any()
+    assert np.array_equal(np.fromfile(out + ".splat", dtype=np.uint8).reshape(n, 32)[:, 0:12], want[:, 0:12])
+
+
 def test_js_renderer_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
