@@ -156,8 +156,8 @@ bool band_is_partial(const gsr_ctx* c)
 // bin, which early termination needs (a segment cannot see whether earlier ones saturated the bin).
 constexpr uint32_t SEG_LEN_EXACT = 512;          // one frame at a time: short items, concurrency from the frame's own segments
 constexpr uint32_t SEG_LEN_THROUGHPUT = 2048;    // GSR_FLAG_THROUGHPUT: concurrency comes from the other frames in flight
-constexpr uint32_t BLEND_GRID_EXACT = 2048;      // persistent compositor workgroups (8 per CU requested, 6 resident)
-constexpr uint32_t BLEND_GRID_THROUGHPUT = 1280; // 5 per CU: leaves room for the other contexts' kernels
+constexpr uint32_t BLEND_GRID_EXACT = 2048;      // persistent compositor workgroups (8 per CU requested, 7 resident)
+constexpr uint32_t BLEND_GRID_THROUGHPUT = 1536; // 6 per CU: leaves room for the other contexts' kernels
 constexpr uint32_t SEG_LEN_WHOLE_BIN = 0x7fffff00u;
 
 int alloc_bins(gsr_ctx* c)

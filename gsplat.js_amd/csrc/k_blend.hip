@@ -36,10 +36,10 @@ constexpr int CHUNK = BLEND_THREADS;
 constexpr int BIN_PIXELS = BIN_PX * BIN_PX;
 constexpr float LOG2E = 1.4426950408889634f;
 
-#ifndef GSR_BLEND_MIN_WAVES
-#define GSR_BLEND_MIN_WAVES 1
-#endif
-__global__ __launch_bounds__(BLEND_THREADS, GSR_BLEND_MIN_WAVES) void k_blend(const uint32_t* __restrict__ items,
+// 7 waves per SIMD: the kernel needs 74 VGPRs unconstrained (6 waves); capped at 72 it spills one register pair that is
+// stored once per workgroup and reloaded once per work item, and the seventh wave hides more of the LDS/barrier
+// waits (measured: k_blend -5.7 % alone; 8 waves = 64 VGPRs spills inside the loops and is no better).
+__global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_blend(const uint32_t* __restrict__ items,
                                                          const uint32_t* __restrict__ seg_start,
                                                          const uint32_t* __restrict__ bin_start,
                                                          const uint32_t* __restrict__ list,

@@ -60,7 +60,7 @@ typedef struct gsr_options {
 #define GSR_FLAG_TIMING 1   /* record HIP events around every stage (gsr_get_timings) */
 #define GSR_FLAG_THROUGHPUT 2 /* the caller keeps several frames in flight on this device (one
                                context per frame): the compositor then uses longer work items
-                               (2048 list entries instead of 512) and 5 instead of 8 persistent
+                               (2048 list entries instead of 512) and 6 instead of 8 persistent
                                workgroups per CU, because the other contexts' kernels, not extra
                                segments of this frame, fill the GPU.  Same pixels either way. */
 
