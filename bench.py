@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="independent frames rendered concurrently on separate contexts/streams (frame k uses context k mod F)")
     ap.add_argument("--equal-bands", action="store_true", help="N>1: equal-width bands instead of cost-balanced ones")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="N>1: nccl = RCCL over xGMI (the product path); gloo = rehearsal on a box without peers: ranks may share "
+                         "a GPU and the slab all-gather is staged through host memory")
     ap.add_argument("--emulate-rank", default=None, metavar="Q/G",
                     help="single GPU only: render just the band rank Q of G would own (no exchange) -> per-rank device time of a G-GPU run")
     args = ap.parse_args()
@@ -100,11 +103,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()      # rehearsal: ranks may share a device
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     cfg = gh.synth.CONFIGS[args.config]
     W, H, N = cfg["width"], cfg["height"], cfg["n"]
@@ -150,7 +158,8 @@ def main():
         dev = "cuda:%d" % local_rank
         if args.exchange == "rgba8":
             fbs = [bands.framebuffer8_tensor(torch, rr, dev) for rr in rs]
-            xchg = bands.FrameExchange(dist, torch, W, H, rank, world, fbs[0].device, edges=edges, dtype=torch.uint8)
+            xchg = bands.FrameExchange(dist, torch, W, H, rank, world, fbs[0].device, edges=edges, dtype=torch.uint8,
+                                       host_staged=args.backend == "gloo")
         else:
             fbs = [bands.framebuffer_tensor(torch, rr, dev) for rr in rs]
             xchg = bands.FrameExchange(dist, torch, W, H, rank, world, fbs[0].device, edges=edges)

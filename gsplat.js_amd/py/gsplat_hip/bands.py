@@ -98,8 +98,11 @@ class FrameExchange:
     (gsr_pack_band_rgba8_async) and de-slabs the gathered buffer with one kernel (gsr_unpack_slabs_rgba8_async),
     so a frame costs one collective and no torch copy kernels."""
 
-    def __init__(self, dist, torch, width, height, rank, world, device, channels=4, edges=None, dtype=None):
+    def __init__(self, dist, torch, width, height, rank, world, device, channels=4, edges=None, dtype=None, host_staged=False):
         self.dist, self.rank, self.world = dist, rank, world
+        # host_staged: rehearsal of the N>1 path on a box without RCCL peers (gloo has no device all-gather): the slab
+        # takes a round trip through host memory around the collective; everything else is the production path
+        self.host_staged = host_staged
         self.edges = list(edges) if edges is not None else band_edges(width, world)
         dtype = dtype or torch.float32
         sw = slab_width(width, world, self.edges)
@@ -124,7 +127,13 @@ class FrameExchange:
             link.renderer_waits_for_event(self.gathered_ev)     # previous collective has read the slab
         renderer.pack_band_rgba8_async(self.slab.data_ptr(), sw)
         link.torch_waits_for_renderer()
-        self.dist.all_gather_into_tensor(self._flat, self.slab)
+        if self.host_staged:
+            host_slab = self.slab.cpu()
+            host_flat = torch.empty(self._flat.shape, dtype=self._flat.dtype)
+            self.dist.all_gather_into_tensor(host_flat, host_slab)
+            self._flat.copy_(host_flat)
+        else:
+            self.dist.all_gather_into_tensor(self._flat, self.slab)
         self.gathered_ev.record()
         renderer.unpack_slabs_rgba8_async(self._flat.data_ptr(), self.full.data_ptr(), sw, self.edges,
                                           torch.cuda.current_stream().cuda_stream)

@@ -41,13 +41,22 @@ def _worker(rank, world, port, out):
         r.render(scene, cam)
         fb = torch.from_numpy(r.readPixelsFloat())
         di = r.lastDepthIndex()
+        # bench.py's RGBA8 path: pack on the renderer's stream -> all-gather (through host memory under gloo) -> one
+        # de-slab kernel on torch's stream; two frames, so the slab-reuse event is exercised too
+        link = bands.StreamLink(torch, r, "cuda:0")
+        x8 = bands.FrameExchange(dist, torch, W, H, rank, world, torch.device("cuda:0"), dtype=torch.uint8, host_staged=True)
+        for _ in range(2):
+            r.render_async()
+            full8 = x8.exchange_native(r, link)
+        torch.cuda.synchronize()
+        full8 = full8.cpu().numpy()
         r.dispose()
         full = bands.FrameExchange(dist, torch, W, H, rank, world, "cpu").exchange(fb)
         if rank == 0:
             ref = gh.HIPRenderer(W, H, device=0)
             ref.render(scene, cam)
             want = ref.readPixelsFloat()
-            ok = np.array_equal(full.numpy(), want) and np.array_equal(di, ref.lastDepthIndex())
+            ok = np.array_equal(full.numpy(), want) and np.array_equal(di, ref.lastDepthIndex()) and np.array_equal(full8, ref.readPixels())
             ref.dispose()
             open(out, "w").write("ok" if ok else "mismatch")
         dist.barrier()
