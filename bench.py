@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="N>1: nccl = RCCL over xGMI (the product path); gloo = rehearsal on a box without peers: ranks may share "
                          "a GPU and the slab all-gather is staged through host memory")
+    ap.add_argument("--timing-interval", type=int, default=8,
+                    help="stage events (HIP) on every k-th frame of the timed region; 1 = every frame")
     ap.add_argument("--emulate-rank", default=None, metavar="Q/G",
                     help="single GPU only: render just the band rank Q of G would own (no exchange) -> per-rank device time of a G-GPU run")
     args = ap.parse_args()
@@ -150,6 +152,7 @@ def main():
     for _ in range(F):   # every context owns its buffers and its stream; frames are independent of each other
         rr = gh.HIPRenderer(W, H, device=local_rank, early_out_eps=args.early_out_eps, band=band, timing=True, throughput=F > 1)
         rr.render(scene, gh.orbit_camera(0, ORBIT_FRAMES, W, H, cfg["fx"]))  # uploads the scene, first frame
+        rr.set_timing_interval(max(1, args.timing_interval))
         rs.append(rr)
     r = rs[0]
 
@@ -266,7 +269,7 @@ def main():
             "config": {"workload": "%s: %d synthetic gaussians (seed %d), %dx%d, 120-pose orbit, full render(scene,camera) "
                                    "= depth key + 17-bit sort + projection + binning + composite"
                                    % (args.config, N, cfg["seed"], W, H),
-                       "early_out_eps": args.early_out_eps, "frames_in_flight": F, "emulated_rank": args.emulate_rank, "parallelism": "tile-column bands x%d%s" % (world, "" if world == 1 else (", %s all-gather, %s edges" % (args.exchange, "equal" if args.equal_bands else "cost-balanced"))),
+                       "early_out_eps": args.early_out_eps, "frames_in_flight": F, "stage_events_every": max(1, args.timing_interval), "emulated_rank": args.emulate_rank, "parallelism": "tile-column bands x%d%s" % (world, "" if world == 1 else (", %s all-gather, %s edges" % (args.exchange, "equal" if args.equal_bands else "cost-balanced"))),
                        "output": "RGBA f32 premultiplied, left in HBM"},
             "sorted_splats_per_sec": N / ((sm["project_key"] + sm["sort"]) * 1e-3),
             "stage_ms": ms,

@@ -71,6 +71,7 @@ struct gsr_ctx {
     uint32_t bin_blocks = 0, bin_capacity = 0, bin_table_elems = 0, bin_nbins_alloc = 0, blk_counts_alloc = 0;
     uint32_t max_items = 0, seg_len = 0, blend_grid = 2048;
     uint32_t seg_target_items = 5000;
+    uint32_t timing_every = 1, frame_no = 0;
     bool sort_culled = false;  // the last sort kept only the band's survivors (depth_index / keys are partial)
     // frame words
     FrameState* fstate = nullptr;       // device
@@ -154,8 +155,11 @@ bool band_is_partial(const gsr_ctx* c)
 
 // Compositor work-item granularity: list entries per (bin, segment) item.  0x7fffff00 = one item per
 // bin, which early termination needs (a segment cannot see whether earlier ones saturated the bin).
-constexpr uint32_t SEG_LEN_EXACT = 512;          // one frame at a time: short items, concurrency from the frame's own segments
-constexpr uint32_t SEG_LEN_THROUGHPUT = 2048;    // GSR_FLAG_THROUGHPUT: concurrency comes from the other frames in flight
+constexpr uint32_t SEG_LEN_MIN = 512;            // shortest segment; k_bin_finalize lengthens it so that the frame is cut
+                                                 // into about SEG_TARGET_* full segments (multiples of 256 entries)
+constexpr uint32_t SEG_TARGET_EXACT = 5000;      // one frame at a time: concurrency from the frame's own segments (C3: 512)
+constexpr uint32_t SEG_TARGET_THROUGHPUT = 1300; // GSR_FLAG_THROUGHPUT: concurrency comes from the other frames in flight
+                                                 // (C3: 2048-entry segments; a 1/8-screen band stays at 512)
 constexpr uint32_t BLEND_GRID_EXACT = 2048;      // persistent compositor workgroups (8 per CU requested, 7 resident)
 constexpr uint32_t BLEND_GRID_THROUGHPUT = 1536; // 6 per CU: leaves room for the other contexts' kernels
 constexpr uint32_t SEG_LEN_WHOLE_BIN = 0x7fffff00u;
@@ -189,7 +193,8 @@ int alloc_bins(gsr_ctx* c)
         items_dirty = true;
     }
     const bool throughput = (c->opt.flags & GSR_FLAG_THROUGHPUT) != 0;
-    c->seg_len = c->opt.early_out_eps > 0.0f ? SEG_LEN_WHOLE_BIN : throughput ? SEG_LEN_THROUGHPUT : SEG_LEN_EXACT;
+    c->seg_len = c->opt.early_out_eps > 0.0f ? SEG_LEN_WHOLE_BIN : SEG_LEN_MIN;
+    c->seg_target_items = throughput ? SEG_TARGET_THROUGHPUT : SEG_TARGET_EXACT;
     c->blend_grid = throughput ? BLEND_GRID_THROUGHPUT : BLEND_GRID_EXACT;
     if (const char* e = getenv("GSR_SEG_TARGET")) {  // tuning knob: full segments a frame is cut into at least
         const long v = atol(e);
@@ -234,7 +239,9 @@ int enqueue_frame(gsr_ctx* c, bool render)
     if (!c->have_cam) return fail(c, GSR_ERR_ARG, "gsr_set_camera has not been called");
     if (render && (!c->W || !c->H)) return fail(c, GSR_ERR_ARG, "framebuffer size is 0");
     hipStream_t s = c->stream;
-    const bool timing = c->ev_valid;
+    // stage timing is sampled: every timing_every-th frame carries the six events (each is a packet the command
+    // processor has to retire; on short frames they cost more than they measure)
+    const bool timing = c->ev_valid && (c->frame_no++ % c->timing_every) == 0;
     if (timing) {
         if (c->ev_pending == gsr_ctx::EV_RING) { if (int r = finish_frame(c)) return r; }
         const int slot = (c->ev_head + c->ev_pending) % gsr_ctx::EV_RING;
@@ -391,6 +398,7 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
     CREATE_TRY(hipMemcpy(c->fstate_init, c->fstate_host, sizeof(FrameState), hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(c->fstate, c->fstate_host, sizeof(FrameState), hipMemcpyHostToDevice));
     if (o.flags & GSR_FLAG_TIMING) {
+        if (const char* e = getenv("GSR_TIMING_EVERY")) c->timing_every = (uint32_t)std::max(1L, atol(e));
         for (auto& set : c->evring)
             for (auto& e : set) CREATE_TRY(hipEventCreate(&e));
         c->ev_valid = true;
@@ -780,6 +788,13 @@ int gsr_get_timings(gsr_ctx* c, gsr_timings* out)
     if (!c || !out) return GSR_ERR_ARG;
     if (c->ev_recorded) { if (int r = finish_frame(c)) return r; }
     *out = c->tm;
+    return GSR_OK;
+}
+
+int gsr_set_timing_interval(gsr_ctx* c, uint32_t every)
+{
+    if (!c || !every) return c ? fail(c, GSR_ERR_ARG, "timing interval must be >= 1") : GSR_ERR_ARG;
+    c->timing_every = every;
     return GSR_OK;
 }
 

@@ -51,7 +51,7 @@ EXPORTS = [
     "gsr_create", "gsr_destroy", "gsr_last_error", "gsr_set_scene", "gsr_set_scene_sh", "gsr_read_sh_colors", "gsr_set_depth_fade", "gsr_resize",
     "gsr_set_scene_rows", "gsr_scene_translate", "gsr_scene_rotate", "gsr_scene_scale", "gsr_scene_limit_box", "gsr_read_scene", "gsr_set_band", "gsr_set_camera",
     "gsr_sort", "gsr_render", "gsr_render_async", "gsr_sync", "gsr_read_depth_index", "gsr_read_pixels_rgba32f",
-    "gsr_read_pixels_rgba8", "gsr_get_timings", "gsr_reset_timings", "gsr_read_keys", "gsr_read_records",
+    "gsr_read_pixels_rgba8", "gsr_get_timings", "gsr_reset_timings", "gsr_set_timing_interval", "gsr_read_keys", "gsr_read_records",
     "gsr_read_bin_totals", "gsr_convert_rgba8_async", "gsr_framebuffer8_device_ptr",
     "gsr_pack_band_rgba8_async", "gsr_unpack_slabs_rgba8_async",
     "gsr_framebuffer_device_ptr", "gsr_stream_handle", "gsr_device_info", "gsplat_sort_host",
@@ -90,6 +90,7 @@ def load_library(path=None):
     L.gsr_read_pixels_rgba32f.argtypes = [vp, vp]
     L.gsr_read_pixels_rgba8.argtypes = [vp, vp]
     L.gsr_get_timings.argtypes = [vp, ctypes.POINTER(GsrTimings)]
+    L.gsr_set_timing_interval.argtypes = [vp, ctypes.c_uint32]
     L.gsr_read_keys.argtypes = [vp, vp, vp]
     L.gsr_read_records.argtypes = [vp, vp, vp]
     L.gsr_read_bin_totals.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
@@ -415,6 +416,10 @@ class HIPRenderer:
         nbx, nby = ctypes.c_int32(0), ctypes.c_int32(0)
         self._check(self._L.gsr_read_bin_totals(self._ctx, out.ctypes.data, ctypes.byref(nbx), ctypes.byref(nby)))
         return out[:nbx.value * nby.value].reshape(nby.value, nbx.value)
+
+    def set_timing_interval(self, every):
+        """Record stage events only on every `every`-th frame (they cost command-processor time on short frames)."""
+        self._check(self._L.gsr_set_timing_interval(self._ctx, every))
 
     def convert_rgba8_async(self):
         self._check(self._L.gsr_convert_rgba8_async(self._ctx))

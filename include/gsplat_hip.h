@@ -136,6 +136,10 @@ int gsr_read_pixels_rgba32f(gsr_ctx *ctx, float *out /* w*h*4, premultiplied, ro
 int gsr_read_pixels_rgba8(gsr_ctx *ctx, uint8_t *out /* w*h*4, round(clamp(x,0,1)*255)   */);
 int gsr_get_timings(gsr_ctx *ctx, gsr_timings *out);
 int gsr_reset_timings(gsr_ctx *ctx);
+/* With GSR_FLAG_TIMING: record the stage events only on every `every`-th frame (default 1).  The six events of a
+ * frame are packets the GPU's command processor has to retire; on short frames (small scenes, one band of a
+ * multi-GPU frame) timing every frame costs up to 15 % of the frame rate.  gsr_timings averages the sampled frames. */
+int gsr_set_timing_interval(gsr_ctx *ctx, uint32_t every);
 
 /* ---- parity/debug read-backs (intermediate device buffers of the last frame) ---- */
 int gsr_read_keys(gsr_ctx *ctx, uint32_t *keys /* n, 17-bit */, int32_t *minmax /* 2 */);
