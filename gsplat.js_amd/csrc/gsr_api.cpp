@@ -84,6 +84,12 @@ struct gsr_ctx {
     size_t fb_pixels = 0;
 
     CamParams cam{};
+    CamParams* cam_dev = nullptr;     // the frame's camera in device memory (k_set_camera)
+    // the frame's launch chain replayed as a HIP graph (frames that carry no stage events)
+    bool graphs_enabled = true;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    std::vector<uint64_t> graph_sig;  // everything the chain's kernel arguments and grids derive from
     bool have_cam = false, have_frame = false, have_sort = false;
 
     // timing: a ring of event sets so that frames can be enqueued back to back without a host
@@ -233,34 +239,15 @@ int alloc_fb(gsr_ctx* c)
 
 int finish_frame(gsr_ctx* c);
 
-// enqueue: frame words reset, projection + depth key, sort, (bin, blend)
-int enqueue_frame(gsr_ctx* c, bool render)
+// the frame's device work on the context's stream: frame words reset, projection + depth key, sort, (bin, blend)
+static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
 {
-    if (!c->have_cam) return fail(c, GSR_ERR_ARG, "gsr_set_camera has not been called");
-    if (render && (!c->W || !c->H)) return fail(c, GSR_ERR_ARG, "framebuffer size is 0");
     hipStream_t s = c->stream;
-    // stage timing is sampled: every timing_every-th frame carries the six events (each is a packet the command
-    // processor has to retire; on short frames they cost more than they measure)
-    const bool timing = c->ev_valid && (c->frame_no++ % c->timing_every) == 0;
-    if (timing) {
-        if (c->ev_pending == gsr_ctx::EV_RING) { if (int r = finish_frame(c)) return r; }
-        const int slot = (c->ev_head + c->ev_pending) % gsr_ctx::EV_RING;
-        c->ev = c->evring[slot];
-        c->ev_is_render[slot] = render;
-    }
-    c->cam.W = c->W; c->cam.H = c->H;
-    {
-        const BinGrid bg = make_grid(c);
-        c->cam.band_px0 = bg.bx_lo * BIN_PX;
-        c->cam.band_px1 = bg.bx_hi * BIN_PX;
-    }
-    c->cam.sh_on = c->sh_count ? 1 : 0;
-    c->cam.band[0] = c->band[0]; c->cam.band[1] = c->band[1]; c->cam.band[2] = c->band[2];
     HIP_TRY(c, hipMemcpyAsync(c->fstate, c->fstate_init, sizeof(FrameState), hipMemcpyDeviceToDevice, s));
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BEGIN], s));
     if (c->n) {
         SceneSoA sc{c->px, c->py, c->pz, c->cov0, c->cov1, c->cov2, c->rgba, c->sh_r, c->sh_g, c->sh_b, c->shcol};
-        launch_project_key(sc, c->n, c->cam, render ? 1 : 0, c->depth, c->fstate->minmax, c->rec, c->bbox, s);
+        launch_project_key(sc, c->n, c->cam_dev, render ? 1 : 0, c->depth, c->fstate->minmax, c->rec, c->bbox, s);
     }
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_PROJECT], s));
     if (c->n) {
@@ -290,6 +277,89 @@ int enqueue_frame(gsr_ctx* c, bool render)
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_COMBINE], s));
     }
     HIP_TRY(c, hipGetLastError());
+    return GSR_OK;
+}
+
+static void drop_graph(gsr_ctx* c)
+{
+    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+    if (c->graph) (void)hipGraphDestroy(c->graph);
+    c->graph_exec = nullptr; c->graph = nullptr;
+    c->graph_sig.clear();
+}
+
+// Every value the chain's kernel arguments, grids and LDS sizes derive from.  The camera is not among them: it is
+// read from c->cam_dev.  A graph captured for one signature is replayed while the signature stays the same.
+static std::vector<uint64_t> chain_signature(const gsr_ctx* c)
+{
+    const BinGrid g = make_grid(c);
+    std::vector<uint64_t> v;
+    auto P = [&v](const void* p) { v.push_back((uint64_t)(uintptr_t)p); };
+    auto U = [&v](uint64_t x) { v.push_back(x); };
+    P(c->px); P(c->py); P(c->pz); P(c->cov0); P(c->cov1); P(c->cov2); P(c->rgba); P(c->sh_r); P(c->sh_g); P(c->sh_b); P(c->shcol);
+    P(c->depth); P(c->keys); P(c->keys_tmp); P(c->idx_tmp); P(c->depth_index); P(c->block_hist); P(c->fstate); P(c->fstate_init);
+    P(c->rec); P(c->bbox); P(c->bin_table); P(c->blk_counts); P(c->bin_rects); P(c->bin_total); P(c->bin_start); P(c->seg_start);
+    P(c->items); P(c->bin_list); P(c->partial); P(c->fb); P(c->accum); P(c->cam_dev);
+    U(c->n); U((uint64_t)c->W); U((uint64_t)c->H); U((uint64_t)g.bx_lo); U((uint64_t)g.bx_hi); U(c->sort_kpb); U(c->sort_blocks);
+    U(c->bin_capacity); U(c->max_items); U(c->seg_len); U(c->seg_target_items); U(c->blend_grid); U(c->bin_blocks);
+    U((uint64_t)c->opt.flags); U((uint64_t)(c->opt.early_out_eps * 1e9f));
+    return v;
+}
+
+// enqueue one frame: camera into its device slot, then the chain -- as individual launches when the frame carries
+// stage events or is sort-only, as one graph launch otherwise (13 launches and a copy become one: the host issues a
+// frame in ~12 us instead of ~45 us, which is what a rank of a multi-GPU run or a small scene is bound by)
+int enqueue_frame(gsr_ctx* c, bool render)
+{
+    if (!c->have_cam) return fail(c, GSR_ERR_ARG, "gsr_set_camera has not been called");
+    if (render && (!c->W || !c->H)) return fail(c, GSR_ERR_ARG, "framebuffer size is 0");
+    hipStream_t s = c->stream;
+    // stage timing is sampled: every timing_every-th frame carries the six events (each is a packet the command
+    // processor has to retire; on short frames they cost more than they measure)
+    const bool timing = c->ev_valid && (c->frame_no++ % c->timing_every) == 0;
+    if (timing) {
+        if (c->ev_pending == gsr_ctx::EV_RING) { if (int r = finish_frame(c)) return r; }
+        const int slot = (c->ev_head + c->ev_pending) % gsr_ctx::EV_RING;
+        c->ev = c->evring[slot];
+        c->ev_is_render[slot] = render;
+    }
+    c->cam.W = c->W; c->cam.H = c->H;
+    {
+        const BinGrid bg = make_grid(c);
+        c->cam.band_px0 = bg.bx_lo * BIN_PX;
+        c->cam.band_px1 = bg.bx_hi * BIN_PX;
+    }
+    c->cam.sh_on = c->sh_count ? 1 : 0;
+    c->cam.band[0] = c->band[0]; c->cam.band[1] = c->band[1]; c->cam.band[2] = c->band[2];
+    launch_set_camera(c->cam, c->cam_dev, s);
+
+    bool replayed = false;
+    if (c->graphs_enabled && render && !timing) {
+        std::vector<uint64_t> sig = chain_signature(c);
+        if (!c->graph_exec || sig != c->graph_sig) {
+            drop_graph(c);
+            bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess;
+            if (ok) {
+                const int r = enqueue_chain(c, true, false);
+                hipGraph_t gph = nullptr;
+                ok = (hipStreamEndCapture(s, &gph) == hipSuccess) && r == GSR_OK && gph;
+                if (ok) ok = hipGraphInstantiate(&c->graph_exec, gph, nullptr, nullptr, 0) == hipSuccess;
+                if (ok) { c->graph = gph; c->graph_sig = std::move(sig); }
+                else if (gph) (void)hipGraphDestroy(gph);
+            }
+            if (!ok) {  // this runtime cannot capture the chain: individual launches from now on
+                (void)hipGetLastError();
+                drop_graph(c);
+                c->graphs_enabled = false;
+            }
+        }
+        if (c->graph_exec) {
+            HIP_TRY(c, hipGraphLaunch(c->graph_exec, s));
+            c->sort_culled = band_is_partial(c);
+            replayed = true;
+        }
+    }
+    if (!replayed) { if (int r = enqueue_chain(c, render, timing)) return r; }
     if (timing) c->ev_pending++;
     c->ev_recorded = timing;
     c->ev_render = render;
@@ -389,6 +459,8 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
     CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CREATE_TRY(hipMalloc((void**)&c->fstate, sizeof(FrameState)));
     CREATE_TRY(hipMalloc((void**)&c->fstate_init, sizeof(FrameState)));
+    CREATE_TRY(hipMalloc((void**)&c->cam_dev, sizeof(CamParams)));
+    if (const char* e = getenv("GSR_NO_GRAPH")) c->graphs_enabled = atoi(e) == 0;
     CREATE_TRY(hipMalloc((void**)&c->accum, 8 * sizeof(uint64_t)));
     CREATE_TRY(hipMemset(c->accum, 0, 8 * sizeof(uint64_t)));
     CREATE_TRY(hipHostMalloc((void**)&c->fstate_host, sizeof(FrameState), hipHostMallocDefault));
@@ -429,6 +501,8 @@ int gsr_destroy(gsr_ctx* c)
     dev_free(&c->block_hist); dev_free(&c->rec); dev_free(&c->bbox);
     dev_free(&c->bin_table); dev_free(&c->bin_total); dev_free(&c->bin_start); dev_free(&c->bin_list);
     dev_free(&c->seg_start); dev_free(&c->items); dev_free(&c->blk_counts); dev_free(&c->partial); dev_free(&c->bin_rects);
+    drop_graph(c);
+    dev_free(&c->cam_dev);
     dev_free(&c->fstate); dev_free(&c->fstate_init); dev_free(&c->accum); dev_free(&c->fb); dev_free(&c->fb8);
     if (c->fstate_host) (void)hipHostFree(c->fstate_host);
     for (auto& set : c->evring)

@@ -71,7 +71,8 @@ void launch_scene_limit_box(uint32_t n, const SceneDev& src, const SceneDev& dst
 void launch_repack_scene(const uint32_t* data, const float* positions, uint32_t n, float* px, float* py, float* pz,
                          uint32_t* cov0, uint32_t* cov1, uint32_t* cov2, uint32_t* rgba, uint32_t* mismatch, hipStream_t s);
 
-void launch_project_key(const SceneSoA& sc, uint32_t n, const CamParams& cam, int do_project, int32_t* depth,
+void launch_set_camera(const CamParams& cam, CamParams* dst, hipStream_t s);
+void launch_project_key(const SceneSoA& sc, uint32_t n, const CamParams* cam_dev, int do_project, int32_t* depth,
                         int32_t* minmax, Record* rec, uint2* bbox, hipStream_t s);
 
 // radix sort of the 17-bit keys; see k_sort.hip

@@ -120,10 +120,14 @@ __device__ __forceinline__ float eval_sh_texture(const uint32_t* __restrict__ te
 // Writes depth[i] always; rec[i] for splats that survive the culls; bbox[i] always
 // (x0 > x1 marks "nothing to draw").
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_project_key(SceneSoA sc, uint32_t n, CamParams cam, int do_project,
-                                                     int32_t* __restrict__ depth, int32_t* __restrict__ minmax,
-                                                     Record* __restrict__ rec, uint2* __restrict__ bbox)
+// The camera lives in device memory (written by k_set_camera just before the frame) so that the frame's kernel
+// arguments do not change from frame to frame and the whole chain can be replayed as a HIP graph.
+__global__ __launch_bounds__(256) void k_project_key(SceneSoA sc, uint32_t n, const CamParams* __restrict__ camp,
+                                                     int do_project, int32_t* __restrict__ depth,
+                                                     int32_t* __restrict__ minmax, Record* __restrict__ rec,
+                                                     uint2* __restrict__ bbox)
 {
+    const CamParams& cam = *camp;  // uniform address: scalar loads
     __shared__ int32_t s_min[4], s_max[4];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     int32_t dmin = 0x7fffffff, dmax = (int32_t)0x80000000;
@@ -294,12 +298,26 @@ __global__ __launch_bounds__(256) void k_project_key(SceneSoA sc, uint32_t n, Ca
     }
 }
 
-void launch_project_key(const SceneSoA& sc, uint32_t n, const CamParams& cam, int do_project, int32_t* depth,
+void launch_project_key(const SceneSoA& sc, uint32_t n, const CamParams* cam, int do_project, int32_t* depth,
                         int32_t* minmax, Record* rec, uint2* bbox, hipStream_t s)
 {
     if (!n) return;
     hipLaunchKernelGGL(k_project_key, dim3((n + 255) / 256), dim3(256), 0, s, sc, n, cam, do_project, depth, minmax, rec,
                        bbox);
+}
+
+// one wave copies the by-value camera into its device slot (kernarg -> global), ordered on the frame's stream
+__global__ void k_set_camera(CamParams cam, CamParams* __restrict__ dst)
+{
+    constexpr int WORDS = sizeof(CamParams) / 4;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&cam);
+    if (threadIdx.x < WORDS) reinterpret_cast<uint32_t*>(dst)[threadIdx.x] = src[threadIdx.x];
+}
+
+void launch_set_camera(const CamParams& cam, CamParams* dst, hipStream_t s)
+{
+    static_assert(sizeof(CamParams) % 4 == 0 && sizeof(CamParams) / 4 <= 64, "one wave copies the camera");
+    hipLaunchKernelGGL(k_set_camera, dim3(1), dim3(64), 0, s, cam, dst);
 }
 
 }  // namespace gsr
