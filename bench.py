@@ -239,6 +239,20 @@ def main():
         f1 = max(int(s1["frames"]), 1)
         solo = {"frames_per_sec": 60 / dt, "ms_per_frame": dt / 60 * 1e3,
                 "stage_ms": {k: s1["sum_ms_" + k] / f1 for k in ("project_key", "sort", "bin", "blend", "combine", "total")}}
+        # the sort path alone, as the reference's worker runs it (wasm.cpp sort(): key + min/max + quantise + order):
+        # gsr_sort = key kernel without projection + the two radix passes
+        sr.reset_stats()
+        for k in range(30):
+            v, p, vp = poses[k % ORBIT_FRAMES]
+            sr.set_camera_arrays(v, p, vp, cfg["fx"], cfg["fx"])
+            sr.sort()
+        s2 = sr.stats()
+        f2 = max(int(s2["frames"]), 1)
+        t_key, t_sort = s2["sum_ms_project_key"] / f2, s2["sum_ms_sort"] / f2
+        solo["sort_only"] = {"ms_key_minmax": t_key, "ms_quantise_radix": t_sort,
+                             "sorted_splats_per_sec": N / ((t_key + t_sort) * 1e-3),
+                             "GBps": 52.0 * N / ((t_key + t_sort) * 1e-3) / 1e9,
+                             "frac_of_hbm_peak": 52.0 * N / ((t_key + t_sort) * 1e-3) / 1e9 / HBM_PEAK_GBS}
         sr.dispose()
 
     if rank == 0:

@@ -61,6 +61,7 @@ struct gsr_ctx {
     uint32_t* block_hist = nullptr;
     Record* rec = nullptr;
     uint2* bbox = nullptr;
+    int2* blk_minmax = nullptr;   // per-workgroup (min, max) depth of k_project_key, folded by k_minmax_reduce
     uint32_t sort_blocks = 0, sort_kpb = 0;
     // binning
     uint32_t *bin_table = nullptr, *bin_total = nullptr, *bin_start = nullptr, *bin_list = nullptr;
@@ -247,7 +248,7 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BEGIN], s));
     if (c->n) {
         SceneSoA sc{c->px, c->py, c->pz, c->cov0, c->cov1, c->cov2, c->rgba, c->sh_r, c->sh_g, c->sh_b, c->shcol};
-        launch_project_key(sc, c->n, c->cam_dev, render ? 1 : 0, c->depth, c->fstate->minmax, c->rec, c->bbox, s);
+        launch_project_key(sc, c->n, c->cam_dev, render ? 1 : 0, c->depth, c->blk_minmax, c->fstate->minmax, c->rec, c->bbox, s);
     }
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_PROJECT], s));
     if (c->n) {
@@ -267,7 +268,7 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
         if (!c->n) HIP_TRY(c, hipMemsetAsync(c->bin_total, 0, sizeof(uint32_t) * nbins, s));
         BinBuffers bb{c->depth_index, &c->fstate->sorted_count, c->bbox, c->bin_table, c->blk_counts, c->bin_rects, c->bin_total, c->bin_start, c->seg_start,
                       c->items, c->bin_list, &c->fstate->overflow, &c->fstate->visible, &c->fstate->tile_entries,
-                      c->accum, c->bin_capacity, c->max_items, c->seg_len, &c->fstate->seg_len, (c->opt.flags & GSR_FLAG_THROUGHPUT) ? 0 : 1, c->seg_target_items, c->bin_blocks};
+                      c->accum, c->bin_capacity, c->max_items, c->seg_len, &c->fstate->seg_len, (c->opt.flags & GSR_FLAG_THROUGHPUT) ? 0 : 1, &c->fstate->queue, std::min<uint32_t>(c->max_items, c->blend_grid), c->seg_target_items, c->bin_blocks};
         launch_bin(bb, g, c->n, s);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BIN], s));
         BlendBuffers bl{c->items, c->seg_start, c->bin_start, c->bin_list, c->rec, c->bbox, c->shcol, c->fb, c->partial,
@@ -298,7 +299,7 @@ static std::vector<uint64_t> chain_signature(const gsr_ctx* c)
     auto U = [&v](uint64_t x) { v.push_back(x); };
     P(c->px); P(c->py); P(c->pz); P(c->cov0); P(c->cov1); P(c->cov2); P(c->rgba); P(c->sh_r); P(c->sh_g); P(c->sh_b); P(c->shcol);
     P(c->depth); P(c->keys); P(c->keys_tmp); P(c->idx_tmp); P(c->depth_index); P(c->block_hist); P(c->fstate); P(c->fstate_init);
-    P(c->rec); P(c->bbox); P(c->bin_table); P(c->blk_counts); P(c->bin_rects); P(c->bin_total); P(c->bin_start); P(c->seg_start);
+    P(c->rec); P(c->bbox); P(c->blk_minmax); P(c->bin_table); P(c->blk_counts); P(c->bin_rects); P(c->bin_total); P(c->bin_start); P(c->seg_start);
     P(c->items); P(c->bin_list); P(c->partial); P(c->fb); P(c->accum); P(c->cam_dev);
     U(c->n); U((uint64_t)c->W); U((uint64_t)c->H); U((uint64_t)g.bx_lo); U((uint64_t)g.bx_hi); U(c->sort_kpb); U(c->sort_blocks);
     U(c->bin_capacity); U(c->max_items); U(c->seg_len); U(c->seg_target_items); U(c->blend_grid); U(c->bin_blocks);
@@ -498,7 +499,7 @@ int gsr_destroy(gsr_ctx* c)
     dev_free(&c->sh_r); dev_free(&c->sh_g); dev_free(&c->sh_b); dev_free(&c->shcol);
     dev_free(&c->rotv); dev_free(&c->sclv);
     dev_free(&c->depth); dev_free(&c->keys); dev_free(&c->keys_tmp); dev_free(&c->idx_tmp); dev_free(&c->depth_index);
-    dev_free(&c->block_hist); dev_free(&c->rec); dev_free(&c->bbox);
+    dev_free(&c->block_hist); dev_free(&c->rec); dev_free(&c->bbox); dev_free(&c->blk_minmax);
     dev_free(&c->bin_table); dev_free(&c->bin_total); dev_free(&c->bin_start); dev_free(&c->bin_list);
     dev_free(&c->seg_start); dev_free(&c->items); dev_free(&c->blk_counts); dev_free(&c->partial); dev_free(&c->bin_rects);
     drop_graph(c);
@@ -529,7 +530,7 @@ int alloc_scene(gsr_ctx* c, uint32_t n, bool with_rows)
         (r = dev_alloc(c, &c->rgba, n)) || (r = dev_alloc(c, &c->depth, n)) || (r = dev_alloc(c, &c->keys, n)) ||
         (r = dev_alloc(c, &c->keys_tmp, n)) || (r = dev_alloc(c, &c->idx_tmp, n)) ||
         (r = dev_alloc(c, &c->depth_index, n)) || (r = dev_alloc(c, &c->rec, n)) || (r = dev_alloc(c, &c->bbox, n)) ||
-        (r = dev_alloc(c, &c->bin_rects, n)))
+        (r = dev_alloc(c, &c->bin_rects, n)) || (r = dev_alloc(c, &c->blk_minmax, (n + 255) / 256)))
         return r;
     if (with_rows && ((r = dev_alloc(c, &c->rotv, n)) || (r = dev_alloc(c, &c->sclv, n)))) return r;
     c->sort_kpb = 2048;

@@ -73,7 +73,7 @@ void launch_repack_scene(const uint32_t* data, const float* positions, uint32_t 
 
 void launch_set_camera(const CamParams& cam, CamParams* dst, hipStream_t s);
 void launch_project_key(const SceneSoA& sc, uint32_t n, const CamParams* cam_dev, int do_project, int32_t* depth,
-                        int32_t* minmax, Record* rec, uint2* bbox, hipStream_t s);
+                        int2* blk_minmax /* ceil(n/256) */, int32_t* minmax, Record* rec, uint2* bbox, hipStream_t s);
 
 // radix sort of the 17-bit keys; see k_sort.hip
 struct SortBuffers {
@@ -121,6 +121,8 @@ struct BinBuffers {
                                  // raises it for long lists and publishes the frame's value in *seg_len_dev
     uint32_t* seg_len_dev;
     int32_t items_by_size;       // order the bins' last segments by size class (one frame at a time) or leave them in raster order
+    uint32_t* queue;             // the compositor's work-item counter, set to queue_start (= its grid size) by k_bin_finalize
+    uint32_t queue_start;
     uint32_t seg_target_items;   // full segments the frame should be cut into at least (long lists -> longer segments)
     uint32_t nblocks;
 };

@@ -63,12 +63,16 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
 
     // Work items come from one device-wide queue (items are ordered heaviest first), so a workgroup
     // that drew light items simply draws more: no static assignment, no long pole.
+    // The first item of a workgroup is its own index (the queue starts at gridDim.x, k_bin_finalize sets it): a
+    // kernel start with ~2000 workgroups drawing from one counter serialises ~2000 same-address atomics.
+    bool first = true;
     for (;;) {
         __syncthreads();  // the previous item no longer uses the LDS words
         if (threadIdx.x == 0) {
-            s_item = atomicAdd(queue, 1u);
+            s_item = first ? blockIdx.x : atomicAdd(queue, 1u);
             s_done = 0;
         }
+        first = false;
         __syncthreads();
         const uint32_t qi = s_item;
         if (qi >= total_items) break;

@@ -124,7 +124,7 @@ __device__ __forceinline__ float eval_sh_texture(const uint32_t* __restrict__ te
 // arguments do not change from frame to frame and the whole chain can be replayed as a HIP graph.
 __global__ __launch_bounds__(256) void k_project_key(SceneSoA sc, uint32_t n, const CamParams* __restrict__ camp,
                                                      int do_project, int32_t* __restrict__ depth,
-                                                     int32_t* __restrict__ minmax, Record* __restrict__ rec,
+                                                     int2* __restrict__ blk_minmax, Record* __restrict__ rec,
                                                      uint2* __restrict__ bbox)
 {
     const CamParams& cam = *camp;  // uniform address: scalar loads
@@ -279,7 +279,9 @@ __global__ __launch_bounds__(256) void k_project_key(SceneSoA sc, uint32_t n, co
         }
     }
 
-    // ---- block min/max -> two global atomics per block ----
+    // ---- block min/max -> one pair per workgroup; k_minmax_reduce folds the pairs.  Not atomics on the two global
+    //      words: the first wave of workgroups all see the initial bounds and ~4000 same-address atomics serialise at one
+    //      L2 channel, which kept this kernel alive for ~30 us after its last store (key-only call: 35 -> 8 us) ----
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         dmin = min(dmin, __shfl_xor(dmin, off));
@@ -288,22 +290,41 @@ __global__ __launch_bounds__(256) void k_project_key(SceneSoA sc, uint32_t n, co
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { s_min[wave] = dmin; s_max[wave] = dmax; }
     __syncthreads();
+    if (threadIdx.x == 0)
+        blk_minmax[blockIdx.x] = make_int2(min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3])),
+                                           max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
+}
+
+// one workgroup: minmax[0..1] = min / max over the per-workgroup pairs (wasm/wasm.cpp:14-31's running min/max)
+__global__ __launch_bounds__(1024) void k_minmax_reduce(const int2* __restrict__ blk_minmax, uint32_t nblocks,
+                                                         int32_t* __restrict__ minmax)
+{
+    __shared__ int32_t s_min[16], s_max[16];
+    int32_t dmin = 0x7fffffff, dmax = (int32_t)0x80000000;
+    for (uint32_t b = threadIdx.x; b < nblocks; b += 1024) {
+        const int2 v = blk_minmax[b];
+        dmin = min(dmin, v.x); dmax = max(dmax, v.y);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        dmin = min(dmin, __shfl_xor(dmin, off));
+        dmax = max(dmax, __shfl_xor(dmax, off));
+    }
+    if ((threadIdx.x & 63) == 0) { s_min[threadIdx.x >> 6] = dmin; s_max[threadIdx.x >> 6] = dmax; }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        dmin = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
-        dmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-        // ~4000 workgroups on two words: only those that would move the bound issue the atomic.  The plain
-        // (agent-scope, L1-bypassing) read may be stale, which can only cost a redundant atomic, never lose one.
-        if (dmin < __hip_atomic_load(&minmax[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&minmax[0], dmin);
-        if (dmax > __hip_atomic_load(&minmax[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&minmax[1], dmax);
+        for (int w = 0; w < 16; w++) { dmin = min(dmin, s_min[w]); dmax = max(dmax, s_max[w]); }
+        minmax[0] = dmin; minmax[1] = dmax;
     }
 }
 
 void launch_project_key(const SceneSoA& sc, uint32_t n, const CamParams* cam, int do_project, int32_t* depth,
-                        int32_t* minmax, Record* rec, uint2* bbox, hipStream_t s)
+                        int2* blk_minmax, int32_t* minmax, Record* rec, uint2* bbox, hipStream_t s)
 {
     if (!n) return;
-    hipLaunchKernelGGL(k_project_key, dim3((n + 255) / 256), dim3(256), 0, s, sc, n, cam, do_project, depth, minmax, rec,
-                       bbox);
+    const uint32_t nblocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_project_key, dim3(nblocks), dim3(256), 0, s, sc, n, cam, do_project, depth, blk_minmax, rec, bbox);
+    hipLaunchKernelGGL(k_minmax_reduce, dim3(1), dim3(1024), 0, s, (const int2*)blk_minmax, nblocks, minmax);
 }
 
 // one wave copies the by-value camera into its device slot (kernarg -> global), ordered on the frame's stream
