@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <cstddef>
 #include <string>
 #include <vector>
 
@@ -22,7 +23,7 @@ thread_local std::string g_create_error;
 
 enum Stage { EV_BEGIN = 0, EV_PROJECT, EV_SORT, EV_BIN, EV_BLEND /* after k_blend */, EV_COMBINE /* after k_combine */, EV_COUNT };
 
-struct FrameState {  // small per-frame device words, (re)initialised by one memcpy per frame
+struct FrameState {  // small per-frame device words, reset by k_begin_frame (minmax to +max / -max, the rest to zero)
     int32_t minmax[2];
     uint32_t overflow;
     uint32_t queue;   // compositor work-item counter
@@ -76,7 +77,6 @@ struct gsr_ctx {
     bool sort_culled = false;  // the last sort kept only the band's survivors (depth_index / keys are partial)
     // frame words
     FrameState* fstate = nullptr;       // device
-    FrameState* fstate_init = nullptr;  // device, constant image copied into fstate every frame
     FrameState* fstate_host = nullptr;  // pinned
     uint64_t* accum = nullptr;          // device [4]: sums over frames (visible, bin entries, tile entries, frames)
     // output
@@ -244,7 +244,6 @@ int finish_frame(gsr_ctx* c);
 static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
 {
     hipStream_t s = c->stream;
-    HIP_TRY(c, hipMemcpyAsync(c->fstate, c->fstate_init, sizeof(FrameState), hipMemcpyDeviceToDevice, s));
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BEGIN], s));
     if (c->n) {
         SceneSoA sc{c->px, c->py, c->pz, c->cov0, c->cov1, c->cov2, c->rgba, c->sh_r, c->sh_g, c->sh_b, c->shcol};
@@ -298,7 +297,7 @@ static std::vector<uint64_t> chain_signature(const gsr_ctx* c)
     auto P = [&v](const void* p) { v.push_back((uint64_t)(uintptr_t)p); };
     auto U = [&v](uint64_t x) { v.push_back(x); };
     P(c->px); P(c->py); P(c->pz); P(c->cov0); P(c->cov1); P(c->cov2); P(c->rgba); P(c->sh_r); P(c->sh_g); P(c->sh_b); P(c->shcol);
-    P(c->depth); P(c->keys); P(c->keys_tmp); P(c->idx_tmp); P(c->depth_index); P(c->block_hist); P(c->fstate); P(c->fstate_init);
+    P(c->depth); P(c->keys); P(c->keys_tmp); P(c->idx_tmp); P(c->depth_index); P(c->block_hist); P(c->fstate);
     P(c->rec); P(c->bbox); P(c->blk_minmax); P(c->bin_table); P(c->blk_counts); P(c->bin_rects); P(c->bin_total); P(c->bin_start); P(c->seg_start);
     P(c->items); P(c->bin_list); P(c->partial); P(c->fb); P(c->accum); P(c->cam_dev);
     U(c->n); U((uint64_t)c->W); U((uint64_t)c->H); U((uint64_t)g.bx_lo); U((uint64_t)g.bx_hi); U(c->sort_kpb); U(c->sort_blocks);
@@ -332,7 +331,8 @@ int enqueue_frame(gsr_ctx* c, bool render)
     }
     c->cam.sh_on = c->sh_count ? 1 : 0;
     c->cam.band[0] = c->band[0]; c->cam.band[1] = c->band[1]; c->cam.band[2] = c->band[2];
-    launch_set_camera(c->cam, c->cam_dev, s);
+    static_assert(offsetof(FrameState, minmax) == 0 && sizeof(FrameState) % 4 == 0, "k_begin_frame resets the frame words");
+    launch_begin_frame(c->cam, c->cam_dev, reinterpret_cast<uint32_t*>(c->fstate), (uint32_t)(sizeof(FrameState) / 4), s);
 
     bool replayed = false;
     if (c->graphs_enabled && render && !timing) {
@@ -459,7 +459,6 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
     CREATE_TRY(hipSetDevice(c->device));
     CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CREATE_TRY(hipMalloc((void**)&c->fstate, sizeof(FrameState)));
-    CREATE_TRY(hipMalloc((void**)&c->fstate_init, sizeof(FrameState)));
     CREATE_TRY(hipMalloc((void**)&c->cam_dev, sizeof(CamParams)));
     if (const char* e = getenv("GSR_NO_GRAPH")) c->graphs_enabled = atoi(e) == 0;
     CREATE_TRY(hipMalloc((void**)&c->accum, 8 * sizeof(uint64_t)));
@@ -468,7 +467,6 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
     memset(c->fstate_host, 0, sizeof(FrameState));
     c->fstate_host->minmax[0] = 0x7fffffff;            // wasm/wasm.cpp:14
     c->fstate_host->minmax[1] = (int32_t)0x80000000;   // wasm/wasm.cpp:15
-    CREATE_TRY(hipMemcpy(c->fstate_init, c->fstate_host, sizeof(FrameState), hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(c->fstate, c->fstate_host, sizeof(FrameState), hipMemcpyHostToDevice));
     if (o.flags & GSR_FLAG_TIMING) {
         if (const char* e = getenv("GSR_TIMING_EVERY")) c->timing_every = (uint32_t)std::max(1L, atol(e));
@@ -504,7 +502,7 @@ int gsr_destroy(gsr_ctx* c)
     dev_free(&c->seg_start); dev_free(&c->items); dev_free(&c->blk_counts); dev_free(&c->partial); dev_free(&c->bin_rects);
     drop_graph(c);
     dev_free(&c->cam_dev);
-    dev_free(&c->fstate); dev_free(&c->fstate_init); dev_free(&c->accum); dev_free(&c->fb); dev_free(&c->fb8);
+    dev_free(&c->fstate); dev_free(&c->accum); dev_free(&c->fb); dev_free(&c->fb8);
     if (c->fstate_host) (void)hipHostFree(c->fstate_host);
     for (auto& set : c->evring)
         for (auto& e : set) if (e) (void)hipEventDestroy(e);

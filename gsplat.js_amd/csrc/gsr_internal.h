@@ -71,7 +71,8 @@ void launch_scene_limit_box(uint32_t n, const SceneDev& src, const SceneDev& dst
 void launch_repack_scene(const uint32_t* data, const float* positions, uint32_t n, float* px, float* py, float* pz,
                          uint32_t* cov0, uint32_t* cov1, uint32_t* cov2, uint32_t* rgba, uint32_t* mismatch, hipStream_t s);
 
-void launch_set_camera(const CamParams& cam, CamParams* dst, hipStream_t s);
+// frame_words: the context's per-frame device words, [0] = minDepth, [1] = maxDepth, the rest zero at frame start
+void launch_begin_frame(const CamParams& cam, CamParams* dst, uint32_t* frame_words, uint32_t nwords, hipStream_t s);
 void launch_project_key(const SceneSoA& sc, uint32_t n, const CamParams* cam_dev, int do_project, int32_t* depth,
                         int2* blk_minmax /* ceil(n/256) */, int32_t* minmax, Record* rec, uint2* bbox, hipStream_t s);
 

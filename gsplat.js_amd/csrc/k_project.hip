@@ -327,18 +327,21 @@ void launch_project_key(const SceneSoA& sc, uint32_t n, const CamParams* cam, in
     hipLaunchKernelGGL(k_minmax_reduce, dim3(1), dim3(1024), 0, s, (const int2*)blk_minmax, nblocks, minmax);
 }
 
-// one wave copies the by-value camera into its device slot (kernarg -> global), ordered on the frame's stream
-__global__ void k_set_camera(CamParams cam, CamParams* __restrict__ dst)
+// Start of a frame, one small workgroup: the by-value camera goes to its device slot (kernarg -> global) and the
+// frame's device words are reset (minDepth / maxDepth to the values wasm/wasm.cpp:14-15 starts from, everything
+// else to zero).  One launch instead of a copy kernel plus a setter.
+__global__ void k_begin_frame(CamParams cam, CamParams* __restrict__ dst, uint32_t* __restrict__ frame_words, uint32_t nwords)
 {
-    constexpr int WORDS = sizeof(CamParams) / 4;
+    constexpr uint32_t WORDS = sizeof(CamParams) / 4;
     const uint32_t* src = reinterpret_cast<const uint32_t*>(&cam);
-    if (threadIdx.x < WORDS) reinterpret_cast<uint32_t*>(dst)[threadIdx.x] = src[threadIdx.x];
+    for (uint32_t w = threadIdx.x; w < WORDS; w += blockDim.x) reinterpret_cast<uint32_t*>(dst)[w] = src[w];
+    for (uint32_t w = threadIdx.x; w < nwords; w += blockDim.x) frame_words[w] = w == 0 ? 0x7fffffffu : w == 1 ? 0x80000000u : 0u;
 }
 
-void launch_set_camera(const CamParams& cam, CamParams* dst, hipStream_t s)
+void launch_begin_frame(const CamParams& cam, CamParams* dst, uint32_t* frame_words, uint32_t nwords, hipStream_t s)
 {
-    static_assert(sizeof(CamParams) % 4 == 0 && sizeof(CamParams) / 4 <= 64, "one wave copies the camera");
-    hipLaunchKernelGGL(k_set_camera, dim3(1), dim3(64), 0, s, cam, dst);
+    static_assert(sizeof(CamParams) % 4 == 0, "camera is copied word by word");
+    hipLaunchKernelGGL(k_begin_frame, dim3(1), dim3(256), 0, s, cam, dst, frame_words, nwords);
 }
 
 }  // namespace gsr

@@ -481,6 +481,34 @@ def test_native_slab_exchange_single_device(gh, scenes):
     whole.dispose()
 
 
+def test_graph_replay_equals_individual_launches(gh, scenes, monkeypatch):
+    # frames without stage events are replayed from a captured HIP graph; the same frames issued as individual launches
+    # (GSR_NO_GRAPH=1 at context creation) must give identical pixels and permutations, across camera changes, a resize
+    # (new chain signature -> recapture) and sampled timing (every 3rd frame takes the individual-launch path)
+    cfg = gh.synth.CONFIGS["C1"]
+    rows, data, pos = scenes("C1")
+    monkeypatch.setenv("GSR_NO_GRAPH", "1")
+    plain = gh.HIPRenderer(cfg["width"], cfg["height"])
+    monkeypatch.delenv("GSR_NO_GRAPH")
+    graph = gh.HIPRenderer(cfg["width"], cfg["height"], timing=True)
+    graph.set_timing_interval(3)
+    for r in (plain, graph):
+        r.set_raw_scene(data, pos)
+    for step, (k, size) in enumerate([(0, None), (11, None), (12, None), (40, (512, 384)), (41, None), (90, (cfg["width"], cfg["height"])), (91, None)]):
+        for r in (plain, graph):
+            if size:
+                r.setSize(*size)
+            r.set_camera(gh.orbit_camera(k, width=r.width, height=r.height, fx=cfg["fx"]))
+            r.render_async(); r.sync()
+        assert np.array_equal(plain.readPixelsFloat(), graph.readPixelsFloat()), step
+        assert np.array_equal(plain.lastDepthIndex(), graph.lastDepthIndex()), step
+    st = graph.stats()
+    assert 2 <= st["frames"] <= 4          # 7 renders + the sort-only calls of lastDepthIndex do not all carry events
+    with pytest.raises(gh.GsplatError):
+        graph.set_timing_interval(0)
+    plain.dispose(); graph.dispose()
+
+
 def test_on_device_scene_build_and_transforms(gh, oracle):
     # Scene.setData / translate / rotate / scale / limitBox as kernels, bit-exact with the
     # f64 restatement of the JavaScript (which tests/test_js_host.py pins against the JS implementation itself)
