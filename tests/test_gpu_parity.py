@@ -509,6 +509,42 @@ def test_graph_replay_equals_individual_launches(gh, scenes, monkeypatch):
     plain.dispose(); graph.dispose()
 
 
+def test_frames_in_flight_equal_sequential_frames(gh, scenes):
+    # bench.py's default mode: three throughput-tuned contexts with a frame in flight each, issued round-robin without
+    # waiting; every frame must equal the one a single default context renders on its own (segment lengths differ
+    # between the two tunings, so the image is compared within the exact-mode tolerance, the permutation bit for bit)
+    cfg = gh.synth.CONFIGS["C2"]
+    rows, data, pos = scenes("C2")
+    W, H = cfg["width"], cfg["height"]
+    rs = [gh.HIPRenderer(W, H, throughput=True, timing=True) for _ in range(3)]
+    for r in rs:
+        r.set_raw_scene(data, pos)
+        r.set_timing_interval(2)
+    ref = gh.HIPRenderer(W, H)
+    ref.set_raw_scene(data, pos)
+    got = {}
+    poses = list(range(0, 120, 9))
+    for n, k in enumerate(poses):
+        r = rs[n % 3]
+        if n >= 3:                      # this context's previous frame: read it back before it is overwritten
+            r.sync()
+            got[poses[n - 3]] = (r.readPixelsFloat(), r.lastDepthIndex())
+        r.set_camera(_camera(gh, k, cfg))
+        r.render_async()
+    for n in range(len(poses) - 3, len(poses)):
+        r = rs[n % 3]
+        r.sync()
+        got[poses[n]] = (r.readPixelsFloat(), r.lastDepthIndex())
+    for k in poses:
+        ref.set_camera(_camera(gh, k, cfg))
+        ref.render_async(); ref.sync()
+        assert np.array_equal(got[k][1], ref.lastDepthIndex()), k
+        err = np.abs(got[k][0].astype(np.float64) - ref.readPixelsFloat().astype(np.float64)).max()
+        assert err <= TOL_EXACT, (k, err)
+    for r in rs + [ref]:
+        r.dispose()
+
+
 def test_on_device_scene_build_and_transforms(gh, oracle):
     # Scene.setData / translate / rotate / scale / limitBox as kernels, bit-exact with the
     # f64 restatement of the JavaScript (which tests/test_js_host.py pins against the JS implementation itself)
