@@ -53,16 +53,19 @@ typedef struct gsr_options {
                                termination); >0: a 16x16 tile stops once every pixel's
                                remaining transmittance 1-alpha is below this value */
     int32_t band_x0, band_x1; /* multi-GPU: this context composites only pixel columns
-                               [band_x0, band_x1) (multiples of 64); 0,0 = whole image */
+                               [band_x0, band_x1): band_x0 a multiple of 32 (whole compositor bins), band_x1 a
+                               multiple of 32 or the image width; 0,0 = whole image */
     int32_t flags;          /* GSR_FLAG_* */
 } gsr_options;
 
 #define GSR_FLAG_TIMING 1   /* record HIP events around every stage (gsr_get_timings) */
 #define GSR_FLAG_THROUGHPUT 2 /* the caller keeps several frames in flight on this device (one
-                               context per frame): the compositor then uses longer work items
-                               (2048 list entries instead of 512) and 6 instead of 8 persistent
-                               workgroups per CU, because the other contexts' kernels, not extra
-                               segments of this frame, fill the GPU.  Same pixels either way. */
+                               context per frame): the compositor then cuts a frame into ~1300
+                               work items instead of ~5000 (2048 list entries per item instead of
+                               512 on a 1 M-splat 1080p frame) and launches 6 instead of 8
+                               persistent workgroups per CU, because the other contexts' kernels,
+                               not extra segments of this frame, fill the GPU.  Same pixels within
+                               float rounding (the segments are combined associatively). */
 
 /* Per-stage device times of the last completed gsr_render / gsr_sort, measured
  * with HIP events on the context's stream, plus the frame's list sizes. */
@@ -116,6 +119,9 @@ int gsr_set_scene_sh(gsr_ctx *ctx, const uint32_t *sh_r, const uint32_t *sh_g, c
 
 /* ---- per resize / per frame ---- */
 int gsr_resize(gsr_ctx *ctx, int32_t width, int32_t height);
+/* Multi-GPU: restrict the context to the pixel columns [x0, x1) (same rule as gsr_options.band_x0/x1; 0,0 = whole
+ * image).  A band context projects every splat (the depth key's min/max needs them all) but sorts, bins and composites
+ * only the splats whose box touches the band. */
 int gsr_set_band(gsr_ctx *ctx, int32_t x0, int32_t x1);
 /* view, proj, view_proj: column-major f32[16] exactly as `new Float32Array(m.buffer)`
  * of Camera.viewMatrix / projectionMatrix / viewProj (src/cameras/Camera.ts:81-92). */
@@ -131,6 +137,8 @@ int gsr_render_async(gsr_ctx *ctx); /* enqueue one frame on the context's stream
 int gsr_sync(gsr_ctx *ctx);         /* wait for the stream; reports deferred errors        */
 
 /* ---- results ---- */
+/* The whole permutation (wasm's depthIndex).  On a band context the frame sorted only the band's survivors; this
+ * call then runs the full sort first. */
 int gsr_read_depth_index(gsr_ctx *ctx, uint32_t *out /* n */);
 int gsr_read_pixels_rgba32f(gsr_ctx *ctx, float *out /* w*h*4, premultiplied, row 0 = top */);
 int gsr_read_pixels_rgba8(gsr_ctx *ctx, uint8_t *out /* w*h*4, round(clamp(x,0,1)*255)   */);
