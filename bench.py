@@ -239,6 +239,18 @@ def main():
         f1 = max(int(s1["frames"]), 1)
         solo = {"frames_per_sec": 60 / dt, "ms_per_frame": dt / 60 * 1e3,
                 "stage_ms": {k: s1["sum_ms_" + k] / f1 for k in ("project_key", "sort", "bin", "blend", "combine", "total")}}
+        # host-visible latency of a frame issued on an idle GPU and waited for (render_async + sync), one orbit
+        lat = []
+        for k in range(ORBIT_FRAMES):
+            v, p, vp = poses[k]
+            t2 = time.perf_counter()
+            sr.set_camera_arrays(v, p, vp, cfg["fx"], cfg["fx"])
+            sr.render_async()
+            sr.sync()
+            lat.append((time.perf_counter() - t2) * 1e3)
+        lat.sort()
+        solo["frame_latency_ms"] = {"p50": lat[len(lat) // 2], "p99": lat[min(len(lat) - 1, int(len(lat) * 0.99))],
+                                    "mean": sum(lat) / len(lat), "frames": len(lat)}
         # the sort path alone, as the reference's worker runs it (wasm.cpp sort(): key + min/max + quantise + order):
         # gsr_sort = key kernel without projection + the two radix passes
         sr.reset_stats()

@@ -60,3 +60,14 @@ def test_create_fails_loudly_without_gpu():
     ctx = ctypes.c_void_p()
     assert lib.gsr_create(ctypes.byref(ctx), None) < 0
     assert not ctx.value
+
+
+def test_cpp_caller_builds_and_fails_loudly_without_gpu():
+    # the third caller of the C ABI is a plain C++ program (tools/bench_cabi.cpp, built by csrc/Makefile)
+    import torch
+    exe = os.path.join(ROOT, "gsplat.js_amd", "lib", "bench_cabi")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_gpu_parity.py::test_cpp_caller_matches_python_host")
+    r = subprocess.run([exe, "--config", "C1", "--frames", "2"], capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stderr and "no CPU path" in r.stderr
