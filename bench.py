@@ -251,6 +251,14 @@ def main():
         lat.sort()
         solo["frame_latency_ms"] = {"p50": lat[len(lat) // 2], "p99": lat[min(len(lat) - 1, int(len(lat) * 0.99))],
                                     "mean": sum(lat) / len(lat), "frames": len(lat)}
+        # frames/s when the host reads every frame back as RGBA8 (conversion kernel + 8.3 MB D2H into pageable memory)
+        t3 = time.perf_counter()
+        for k in range(30):
+            v, p, vp = poses[k]
+            sr.set_camera_arrays(v, p, vp, cfg["fx"], cfg["fx"])
+            sr.render_async()
+            sr.readPixels()
+        solo["frames_per_sec_with_rgba8_readback"] = 30 / (time.perf_counter() - t3)
         # the sort path alone, as the reference's worker runs it (wasm.cpp sort(): key + min/max + quantise + order):
         # gsr_sort = key kernel without projection + the two radix passes
         sr.reset_stats()
