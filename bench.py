@@ -305,7 +305,7 @@ def main():
                                    % (args.config, N, cfg["seed"], W, H),
                        "early_out_eps": args.early_out_eps, "frames_in_flight": F, "stage_events_every": max(1, args.timing_interval), "emulated_rank": args.emulate_rank, "parallelism": "tile-column bands x%d%s" % (world, "" if world == 1 else (", %s all-gather, %s edges" % (args.exchange, "equal" if args.equal_bands else "cost-balanced"))),
                        "output": "RGBA f32 premultiplied, left in HBM"},
-            "sorted_splats_per_sec": N / ((sm["project_key"] + sm["sort"]) * 1e-3),
+            "sorted_splats_per_sec": N / ((sm["project_key"] + sm["sort"]) * 1e-3) if (sm["project_key"] + sm["sort"]) > 0 else None,
             "stage_ms": ms,
             "counts": {"N": N, "V": V, "D_tiles16": D, "bin_entries32": E, "P": band_px},
             "roofline": {"bound": "hbm", "kernel": "k_blend", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -321,7 +321,7 @@ def main():
             # secondary ceiling: VALU issue.  peak = what tools/valu_peak.hip sustains on this chip for the compositor's
             # own instruction mix (11 VALU of a covered quadrant incl. v_exp_f32 and v_pk_fma_f32, operands in VGPRs,
             # 8 waves/SIMD): 0.667e12 wave-instr/s (profiles/r01_valu_peak_mi355x.txt); plain v_fma_f32 sustains 0.623e12
-            "valu": None if not valu else (lambda t_ms, v: {
+            "valu": None if not valu or not sm["blend"] else (lambda t_ms, v: {
                 "wave_instr_per_launch": v, "launch_ms": t_ms, "achieved_wave_instr_per_s": v / (t_ms * 1e-3),
                 "peak_wave_instr_per_s": 0.667e12, "frac": v / (t_ms * 1e-3) / 0.667e12,
                 "note": "one frame in flight (kernels of several frames overlap in the timed region)" if solo else ""})(

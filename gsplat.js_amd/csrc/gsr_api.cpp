@@ -868,6 +868,7 @@ int gsr_set_timing_interval(gsr_ctx* c, uint32_t every)
 {
     if (!c || !every) return c ? fail(c, GSR_ERR_ARG, "timing interval must be >= 1") : GSR_ERR_ARG;
     c->timing_every = every;
+    c->frame_no = 0;
     return GSR_OK;
 }
 
@@ -879,6 +880,7 @@ int gsr_reset_timings(gsr_ctx* c)
     c->tm = gsr_timings{};
     HIP_TRY(c, hipMemsetAsync(c->accum, 0, 4 * sizeof(uint64_t), c->stream));
     c->tm.visible = v; c->tm.bin_entries = b; c->tm.tile_entries = d; c->tm.n = c->n;
+    c->frame_no = 0;  // the sampling restarts: the next frame carries the stage events
     return GSR_OK;
 }
 
