@@ -165,7 +165,7 @@ def main():
                                        host_staged=args.backend == "gloo")
         else:
             fbs = [bands.framebuffer_tensor(torch, rr, dev) for rr in rs]
-            xchg = bands.FrameExchange(dist, torch, W, H, rank, world, fbs[0].device, edges=edges)
+            xchg = bands.FrameExchange(dist, torch, W, H, rank, world, fbs[0].device, edges=edges, host_staged=args.backend == "gloo")
         links = [bands.StreamLink(torch, rr, dev) for rr in rs]
 
     # Camera.update for the 120 poses is host JS/Python f64 work outside the device path: precomputed

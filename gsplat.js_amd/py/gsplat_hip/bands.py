@@ -146,7 +146,12 @@ class FrameExchange:
             self.slab[:, :x1 - x0].copy_(fb[:, x0:x1])
         if self.copied is not None:
             self.copied.record()        # from here on the producer may overwrite fb
-        self.dist.all_gather_into_tensor(self._flat, self.slab)
+        if self.host_staged and self.slab.is_cuda:   # rehearsal under gloo: no device all-gather
+            host_flat = self._flat.cpu()
+            self.dist.all_gather_into_tensor(host_flat, self.slab.cpu())
+            self._flat.copy_(host_flat)
+        else:
+            self.dist.all_gather_into_tensor(self._flat, self.slab)
         for q, (a, b) in enumerate(self.edges):
             if b > a:
                 self.full[:, a:b].copy_(self.gathered[q, :, :b - a])
