@@ -29,6 +29,7 @@ struct FrameState {  // small per-frame device words, reset by k_begin_frame (mi
     uint32_t queue;   // compositor work-item counter
     uint64_t visible;
     uint64_t tile_entries;
+    uint64_t report[6];  // written by k_bin_finalize for the host: running sums accum[0..4], this frame's bin entries
     uint32_t digit_total[RADIX_LO_BINS + RADIX_HI_BINS];
     uint32_t sorted_count;  // entries of depth_index: n, or the band's survivors (SortBuffers::count)
     uint32_t seg_len;       // the frame's compositor segment length (k_bin_finalize -> k_blend)
@@ -267,7 +268,7 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
         if (!c->n) HIP_TRY(c, hipMemsetAsync(c->bin_total, 0, sizeof(uint32_t) * nbins, s));
         BinBuffers bb{c->depth_index, &c->fstate->sorted_count, c->bbox, c->bin_table, c->blk_counts, c->bin_rects, c->bin_total, c->bin_start, c->seg_start,
                       c->items, c->bin_list, &c->fstate->overflow, &c->fstate->visible, &c->fstate->tile_entries,
-                      c->accum, c->bin_capacity, c->max_items, c->seg_len, &c->fstate->seg_len, (c->opt.flags & GSR_FLAG_THROUGHPUT) ? 0 : 1, &c->fstate->queue, std::min<uint32_t>(c->max_items, c->blend_grid), c->seg_target_items, c->bin_blocks};
+                      c->accum, c->fstate->report, c->bin_capacity, c->max_items, c->seg_len, &c->fstate->seg_len, (c->opt.flags & GSR_FLAG_THROUGHPUT) ? 0 : 1, &c->fstate->queue, std::min<uint32_t>(c->max_items, c->blend_grid), c->seg_target_items, c->bin_blocks};
         launch_bin(bb, g, c->n, s);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BIN], s));
         BlendBuffers bl{c->items, c->seg_start, c->bin_start, c->bin_list, c->rec, c->bbox, c->shcol, c->fb, c->partial,
@@ -399,14 +400,11 @@ int finish_frame(gsr_ctx* c)
 // after a synchronised render: pull the frame words, regrow the bin list if it overflowed
 int check_frame_words(gsr_ctx* c, bool* overflowed)
 {
-    HIP_TRY(c, hipMemcpyAsync(c->fstate_host, c->fstate, 32, hipMemcpyDeviceToHost, c->stream));
-    uint32_t total = 0;
-    const BinGrid g = make_grid(c);
-    const int nbins = (g.bx_hi - g.bx_lo) * g.nby;
-    HIP_TRY(c, hipMemcpyAsync(&total, c->bin_start + nbins, 4, hipMemcpyDeviceToHost, c->stream));
-    uint64_t acc[5] = {0, 0, 0, 0, 0};
-    HIP_TRY(c, hipMemcpyAsync(acc, c->accum, sizeof acc, hipMemcpyDeviceToHost, c->stream));
+    // one small copy: the frame words up to and including k_bin_finalize's report
+    HIP_TRY(c, hipMemcpyAsync(c->fstate_host, c->fstate, offsetof(FrameState, digit_total), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint64_t* acc = c->fstate_host->report;
+    const uint32_t total = (uint32_t)c->fstate_host->report[5];
     c->tm.sum_visible = acc[0]; c->tm.sum_bin_entries = acc[1]; c->tm.sum_tile_entries = acc[2]; c->tm.sum_frames = acc[3];
     c->tm.visible = c->fstate_host->visible;
     c->tm.tile_entries = c->fstate_host->tile_entries;

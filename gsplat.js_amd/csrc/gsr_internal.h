@@ -116,6 +116,7 @@ struct BinBuffers {
     uint64_t* visible;           // V counter
     uint64_t* tile_entries;      // D counter (16x16 tiles overlapped by visible bboxes)
     uint64_t* accum;             // [5] running sums over frames: visible, bin entries, tile entries, frames; [4] = entries the last frame needs
+    uint64_t* report;            // [6] per-frame copy for the host: accum[0..4] after this frame, [5] = this frame's bin entries
     uint32_t capacity;
     uint32_t max_items;
     uint32_t seg_len;            // minimum list entries per compositor work item (multiple of 256); k_bin_finalize

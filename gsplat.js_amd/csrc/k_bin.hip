@@ -197,7 +197,8 @@ __global__ __launch_bounds__(FIN_THREADS) void k_bin_finalize(const uint32_t* __
                                                               uint32_t* __restrict__ seg_start, uint32_t* __restrict__ items,
                                                               uint32_t* __restrict__ overflow, uint64_t* __restrict__ visible,
                                                               uint64_t* __restrict__ tile_entries, uint64_t* __restrict__ accum,
-                                                              uint32_t* __restrict__ queue, uint32_t queue_start)
+                                                              uint64_t* __restrict__ report, uint32_t* __restrict__ queue,
+                                                              uint32_t queue_start)
 {
     __shared__ uint32_t s_w[5][FIN_WAVES];
     const int per = (nbins + FIN_THREADS - 1) / FIN_THREADS;
@@ -268,6 +269,9 @@ __global__ __launch_bounds__(FIN_THREADS) void k_bin_finalize(const uint32_t* __
         *visible = ctot.v[0];
         *tile_entries = ctot.v[1];
         accum[0] += ctot.v[0]; accum[1] += tot.v[0]; accum[2] += ctot.v[1]; accum[3] += 1;
+#pragma unroll
+        for (int k = 0; k < 5; k++) report[k] = accum[k];   // what the host reads at the next synchronisation: one copy
+        report[5] = fits ? tot.v[0] : 0u;
     }
 }
 
@@ -435,7 +439,7 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
     }
     hipLaunchKernelGGL(k_bin_finalize, dim3(1), dim3(FIN_THREADS), 0, s, (const uint32_t*)b.bin_total, nbins, b.seg_len,
                        b.seg_target_items, b.items_by_size, b.seg_len_dev, b.max_items, b.capacity, (const uint2*)b.blk_counts, n ? b.nblocks : 0u,
-                       b.bin_start, b.seg_start, b.items, b.overflow, b.visible, b.tile_entries, b.accum, b.queue, b.queue_start);
+                       b.bin_start, b.seg_start, b.items, b.overflow, b.visible, b.tile_entries, b.accum, b.report, b.queue, b.queue_start);
     if (n)
         hipLaunchKernelGGL(k_bin_scatter, dim3(b.nblocks, sl.sx * sl.sy), dim3(SCAT_THREADS), lds, s, b.depth_index,
                            (const uint32_t*)b.rects, b.count, g, sl, (const uint32_t*)b.table, (const uint32_t*)b.bin_start, b.list,
