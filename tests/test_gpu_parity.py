@@ -570,6 +570,39 @@ def test_cpp_caller_matches_python_host(gh, scenes, tmp_path):
     r.dispose()
 
 
+def test_randomised_configurations(gh, oracle, scenes):
+    # seeded sweep over the knobs that change code paths: splat count (incl. tiny), ragged framebuffer sizes, splat
+    # size range, orbit radius / elevation (camera inside and outside the cloud), bands, early termination, the
+    # throughput tuning, stage events; permutation bit-exact, image within the mode's tolerance of the oracle
+    rng = np.random.default_rng(20260404)
+    for case in range(24):
+        n = int(rng.choice([1, 2, 63, 65, 300, 2049, 5000, 20000]))
+        W, H = int(rng.integers(17, 900)), int(rng.integers(17, 700))
+        s_hi = float(rng.choice([0.02, 0.06, 0.3]))
+        rows, data, pos = scenes(n, 1000 + case, sigma=float(rng.choice([0.5, 1.5])), s_lo=0.004, s_hi=s_hi)
+        cam = gh.orbit_camera(int(rng.integers(0, 120)), width=W, height=H, fx=float(rng.choice([300.0, 1132.0])),
+                              beta=float(rng.uniform(-1.2, 1.2)), radius=float(rng.choice([0.5, 3.0, 8.0, 20.0])))
+        eps = float(rng.choice([0.0, 0.0, 1e-3]))
+        band = None
+        if rng.random() < 0.4 and W > 64:
+            b0 = int(rng.integers(0, (W - 1) // 32)) * 32
+            band = (b0, min(W, b0 + 32 * int(rng.integers(1, 6))))
+        r = gh.HIPRenderer(W, H, early_out_eps=eps, band=band, throughput=bool(rng.random() < 0.5), timing=bool(rng.random() < 0.5))
+        r.set_raw_scene(data, pos)
+        r.set_camera(cam)
+        r.render_async(); r.sync()
+        img, di = r.readPixelsFloat(), r.lastDepthIndex()
+        r.dispose()
+        v, p, vp = cam.f32()
+        oimg, odi, V, D = oracle.render_scene(data, pos, v, p, vp, cam.fx, cam.fy, W, H, mode=1)
+        assert np.array_equal(di, odi), case
+        if band:
+            assert not img[:, :band[0]].any() and not img[:, band[1]:].any(), case
+            img, oimg = img[:, band[0]:band[1]], oimg[:, band[0]:band[1]]
+        err = np.abs(img.astype(np.float64) - oimg.astype(np.float64)).max() if img.size else 0.0
+        assert err <= (TOL_EARLY * 2 if eps > 0 else TOL_EXACT), (case, n, W, H, band, eps, err)
+
+
 def test_on_device_scene_build_and_transforms(gh, oracle):
     # Scene.setData / translate / rotate / scale / limitBox as kernels, bit-exact with the
     # f64 restatement of the JavaScript (which tests/test_js_host.py pins against the JS implementation itself)
