@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""One-off robustness check at a scene size far above the bench configs (default 20 M splats, 1080p): the permutation
+must equal the oracle's, the frame must render (list regrowth included) and the counters must be consistent."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "gsplat.js_amd", "py"))
+import numpy as np
+import gsplat_hip as gh
+from oracle import oracle as O
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
+W, H = 1920, 1080
+t0 = time.time()
+rows = gh.synth.synth_rows(n, 77, sigma=1.5, s_lo=0.002, s_hi=0.02)
+r = gh.HIPRenderer(W, H, timing=True)
+r.set_scene_rows(rows)              # device-side Scene.setData
+del rows
+cam = gh.orbit_camera(33, width=W, height=H, fx=1132.0)
+r.set_camera(cam)
+r.render_async(); r.sync()
+st = r.stats()
+print("n=%d  rendered in %.2f ms (project %.3f sort %.3f bin %.3f blend %.3f)  V=%d bin_entries=%d" % (
+    n, st["ms_total"], st["ms_project_key"], st["ms_sort"], st["ms_bin"], st["ms_blend"], st["visible"], st["bin_entries"]), flush=True)
+di = r.lastDepthIndex()
+data, pos = r.read_scene()[:2]
+v, p, vp = cam.f32()
+odi, okeys, omm = O.sort(vp, pos)
+assert np.array_equal(di, odi), "permutation differs from the oracle"
+img = r.readPixelsFloat()
+assert np.isfinite(img).all() and img[..., 3].max() <= 1.0 + 1e-6 and img[..., 3].min() >= 0.0
+assert 0 < st["visible"] <= n and st["bin_entries"] >= st["visible"]
+print("ok: depthIndex bit-exact at n=%d, image finite, %.0f s total" % (n, time.time() - t0))
