@@ -40,6 +40,12 @@ class GsrTimings(ctypes.Structure):
                 ("sum_tile_entries", ctypes.c_uint64), ("sum_frames", ctypes.c_uint64)]
 
 
+def edge_arrays(edges):
+    """[(x0, x1)] per rank -> (c_int32[world], c_int32[world]) for gsr_unpack_slabs_rgba8_async."""
+    world = len(edges)
+    return ((ctypes.c_int32 * world)(*[int(a) for a, _ in edges]), (ctypes.c_int32 * world)(*[int(b) for _, b in edges]))
+
+
 class GsplatError(RuntimeError):
     pass
 
@@ -429,12 +435,11 @@ class HIPRenderer:
         self._check(self._L.gsr_pack_band_rgba8_async(self._ctx, ctypes.c_void_p(slab_ptr), slab_width_px))
 
     def unpack_slabs_rgba8_async(self, gathered_ptr, image_ptr, slab_width_px, edges, stream_handle):
-        """Gathered slabs [world][H][slab_w] -> row-major image, on `stream_handle` (the collective's stream)."""
-        world = len(edges)
-        x0 = (ctypes.c_int32 * world)(*[int(a) for a, _ in edges])
-        x1 = (ctypes.c_int32 * world)(*[int(b) for _, b in edges])
+        """Gathered slabs [world][H][slab_w] -> row-major image, on `stream_handle` (the collective's stream).
+        `edges`: [(x0, x1)] per rank, or the pair of ctypes arrays `edge_arrays(edges)` returns (per-frame callers)."""
+        x0, x1 = edges if isinstance(edges, tuple) and not isinstance(edges[0], (tuple, list)) else edge_arrays(edges)
         self._check(self._L.gsr_unpack_slabs_rgba8_async(self._ctx, ctypes.c_void_p(gathered_ptr), ctypes.c_void_p(image_ptr),
-                                                         slab_width_px, world, x0, x1, ctypes.c_void_p(stream_handle)))
+                                                         slab_width_px, len(x0), x0, x1, ctypes.c_void_p(stream_handle)))
 
     def framebuffer8_ptr(self):
         return self._L.gsr_framebuffer8_device_ptr(self._ctx)

@@ -114,6 +114,8 @@ class FrameExchange:
         # recorded on the current stream right after the band has been copied into the slab (device tensors only)
         self.copied = torch.cuda.Event() if str(device).startswith("cuda") else None
         self.gathered_ev = None
+        self._edge_arrays = None          # ctypes copies of the edges for the de-slab call (built once)
+        self._ptrs = None
 
     def exchange_native(self, renderer, link):
         """RGBA8 exchange of the frame `renderer` has enqueued.  Device-side ordering only:
@@ -121,11 +123,15 @@ class FrameExchange:
         The slab is reused by the next call, so the next pack waits for this all-gather (event `gathered`)."""
         torch = link.torch
         sw = self.slab.shape[1]
+        if self._edge_arrays is None:
+            from . import edge_arrays
+            self._edge_arrays = edge_arrays(self.edges)
+            self._ptrs = (self.slab.data_ptr(), self._flat.data_ptr(), self.full.data_ptr())
         if self.gathered_ev is None:
             self.gathered_ev = torch.cuda.Event()
         else:
             link.renderer_waits_for_event(self.gathered_ev)     # previous collective has read the slab
-        renderer.pack_band_rgba8_async(self.slab.data_ptr(), sw)
+        renderer.pack_band_rgba8_async(self._ptrs[0], sw)
         link.torch_waits_for_renderer()
         if self.host_staged:
             host_slab = self.slab.cpu()
@@ -135,7 +141,7 @@ class FrameExchange:
         else:
             self.dist.all_gather_into_tensor(self._flat, self.slab)
         self.gathered_ev.record()
-        renderer.unpack_slabs_rgba8_async(self._flat.data_ptr(), self.full.data_ptr(), sw, self.edges,
+        renderer.unpack_slabs_rgba8_async(self._ptrs[1], self._ptrs[2], sw, self._edge_arrays,
                                           torch.cuda.current_stream().cuda_stream)
         return self.full
 
