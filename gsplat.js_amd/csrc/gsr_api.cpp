@@ -86,7 +86,8 @@ struct gsr_ctx {
     size_t fb_pixels = 0;
 
     CamParams cam{};
-    CamParams* cam_dev = nullptr;     // the frame's camera in device memory (k_set_camera)
+    CamParams* cam_dev = nullptr;     // the frame's camera in device memory (k_begin_frame)
+    hipEvent_t link_ev[2] = {nullptr, nullptr};  // gsr_stream_order
     // the frame's launch chain replayed as a HIP graph (frames that carry no stage events)
     bool graphs_enabled = true;
     hipGraph_t graph = nullptr;
@@ -504,6 +505,7 @@ int gsr_destroy(gsr_ctx* c)
     if (c->fstate_host) (void)hipHostFree(c->fstate_host);
     for (auto& set : c->evring)
         for (auto& e : set) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->link_ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return GSR_OK;
@@ -987,6 +989,19 @@ int gsr_unpack_slabs_rgba8_async(gsr_ctx* c, const void* gathered, void* image, 
 
 void* gsr_framebuffer_device_ptr(gsr_ctx* c) { return c ? (void*)c->fb : nullptr; }
 void* gsr_stream_handle(gsr_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int gsr_stream_order(gsr_ctx* c, void* other_stream, int32_t ctx_waits)
+{
+    if (!c) return GSR_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipEvent_t& ev = c->link_ev[ctx_waits ? 1 : 0];
+    if (!ev) HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipStream_t from = ctx_waits ? (hipStream_t)other_stream : c->stream;
+    hipStream_t to = ctx_waits ? c->stream : (hipStream_t)other_stream;
+    HIP_TRY(c, hipEventRecord(ev, from));
+    HIP_TRY(c, hipStreamWaitEvent(to, ev, 0));
+    return GSR_OK;
+}
 
 int gsr_device_info(gsr_ctx* c, char* name, int32_t name_len, int32_t* cus, int32_t* clock_khz)
 {

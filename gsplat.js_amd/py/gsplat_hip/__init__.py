@@ -60,7 +60,7 @@ EXPORTS = [
     "gsr_read_pixels_rgba8", "gsr_get_timings", "gsr_reset_timings", "gsr_set_timing_interval", "gsr_read_keys", "gsr_read_records",
     "gsr_read_bin_totals", "gsr_convert_rgba8_async", "gsr_framebuffer8_device_ptr",
     "gsr_pack_band_rgba8_async", "gsr_unpack_slabs_rgba8_async",
-    "gsr_framebuffer_device_ptr", "gsr_stream_handle", "gsr_device_info", "gsplat_sort_host",
+    "gsr_framebuffer_device_ptr", "gsr_stream_handle", "gsr_stream_order", "gsr_device_info", "gsplat_sort_host",
 ]
 
 
@@ -101,6 +101,7 @@ def load_library(path=None):
     L.gsr_read_records.argtypes = [vp, vp, vp]
     L.gsr_read_bin_totals.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
     L.gsr_convert_rgba8_async.argtypes = [vp]
+    L.gsr_stream_order.argtypes = [vp, vp, ctypes.c_int32]
     L.gsr_pack_band_rgba8_async.argtypes = [vp, vp, ctypes.c_int32]
     L.gsr_unpack_slabs_rgba8_async.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
                                                ctypes.POINTER(ctypes.c_int32), vp]
@@ -446,6 +447,10 @@ class HIPRenderer:
 
     def framebuffer_ptr(self):
         return self._L.gsr_framebuffer_device_ptr(self._ctx)
+
+    def stream_order(self, other_stream_handle, ctx_waits):
+        """Device-side ordering with another stream (see gsr_stream_order)."""
+        self._check(self._L.gsr_stream_order(self._ctx, ctypes.c_void_p(other_stream_handle), 1 if ctx_waits else 0))
 
     def stream_handle(self):
         return self._L.gsr_stream_handle(self._ctx)

@@ -76,13 +76,15 @@ class StreamLink:
 
     def __init__(self, torch, renderer, device):
         self.torch = torch
+        self.renderer = renderer
         self.ext = torch.cuda.ExternalStream(renderer.stream_handle(), device=device)
 
     def torch_waits_for_renderer(self):
-        self.torch.cuda.current_stream().wait_stream(self.ext)
+        # one event record + one stream wait inside the library (a third of the cost of the torch calls)
+        self.renderer.stream_order(self.torch.cuda.current_stream().cuda_stream, False)
 
     def renderer_waits_for_torch(self):
-        self.ext.wait_stream(self.torch.cuda.current_stream())
+        self.renderer.stream_order(self.torch.cuda.current_stream().cuda_stream, True)
 
     def renderer_waits_for_event(self, event):
         """Narrower than renderer_waits_for_torch: the renderer's stream waits only for `event` (e.g. "my band has been
@@ -113,24 +115,23 @@ class FrameExchange:
         self.full = torch.empty((height, width, channels), dtype=dtype, device=device)
         # recorded on the current stream right after the band has been copied into the slab (device tensors only)
         self.copied = torch.cuda.Event() if str(device).startswith("cuda") else None
-        self.gathered_ev = None
+        self._exchanged = False
         self._edge_arrays = None          # ctypes copies of the edges for the de-slab call (built once)
         self._ptrs = None
 
     def exchange_native(self, renderer, link):
         """RGBA8 exchange of the frame `renderer` has enqueued.  Device-side ordering only:
         pack on the renderer's stream -> torch's stream waits -> all-gather -> de-slab on torch's stream.
-        The slab is reused by the next call, so the next pack waits for this all-gather (event `gathered`)."""
+        The slab is reused by the next call, so the next pack waits for what torch's stream holds by then (this all-gather)."""
         torch = link.torch
         sw = self.slab.shape[1]
         if self._edge_arrays is None:
             from . import edge_arrays
             self._edge_arrays = edge_arrays(self.edges)
             self._ptrs = (self.slab.data_ptr(), self._flat.data_ptr(), self.full.data_ptr())
-        if self.gathered_ev is None:
-            self.gathered_ev = torch.cuda.Event()
-        else:
-            link.renderer_waits_for_event(self.gathered_ev)     # previous collective has read the slab
+        if self._exchanged:
+            link.renderer_waits_for_torch()      # the previous collective (and de-slab) has read the slab
+        self._exchanged = True
         renderer.pack_band_rgba8_async(self._ptrs[0], sw)
         link.torch_waits_for_renderer()
         if self.host_staged:
@@ -140,7 +141,6 @@ class FrameExchange:
             self._flat.copy_(host_flat)
         else:
             self.dist.all_gather_into_tensor(self._flat, self.slab)
-        self.gathered_ev.record()
         renderer.unpack_slabs_rgba8_async(self._ptrs[1], self._ptrs[2], sw, self._edge_arrays,
                                           torch.cuda.current_stream().cuda_stream)
         return self.full

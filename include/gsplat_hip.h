@@ -174,6 +174,10 @@ int gsr_unpack_slabs_rgba8_async(gsr_ctx *ctx, const void *gathered, void *image
 /* ---- device interop (torch / RCCL plumbing in the harness) ---- */
 void *gsr_framebuffer_device_ptr(gsr_ctx *ctx); /* float4[h][w] on the device */
 void *gsr_stream_handle(gsr_ctx *ctx);          /* hipStream_t */
+/* Device-side ordering between the context's stream and another stream of the same device (no host wait):
+ * ctx_waits = 0: work submitted to `other_stream` after this call waits for everything enqueued on the context so far;
+ * ctx_waits = 1: the context's later work waits for everything enqueued on `other_stream` so far. */
+int gsr_stream_order(gsr_ctx *ctx, void *other_stream, int32_t ctx_waits);
 int gsr_device_info(gsr_ctx *ctx, char *name, int32_t name_len, int32_t *compute_units, int32_t *clock_khz);
 
 /* ---- drop-in for the wasm export, same argument list as wasm/wasm.cpp:8-13.
