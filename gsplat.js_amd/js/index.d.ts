@@ -100,6 +100,9 @@ export class HIPRenderer {
     width: number; height: number;
     constructor(targetOrOptions?: HIPRendererOptions | { width: number; height: number } | null, shaderPasses?: ShaderPass[] | null);
     render(scene: Scene, camera: Camera): void;
+    /** enqueue the frame and return; pair with sync() (several `throughput` renderers used round-robin keep the GPU full) */
+    renderAsync(scene: Scene, camera: Camera): void;
+    sync(): void;
     sort(camera?: Camera): void;
     setSize(width: number, height: number): void;
     resize(): void;

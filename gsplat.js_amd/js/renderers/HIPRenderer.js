@@ -88,6 +88,22 @@ class HIPRenderer {
             for (const p of passes) p.render();
             this._n.render(this._h);
         };
+        // Frames in flight (no counterpart in the reference, whose render() is one synchronous draw): renderAsync()
+        // enqueues the frame and returns; sync() waits for it.  Several renderers created with { throughput: true }
+        // and used round-robin keep the GPU full (bench.py --frames-in-flight).
+        this.renderAsync = (scene, camera) => {
+            activeCamera = camera;
+            if (scene !== activeScene) {
+                if (activeScene) activeScene.removeEventListener("change", onSceneChange);
+                activeScene = scene;
+                activeScene.addEventListener("change", onSceneChange);
+                upload();
+            }
+            pushCamera();
+            for (const p of passes) p.render();
+            this._n.renderAsync(this._h);
+        };
+        this.sync = () => this._n.sync(this._h);
         this.sort = (camera) => {                // the worker's job alone (Worker.ts:36-43)
             if (camera) { activeCamera = camera; pushCamera(); }
             this._n.sort(this._h);

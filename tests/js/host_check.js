@@ -77,6 +77,33 @@ if (mode === "pack") {                     // pack <splat> <outprefix> <W> <H> <
     writeBin(out + ".sortHost.depthIndex.bin", di);
     fs.writeFileSync(out + ".json", JSON.stringify({ stats: r.stats(), device: r.deviceInfo(), viewProj: cam.viewProj.buffer }));
     r.dispose();
+} else if (mode === "inflight") {          // inflight <splat> <outprefix> <W> <H> <fx>: three throughput renderers used round-robin
+    const [file, out, W, H, fx] = a;
+    const scene = new G.Scene();
+    G.Loader.LoadSync(file, scene);
+    const rs = [0, 1, 2].map(() => new G.WebGLRenderer({ width: +W, height: +H, throughput: true }, []));
+    const ref = new G.WebGLRenderer({ width: +W, height: +H }, []);
+    let same = true, frames = 0;
+    const pending = [null, null, null];
+    const check = (slot) => {
+        const r = rs[slot];
+        r.sync();
+        ref.render(scene, orbitCamera(pending[slot], 120, +fx));
+        const a1 = r.lastDepthIndex(), a2 = ref.lastDepthIndex();
+        for (let i = 0; same && i < a1.length; i++) same = a1[i] === a2[i];
+        const p1 = r.readPixels(), p2 = ref.readPixels();
+        for (let i = 0; same && i < p1.length; i++) same = Math.abs(p1[i] - p2[i]) <= 1;
+        frames++;
+    };
+    for (let k = 0; k < 12; k++) {
+        const slot = k % 3;
+        if (pending[slot] !== null) check(slot);
+        rs[slot].renderAsync(scene, orbitCamera(7 * k, 120, +fx));
+        pending[slot] = 7 * k;
+    }
+    for (let slot = 0; slot < 3; slot++) check(slot);
+    fs.writeFileSync(out + ".json", JSON.stringify({ same, frames }));
+    rs.forEach((r) => r.dispose()); ref.dispose();
 } else if (mode === "renderfade") {       // renderfade <splat> <outprefix> <W> <H> <fx> <pose> <frames>: default passes = [FadeInPass]
     const [file, out, W, H, fx, pose, frames] = a;
     const scene = new G.Scene();

@@ -168,6 +168,19 @@ def test_js_renderer_fails_loudly_without_gpu():
 
 
 @pytest.mark.gpu
+def test_js_frames_in_flight(tmp_path):
+    # Node host, three `throughput` renderers used round-robin through renderAsync()/sync(): every frame equals the one a
+    # default renderer draws synchronously (permutation bit for bit, RGBA8 within one step: the segment lengths differ)
+    import gsplat_hip as gh
+    cfg = gh.synth.CONFIGS["C1"]
+    f = tmp_path / "c1.splat"
+    gh.synth.config_rows("C1").tofile(f)
+    out = str(tmp_path / "f")
+    run("inflight", f, out, cfg["width"], cfg["height"], cfg["fx"])
+    assert json.load(open(out + ".json")) == {"same": True, "frames": 12}
+
+
+@pytest.mark.gpu
 def test_js_render_matches_oracle(tmp_path, oracle):
     import gsplat_hip as gh
     cfg = gh.synth.CONFIGS["C1"]
