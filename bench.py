@@ -59,7 +59,24 @@ def cpu_baseline(gh, cfg, data, pos, sample_frames=2, sort_calls=10):
         t_frame.append(time.perf_counter() - t0)
     t_frame = float(np.mean(t_frame))
     n = pos.size // 3
+    # the same four passes in plain JavaScript under Node (tools/sort_js_baseline.js): what the reference's worker
+    # would cost without wasm; reported beside the native build of the reference's C++ (no emcc here to rebuild the wasm)
+    js = None
+    try:
+        import shutil, subprocess, tempfile
+        node = shutil.which("node")
+        if node:
+            with tempfile.NamedTemporaryFile(suffix=".f32") as tf:
+                np.asarray(pos, dtype=np.float32).tofile(tf.name)
+                vp = cams[0].f32()[2]
+                out = subprocess.run([node, os.path.join(ROOT, "tools", "sort_js_baseline.js"), tf.name, repr(float(vp[2])),
+                                      repr(float(vp[6])), repr(float(vp[10])), "5"], capture_output=True, text=True, timeout=120)
+                js = json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception:
+        js = None
     return {
+        "sort_js_ms": js["ms_median"] if js else None,
+        "sort_js_note": "wasm.cpp's loops in plain JavaScript (V8, Math.fround per operation), 1 thread; an upper bound for the wasm worker" if js else None,
         "value": 1.0 / t_frame, "unit": "frames/s", "cores": cores, "kind": "port",
         "sample": "%d full frames of the same 1M-splat 1080p workload (sort 1 thread + project 1 thread + composite on %d threads)"
                   % (sample_frames, cores),

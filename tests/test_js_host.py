@@ -157,6 +157,26 @@ def test_js_quantized_ply_loader(tmp_path, oracle):
     assert np.array_equal(np.fromfile(out + ".splat", dtype=np.uint8).reshape(n, 32)[:, 0:12], want[:, 0:12])
 
 
+def test_js_sort_baseline_matches_oracle(tmp_path, oracle):
+    # tools/sort_js_baseline.js (the CPU stand-in bench.py times beside the native reference sort) is the same algorithm:
+    # its depthIndex hashes to the oracle's
+    import gsplat_hip as gh
+    rows = gh.synth.synth_rows(50000, 9)
+    data, pos = oracle.scene_pack(rows)
+    f = tmp_path / "pos.f32"
+    np.asarray(pos, dtype=np.float32).tofile(f)
+    vp = gh.orbit_camera(31).f32()[2]
+    r = subprocess.run(["node", os.path.join(ROOT, "tools", "sort_js_baseline.js"), str(f), repr(float(vp[2])), repr(float(vp[6])),
+                        repr(float(vp[10])), "2"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    di, _, _ = oracle.sort(vp, pos)
+    h = 0xcbf29ce484222325
+    for b in di.astype("<u4").tobytes():
+        h = ((h ^ b) * 0x100000001b3) & 0xffffffffffffffff
+    assert got["n"] == 50000 and int(got["checksum"], 16) == h
+
+
 def test_js_renderer_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
