@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--early-out-eps", type=float, default=0.0,
                     help="0 = composite every splat like the reference (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="skip the untimed secondary legs (one frame in flight, latency, readback, sort alone) and the CPU baseline: "
+                         "for profiler runs, so that every traced launch belongs to the timed configuration")
     ap.add_argument("--exchange", choices=("rgba8", "f32"), default="rgba8",
                     help="N>1: framebuffer slab format of the per-frame all-gather (rgba8: what a display consumes)")
     ap.add_argument("--frames-in-flight", type=int, default=3,
@@ -240,7 +243,7 @@ def main():
     # secondary leg outside the timed region: ONE frame in flight on a context tuned for that (no GSR_FLAG_THROUGHPUT)
     # -> per-frame latency and uncontended stage times
     solo = None
-    if F > 1 and world == 1:
+    if F > 1 and world == 1 and not args.timed_only:
         sr = gh.HIPRenderer(W, H, device=local_rank, early_out_eps=args.early_out_eps, timing=True)
         for k in range(4):
             sr.render(scene, gh.orbit_camera(k, ORBIT_FRAMES, W, H, cfg["fx"]))
@@ -356,7 +359,7 @@ def main():
             "band_edges": band_edges_used,
             "device": r.device_info(),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.timed_only:
             out["cpu_baseline"] = cpu_baseline(gh, cfg, scene.data[:8 * N], scene.positions)
         print(json.dumps(out))
     for rr in rs:

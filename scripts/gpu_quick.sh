@@ -8,4 +8,4 @@ rm -f gpurun_out/bench1_seg*.json
 timeout -k 10 300 python bench.py --steps 240 --warmup 20 $BENCH_ARGS > gpurun_out/bench1.json 2> gpurun_out/bench1.err; echo "bench rc=$?"
 timeout -k 10 300 python bench.py --steps 240 --warmup 20 --early-out-eps 1e-4 --no-cpu-baseline > gpurun_out/bench1_eo.json 2>> gpurun_out/bench1.err; echo "bench eo rc=$?"
 rm -rf gpurun_out/prof1
-cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof1 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 60 --warmup 10 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof1.log 2>&1; echo "prof rc=$?"
+cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof1 -- python3 $GRAFT_REPO_ROOT/bench.py --timed-only > $GRAFT_REPO_ROOT/gpurun_out/prof1.log 2>&1; echo "prof rc=$?"
