@@ -120,7 +120,7 @@ __device__ __forceinline__ float eval_sh_texture(const uint32_t* __restrict__ te
 // Writes depth[i] always; rec[i] for splats that survive the culls; bbox[i] always
 // (x0 > x1 marks "nothing to draw").
 // ---------------------------------------------------------------------------
-// The camera lives in device memory (written by k_set_camera just before the frame) so that the frame's kernel
+// The camera lives in device memory (written by k_begin_frame just before the frame) so that the frame's kernel
 // arguments do not change from frame to frame and the whole chain can be replayed as a HIP graph.
 __global__ __launch_bounds__(256) void k_project_key(SceneSoA sc, uint32_t n, const CamParams* __restrict__ camp,
                                                      int do_project, int32_t* __restrict__ depth,
