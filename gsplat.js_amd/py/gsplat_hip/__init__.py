@@ -72,6 +72,17 @@ def load_library(path=None):
     p = path or os.environ.get("GSPLAT_HIP_LIB") or LIB_PATH   # GSPLAT_HIP_LIB: experiment builds
     if not os.path.exists(p):
         raise GsplatError("libgsplat_hip.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`" % p)
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as the system one
+    # this library links against).  If torch is imported first, the loader gives this library torch's copy and the two
+    # share streams, events and memory (the N>1 exchange relies on that); loaded the other way round, the process ends
+    # up with two runtimes and torch cannot see the GPU any more.  So: when torch is installed, import it before the
+    # library (GSPLAT_HIP_NO_TORCH=1 skips this for hosts that never touch torch).
+    import sys
+    if "torch" not in sys.modules and os.environ.get("GSPLAT_HIP_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = ctypes.CDLL(p)
     vp = ctypes.c_void_p
     L.gsr_create.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(GsrOptions)]
