@@ -30,24 +30,55 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ORBIT_FRAMES = 120
 
 
+def host_cpu():
+    """(model name, logical cores of the host, cores this process may use)"""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = list(range(os.cpu_count() or 1))
+    return model, os.cpu_count() or 1, usable
+
+
 def cpu_baseline(gh, cfg, data, pos, sample_frames=2, sort_calls=10):
     """The reference's CPU path timed on this host.  Sort: the reference's own wasm/wasm.cpp compiled
-    natively (oracle/_ref) when present, else the bit-identical restatement; 1 thread like the
-    reference's single worker.  Project + composite have no CPU implementation in the reference
-    (they run in WebGL): the oracle's restatement stands in, on `cores` threads."""
+    natively (oracle/_ref) when present, else the bit-identical restatement; ONE thread pinned to one core,
+    like the reference's single worker (Worker.ts:36-57).  Project + composite have no CPU implementation in
+    the reference (they run in WebGL): the oracle's restatement stands in, on `cores` threads."""
     from oracle import oracle as O
-    cores = min(os.cpu_count() or 1, 16)
+    model, host_cores, usable = host_cpu()
+    cores = min(len(usable), 16)
     cams = [gh.orbit_camera(k * 7, ORBIT_FRAMES, cfg["width"], cfg["height"], cfg["fx"]) for k in range(max(sort_calls, sample_frames))]
     use_ref = O.ref_available()
+    pinned = None
+    try:
+        os.sched_setaffinity(0, {usable[len(usable) // 2]})   # SURVEY 8(d): 1 thread, pinned
+        pinned = usable[len(usable) // 2]
+    except (AttributeError, OSError):
+        pass
     t_sort = []
-    for cam in cams[:sort_calls]:
-        vp = cam.f32()[2]
-        t0 = time.perf_counter()
-        if use_ref:
-            O.ref_sort(vp, pos, calls=1)  # two reference calls inside (count + sort): halve below
-        else:
-            O.sort(vp, pos)
-        t_sort.append((time.perf_counter() - t0) / (2.0 if use_ref else 1.0))
+    try:
+        for cam in cams[:2]:    # warm-ups
+            (O.ref_sort(cam.f32()[2], pos, calls=1) if use_ref else O.sort(cam.f32()[2], pos))
+        for cam in cams[:sort_calls]:
+            vp = cam.f32()[2]
+            t0 = time.perf_counter()
+            if use_ref:
+                O.ref_sort(vp, pos, calls=1)  # two reference calls inside (count + sort): halve below
+            else:
+                O.sort(vp, pos)
+            t_sort.append((time.perf_counter() - t0) / (2.0 if use_ref else 1.0))
+    finally:
+        if pinned is not None:
+            os.sched_setaffinity(0, set(usable))
     t_sort = float(np.median(t_sort))
     t_frame = []
     for cam in cams[:sample_frames]:
@@ -78,11 +109,12 @@ def cpu_baseline(gh, cfg, data, pos, sample_frames=2, sort_calls=10):
         "sort_js_ms": js["ms_median"] if js else None,
         "sort_js_note": "wasm.cpp's loops in plain JavaScript (V8, Math.fround per operation), 1 thread; an upper bound for the wasm worker" if js else None,
         "value": 1.0 / t_frame, "unit": "frames/s", "cores": cores, "kind": "port",
-        "sample": "%d full frames of the same 1M-splat 1080p workload (sort 1 thread + project 1 thread + composite on %d threads)"
-                  % (sample_frames, cores),
+        "host_cpu": model, "host_cores_total": host_cores, "sort_pinned_to_cpu": pinned,
+        "sample": "%d full frames of the same %d-splat %dx%d workload (sort 1 thread + project 1 thread + composite on %d threads)"
+                  % (sample_frames, n, cfg["width"], cfg["height"], cores),
         "sort_splats_per_s": n / t_sort, "sort_ms": t_sort * 1e3, "sort_cores": 1,
         "sort_kind": "reference" if use_ref else "port",
-        "sort_sample": "%d sorts of the 1M-splat scene, median" % sort_calls,
+        "sort_sample": "%d sorts of the %d-splat scene after 2 warm-ups, median; 1 core used of %d" % (sort_calls, n, host_cores),
         "frame_ms": t_frame * 1e3,
     }
 
@@ -113,12 +145,25 @@ def main():
                     help="single GPU only: render just the band rank Q of G would own (no exchange) -> per-rank device time of a G-GPU run")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Not under a launcher: start one rank per GPU ourselves.  This process has not touched the GPU (torch is not
+        # even imported yet), so the ranks are plain children and this parent only relays their exit code; rank 0
+        # prints the JSON line.  (The driver's own form, `python -m torch.distributed.run ... bench.py --gpus N`,
+        # arrives with WORLD_SIZE set and takes the branch below.)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus != world:   # every value, 1 included: a silent one-GPU run under an N-rank launcher measures nothing
+        raise SystemExit("bench.py: --gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
 
     import torch
     import gsplat_hip as gh
@@ -210,7 +255,11 @@ def main():
 
     def fence():
         for rr in rs:
-            rr.sync()
+            try:
+                rr.sync()
+            except gh.GsplatError as e:   # frames lost to a list overflow: counted below, the run is then invalid
+                if "not composited" not in str(e):
+                    raise
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -221,6 +270,7 @@ def main():
     fence()
     for rr in rs:
         rr.reset_stats()
+    overflow_before = (sum(int(rr.stats()["overflow_frames"]) for rr in rs), sum(int(rr.stats()["dropped_frames"]) for rr in rs))
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k)
@@ -232,6 +282,11 @@ def main():
         elapsed = float(t.item())
 
     sts = [rr.stats() for rr in rs]
+    overflow_frames = sum(int(x["overflow_frames"]) for x in sts) - overflow_before[0]
+    dropped_frames = sum(int(x["dropped_frames"]) for x in sts) - overflow_before[1]
+    if dropped_frames:
+        # a frame whose lists did not fit is not composited; a timed region containing one has not rendered K frames
+        raise SystemExit("bench.py: %d frame(s) of the timed region were dropped by a bin-list overflow: result invalid" % dropped_frames)
     st = {k: sum(x[k] for x in sts) for k in sts[0] if k.startswith("sum_") or k == "frames"}
     frames = max(int(st["frames"]), 1)
     ms = {k: st["sum_ms_" + k] / frames for k in ("project_key", "sort", "bin", "blend", "combine", "total")}
@@ -304,17 +359,34 @@ def main():
         b_sort = 52.0 * N
         b_proj = 16.0 * N + 48.0 * V
         b_bin = 8.0 * D
-        traffic = valu = traffic_solo = None
-        tpath = os.path.join(ROOT, "profiles", "blend_traffic.json")   # committed PMC measurement (scripts/gpu_pmc.sh)
+        # HBM traffic and VALU instruction counts of k_blend come from rocprofv3 --pmc passes (scripts/gpu_pmc.sh ->
+        # profiles/blend_traffic.json).  They describe ONE build of the kernels: the file carries the build id it was
+        # measured on, and a library with another id gets null rather than a stale figure.
+        traffic = valu = traffic_solo = valu_solo = None
+        tpath = os.path.join(ROOT, "profiles", "blend_traffic.json")
+        traffic_note = "no PMC measurement committed for this workload/configuration"
         if os.path.exists(tpath) and args.config == "C3" and eworld == 1 and args.early_out_eps == 0.0:
             try:
                 tj = json.load(open(tpath))
-                sel = tj["frames_in_flight" if F > 1 else "one_frame"]
-                traffic, valu = sel["hbm_bytes_per_launch"], sel["valu_wave_instructions_per_launch"]
-                traffic_solo = tj["one_frame"]["hbm_bytes_per_launch"]
+                if tj.get("build_id") == gh.build_id():
+                    sel = tj["frames_in_flight" if F > 1 else "one_frame"]
+                    traffic, valu = sel["hbm_bytes_per_launch"], sel["valu_wave_instructions_per_launch"]
+                    traffic_solo = tj["one_frame"]["hbm_bytes_per_launch"]
+                    valu_solo = tj["one_frame"]["valu_wave_instructions_per_launch"]
+                    traffic_note = "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes on this build (profiles/blend_traffic.json)"
+                else:
+                    traffic_note = "profiles/blend_traffic.json was measured on build %s, this library is %s: not reported" % (
+                        tj.get("build_id"), gh.build_id())
             except Exception:
-                traffic = valu = traffic_solo = None
+                traffic = valu = traffic_solo = valu_solo = None
+        # The kernel's launch duration: HIP events on the library's stream.  With several frames in flight the kernels of
+        # different frames overlap, so an event pair around k_blend also spans time in which other frames' kernels held
+        # the CUs: that figure can exceed ms_per_step and is kept only as `timed_region`.  The roofline fraction uses
+        # the duration of the same kernel on the same frames with ONE frame in flight (untimed secondary leg), which is
+        # what the committed rocprofv3 --kernel-trace summary of `bench.py --frames-in-flight 1 --timed-only` shows too.
         ach = b_blend / (ms["blend"] * 1e-3) / 1e9 if ms["blend"] > 0 else 0.0
+        blend_ms = solo["stage_ms"]["blend"] if solo else ms["blend"]
+        ach_solo = b_blend / (blend_ms * 1e-3) / 1e9 if blend_ms > 0 else 0.0
         sm = solo["stage_ms"] if solo else ms   # per-stage figures: uncontended times when several frames were in flight
         out = {
             "metric": "frames_per_sec", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -323,29 +395,29 @@ def main():
             "config": {"workload": "%s: %d synthetic gaussians (seed %d), %dx%d, 120-pose orbit, full render(scene,camera) "
                                    "= depth key + 17-bit sort + projection + binning + composite"
                                    % (args.config, N, cfg["seed"], W, H),
-                       "early_out_eps": args.early_out_eps, "frames_in_flight": F, "stage_events_every": max(1, args.timing_interval), "emulated_rank": args.emulate_rank, "parallelism": "tile-column bands x%d%s" % (world, "" if world == 1 else (", %s all-gather, %s edges" % (args.exchange, "equal" if args.equal_bands else "cost-balanced"))),
+                       "early_out_eps": args.early_out_eps, "frames_in_flight": F, "stage_events_every": max(1, args.timing_interval), "emulated_rank": args.emulate_rank, "backend": (args.backend if world > 1 else None), "world_size": world, "parallelism": "tile-column bands x%d%s" % (world, "" if world == 1 else (", %s all-gather, %s edges" % (args.exchange, "equal" if args.equal_bands else "cost-balanced"))),
                        "output": "RGBA f32 premultiplied, left in HBM"},
             "sorted_splats_per_sec": N / ((sm["project_key"] + sm["sort"]) * 1e-3) if (sm["project_key"] + sm["sort"]) > 0 else None,
             "stage_ms": ms,
             "counts": {"N": N, "V": V, "D_tiles16": D, "bin_entries32": E, "P": band_px},
-            "roofline": {"bound": "hbm", "kernel": "k_blend", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": b_blend, "avg_launch_ms": ms["blend"],
-                         "one_frame_in_flight": None if not solo else {
-                             "avg_launch_ms": solo["stage_ms"]["blend"],
-                             "achieved": b_blend / (solo["stage_ms"]["blend"] * 1e-3) / 1e9,
-                             "frac": b_blend / (solo["stage_ms"]["blend"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "traffic": traffic_solo},
+            "roofline": {"bound": "hbm", "kernel": "k_blend", "achieved": ach_solo, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach_solo / HBM_PEAK_GBS, "traffic": traffic_solo if solo else traffic, "traffic_note": traffic_note,
+                         "algorithmic_bytes_per_launch": b_blend, "avg_launch_ms": blend_ms,
+                         "frames_in_flight_of_this_figure": 1 if solo else F,
+                         "timed_region": None if not solo else {
+                             "frames_in_flight": F, "avg_launch_ms": ms["blend"], "achieved": ach, "frac": ach / HBM_PEAK_GBS,
+                             "traffic": traffic,
+                             "note": "event pairs around k_blend while other frames' kernels share the GPU: overlap-inflated"},
                          "note": "the compositor is bound by VALU issue and wave stalls (barriers, LDS reads), not by HBM "
                                  "(SURVEY 8(d) honest note); see valu and DESIGN.md section 8"},
             # secondary ceiling: VALU issue.  peak = what tools/valu_peak.hip sustains on this chip for the compositor's
             # own instruction mix (11 VALU of a covered quadrant incl. v_exp_f32 and v_pk_fma_f32, operands in VGPRs,
             # 8 waves/SIMD): 0.667e12 wave-instr/s (profiles/r01_valu_peak_mi355x.txt); plain v_fma_f32 sustains 0.623e12
-            "valu": None if not valu or not sm["blend"] else (lambda t_ms, v: {
+            "valu": None if not (valu_solo if solo else valu) or not blend_ms else (lambda t_ms, v: {
                 "wave_instr_per_launch": v, "launch_ms": t_ms, "achieved_wave_instr_per_s": v / (t_ms * 1e-3),
-                "peak_wave_instr_per_s": 0.667e12, "frac": v / (t_ms * 1e-3) / 0.667e12,
-                "note": "one frame in flight (kernels of several frames overlap in the timed region)" if solo else ""})(
-                    sm["blend"], tj["one_frame"]["valu_wave_instructions_per_launch"] if solo else valu),
+                "peak_wave_instr_per_s": 0.667e12, "frac": v / (t_ms * 1e-3) / 0.667e12})(blend_ms, valu_solo if solo else valu),
+            "overflow_frames": overflow_frames, "dropped_frames": dropped_frames,
+            "build_id": gh.build_id(),
             "stage_roofline": {
                 "sort": {"bytes": b_sort, "ms": sm["sort"], "GBps": b_sort / (sm["sort"] * 1e-3) / 1e9 if sm["sort"] else 0,
                          "frac": b_sort / (sm["sort"] * 1e-3) / 1e9 / HBM_PEAK_GBS if sm["sort"] else 0},

@@ -79,7 +79,14 @@ struct gsr_ctx {
     // frame words
     FrameState* fstate = nullptr;       // device
     FrameState* fstate_host = nullptr;  // pinned
-    uint64_t* accum = nullptr;          // device [4]: sums over frames (visible, bin entries, tile entries, frames)
+    uint64_t* accum = nullptr;          // device [8]: sums over frames (visible, bin entries, tile entries, frames), [4] entries of
+                                        // the last frame, sticky [5] frames that did not fit, [6]/[7] most entries/items one needed
+    uint64_t* mailbox = nullptr;        // pinned host word the device stores accum[5] into (k_bin_finalize)
+    uint64_t* mailbox_dev = nullptr;    // its device address
+    uint64_t overflow_seen = 0;         // accum[5] as of the last regrowth
+    uint64_t overflow_frames = 0;       // frames that did not fit, since the context was created
+    uint64_t dropped_frames = 0;        // of those, frames never composited (later frames had been enqueued before the host noticed)
+    uint64_t dropped_unreported = 0;    // dropped frames gsr_sync has not reported yet
     // output
     float4* fb = nullptr;
     uint32_t* fb8 = nullptr;
@@ -241,6 +248,8 @@ int alloc_fb(gsr_ctx* c)
 }
 
 int finish_frame(gsr_ctx* c);
+int handle_overflow(gsr_ctx* c, uint64_t* newly);
+inline bool overflow_pending(const gsr_ctx* c);
 
 // the frame's device work on the context's stream: frame words reset, projection + depth key, sort, (bin, blend)
 static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
@@ -269,7 +278,7 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
         if (!c->n) HIP_TRY(c, hipMemsetAsync(c->bin_total, 0, sizeof(uint32_t) * nbins, s));
         BinBuffers bb{c->depth_index, &c->fstate->sorted_count, c->bbox, c->bin_table, c->blk_counts, c->bin_rects, c->bin_total, c->bin_start, c->seg_start,
                       c->items, c->bin_list, &c->fstate->overflow, &c->fstate->visible, &c->fstate->tile_entries,
-                      c->accum, c->fstate->report, c->bin_capacity, c->max_items, c->seg_len, &c->fstate->seg_len, (c->opt.flags & GSR_FLAG_THROUGHPUT) ? 0 : 1, &c->fstate->queue, std::min<uint32_t>(c->max_items, c->blend_grid), c->seg_target_items, c->bin_blocks};
+                      c->accum, c->mailbox_dev, c->fstate->report, c->bin_capacity, c->max_items, c->seg_len, &c->fstate->seg_len, (c->opt.flags & GSR_FLAG_THROUGHPUT) ? 0 : 1, &c->fstate->queue, std::min<uint32_t>(c->max_items, c->blend_grid), c->seg_target_items, c->bin_blocks};
         launch_bin(bb, g, c->n, s);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BIN], s));
         BlendBuffers bl{c->items, c->seg_start, c->bin_start, c->bin_list, c->rec, c->bbox, c->shcol, c->fb, c->partial,
@@ -316,6 +325,14 @@ int enqueue_frame(gsr_ctx* c, bool render)
     if (!c->have_cam) return fail(c, GSR_ERR_ARG, "gsr_set_camera has not been called");
     if (render && (!c->W || !c->H)) return fail(c, GSR_ERR_ARG, "framebuffer size is 0");
     hipStream_t s = c->stream;
+    if (render && overflow_pending(c)) {
+        // an earlier asynchronous frame did not fit: regrow before this one is enqueued.  The frames that overflowed
+        // are lost (later frames were already behind them); gsr_sync reports how many.
+        uint64_t newly = 0;
+        if (int r = handle_overflow(c, &newly)) return r;
+        c->dropped_frames += newly;
+        c->dropped_unreported += newly;
+    }
     // stage timing is sampled: every timing_every-th frame carries the six events (each is a packet the command
     // processor has to retire; on short frames they cost more than they measure)
     const bool timing = c->ev_valid && (c->frame_no++ % c->timing_every) == 0;
@@ -398,7 +415,7 @@ int finish_frame(gsr_ctx* c)
     return GSR_OK;
 }
 
-// after a synchronised render: pull the frame words, regrow the bin list if it overflowed
+// after a synchronised render: pull the frame words of the last frame (counts for gsr_timings, its overflow word)
 int check_frame_words(gsr_ctx* c, bool* overflowed)
 {
     // one small copy: the frame words up to and including k_bin_finalize's report
@@ -412,16 +429,39 @@ int check_frame_words(gsr_ctx* c, bool* overflowed)
     c->tm.bin_entries = total;
     c->tm.n = c->n;
     *overflowed = c->fstate_host->overflow != 0;
-    if (*overflowed) {
-        const uint64_t need = std::max<uint64_t>(acc[4], total);
-        const uint64_t want = need + (need >> 2) + (1u << 20);
-        if (want > 0xfffffff0ull) return fail(c, GSR_ERR_OVERFLOW, "bin list would need %llu entries", (unsigned long long)want);
+    return GSR_OK;
+}
+
+// true when the device has counted frames that did not fit (k_bin_finalize, sticky accum[5] mirrored into the
+// host-mapped mailbox) that the host has not sized the buffers for yet: a plain host read, no copy, no sync
+inline bool overflow_pending(const gsr_ctx* c)
+{
+    return c->mailbox && *reinterpret_cast<volatile const uint64_t*>(c->mailbox) != c->overflow_seen;
+}
+
+// Frames did not fit since the host last looked: wait for the stream, regrow the list for the largest of them and
+// count them (*newly).  Those frames were not composited: a frame whose lists do not fit publishes no work items, so
+// the framebuffer kept the image before it.  The caller decides whether one of them can still be rendered again.
+int handle_overflow(gsr_ctx* c, uint64_t* newly)
+{
+    *newly = 0;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    uint64_t acc[8];
+    HIP_TRY(c, hipMemcpyAsync(acc, c->accum, sizeof acc, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (acc[5] == c->overflow_seen) return GSR_OK;
+    *newly = acc[5] - c->overflow_seen;
+    c->overflow_seen = acc[5];
+    c->overflow_frames += *newly;
+    const uint64_t need = acc[6];
+    const uint64_t want = need + (need >> 2) + (1u << 20);
+    if (want > 0xfffffff0ull) return fail(c, GSR_ERR_OVERFLOW, "bin list would need %llu entries", (unsigned long long)want);
+    if (want > c->bin_capacity) {
         c->bin_capacity = (uint32_t)want;
         if (int r = dev_alloc(c, &c->bin_list, c->bin_capacity)) return r;
-        c->max_items = 0;
-        if (int r = alloc_bins(c)) return r;
     }
-    return GSR_OK;
+    c->max_items = 0;
+    return alloc_bins(c);
 }
 
 }  // namespace
@@ -462,6 +502,9 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
     if (const char* e = getenv("GSR_NO_GRAPH")) c->graphs_enabled = atoi(e) == 0;
     CREATE_TRY(hipMalloc((void**)&c->accum, 8 * sizeof(uint64_t)));
     CREATE_TRY(hipMemset(c->accum, 0, 8 * sizeof(uint64_t)));
+    CREATE_TRY(hipHostMalloc((void**)&c->mailbox, 64, hipHostMallocMapped));
+    memset(c->mailbox, 0, 64);
+    CREATE_TRY(hipHostGetDevicePointer((void**)&c->mailbox_dev, c->mailbox, 0));
     CREATE_TRY(hipHostMalloc((void**)&c->fstate_host, sizeof(FrameState), hipHostMallocDefault));
     memset(c->fstate_host, 0, sizeof(FrameState));
     c->fstate_host->minmax[0] = 0x7fffffff;            // wasm/wasm.cpp:14
@@ -503,6 +546,7 @@ int gsr_destroy(gsr_ctx* c)
     dev_free(&c->cam_dev);
     dev_free(&c->fstate); dev_free(&c->accum); dev_free(&c->fb); dev_free(&c->fb8);
     if (c->fstate_host) (void)hipHostFree(c->fstate_host);
+    if (c->mailbox) (void)hipHostFree(c->mailbox);
     for (auto& set : c->evring)
         for (auto& e : set) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->link_ev) if (e) (void)hipEventDestroy(e);
@@ -648,25 +692,39 @@ int gsr_scene_limit_box(gsr_ctx* c, const double* box, uint32_t* new_count)
         gsr_ctx* d = &tmp_holder;
         uint32_t* block_count = nullptr;
         uint32_t* total = nullptr;
+        auto free_tmp = [&]() {
+            dev_free(&d->px); dev_free(&d->py); dev_free(&d->pz); dev_free(&d->cov0); dev_free(&d->cov1); dev_free(&d->cov2);
+            dev_free(&d->rgba); dev_free(&d->rotv); dev_free(&d->sclv); dev_free(&block_count); dev_free(&total);
+        };
         int r;
         if ((r = dev_alloc(c, &d->px, n)) || (r = dev_alloc(c, &d->py, n)) || (r = dev_alloc(c, &d->pz, n)) ||
             (r = dev_alloc(c, &d->cov0, n)) || (r = dev_alloc(c, &d->cov1, n)) || (r = dev_alloc(c, &d->cov2, n)) ||
             (r = dev_alloc(c, &d->rgba, n)) || (r = dev_alloc(c, &d->rotv, n)) || (r = dev_alloc(c, &d->sclv, n)) ||
-            (r = dev_alloc(c, &block_count, (n + 1023) / 1024)) || (r = dev_alloc(c, &total, 1)))
+            (r = dev_alloc(c, &block_count, (n + 1023) / 1024)) || (r = dev_alloc(c, &total, 1))) {
+            free_tmp();
             return r;
+        }
         launch_scene_limit_box(n, scene_dev(c), scene_dev(d), box, block_count, total, c->stream);
         hipError_t e1 = hipMemcpyAsync(&kept, total, 4, hipMemcpyDeviceToHost, c->stream);
         hipError_t e2 = hipStreamSynchronize(c->stream);
-        std::swap(c->px, d->px); std::swap(c->py, d->py); std::swap(c->pz, d->pz);
-        std::swap(c->cov0, d->cov0); std::swap(c->cov1, d->cov1); std::swap(c->cov2, d->cov2); std::swap(c->rgba, d->rgba);
-        std::swap(c->rotv, d->rotv); std::swap(c->sclv, d->sclv);
-        dev_free(&d->px); dev_free(&d->py); dev_free(&d->pz); dev_free(&d->cov0); dev_free(&d->cov1); dev_free(&d->cov2);
-        dev_free(&d->rgba); dev_free(&d->rotv); dev_free(&d->sclv); dev_free(&block_count); dev_free(&total);
-        for (hipError_t e : {e1, e2, hipGetLastError()})
+        const hipError_t e3 = hipGetLastError();
+        if (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess) {
+            std::swap(c->px, d->px); std::swap(c->py, d->py); std::swap(c->pz, d->pz);
+            std::swap(c->cov0, d->cov0); std::swap(c->cov1, d->cov1); std::swap(c->cov2, d->cov2); std::swap(c->rgba, d->rgba);
+            std::swap(c->rotv, d->rotv); std::swap(c->sclv, d->sclv);
+        }
+        free_tmp();
+        for (hipError_t e : {e1, e2, e3})
             if (e != hipSuccess) return fail(c, GSR_ERR_HIP, "limitBox failed: %s", hipGetErrorString(e));
         c->n = kept;   // arrays keep their old capacity; per-frame buffers sized for the old count still fit
         c->sort_blocks = (kept + c->sort_kpb - 1) / c->sort_kpb;
         c->bin_blocks = (kept + 2047) / 2048;
+        // The compaction renumbers the splats, so SH rows (indexed by splat - (bandsIndices[0] + 1)) and the band
+        // thresholds no longer belong to them: the SH state is dropped and the scene falls back to its rgba8 colours
+        // until gsr_set_scene_sh is called again.  (Scene.limitBox, Scene.ts:307-366, leaves shs_rgb / bandsIndices
+        // untouched, i.e. stale; a host that wants SH after limitBox re-packs them for the kept splats.)
+        c->sh_count = 0; c->band[0] = c->band[1] = c->band[2] = -1;
+        dev_free(&c->sh_r); dev_free(&c->sh_g); dev_free(&c->sh_b); dev_free(&c->shcol);
     }
     if (new_count) *new_count = kept;
     return GSR_OK;
@@ -678,6 +736,7 @@ int gsr_read_scene(gsr_ctx* c, uint32_t* data, float* positions, float* rotation
     HIP_TRY(c, hipSetDevice(c->device));
     const uint32_t n = c->n;
     if (count) *count = n;
+    if (!data && !positions && !rotations && !scales) return GSR_OK;  // count only: nothing to copy
     if ((rotations || scales) && !c->have_rows) return fail(c, GSR_ERR_ARG, "rotations/scales exist only for scenes built with gsr_set_scene_rows");
     std::vector<float> x(n), y(n), z(n);
     std::vector<uint32_t> c0, c1, c2, cw;
@@ -705,6 +764,13 @@ int gsr_read_scene(gsr_ctx* c, uint32_t* data, float* positions, float* rotation
         if (rotations) { float* r = rotations + 4 * (size_t)i; r[0] = rv[i].x; r[1] = rv[i].y; r[2] = rv[i].z; r[3] = rv[i].w; }
         if (scales) { float* q = scales + 3 * (size_t)i; q[0] = sv[i].x; q[1] = sv[i].y; q[2] = sv[i].z; }
     }
+    return GSR_OK;
+}
+
+int gsr_scene_count(gsr_ctx* c, uint32_t* count)
+{
+    if (!c || !count) return GSR_ERR_ARG;
+    *count = c->n;
     return GSR_OK;
 }
 
@@ -794,17 +860,47 @@ int gsr_sync(gsr_ctx* c)
     if (!c) return GSR_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     if (int r = finish_frame(c)) return r;
+    bool last_ov = false;
     if (c->have_frame && c->ev_render) {
-        bool ov = false;
-        if (int r = check_frame_words(c, &ov)) return r;
-        if (ov) {  // the list was too small: it has been regrown, redo the last frame once
+        if (int r = check_frame_words(c, &last_ov)) return r;
+    }
+    if (overflow_pending(c)) {
+        uint64_t newly = 0;
+        if (int r = handle_overflow(c, &newly)) return r;   // buffers regrown for the largest frame seen
+        if (last_ov && newly) {  // the last frame is one of them and nothing has been enqueued behind it: render it again
             if (int r = enqueue_frame(c, true)) return r;
             if (int r = finish_frame(c)) return r;
-            if (int r = check_frame_words(c, &ov)) return r;
-            if (ov) return fail(c, GSR_ERR_OVERFLOW, "bin list overflow after regrowth");
+            bool again = false;
+            if (int r = check_frame_words(c, &again)) return r;
+            if (again) return fail(c, GSR_ERR_OVERFLOW, "bin list overflow after regrowth");
+            newly -= 1;
         }
+        c->dropped_frames += newly;
+        c->dropped_unreported += newly;
+    }
+    if (c->dropped_unreported) {
+        const unsigned long long k = c->dropped_unreported;
+        c->dropped_unreported = 0;
+        return fail(c, GSR_ERR_OVERFLOW,
+                    "%llu asynchronous frame(s) were not composited: their bin lists did not fit and later frames had already been "
+                    "enqueued (the framebuffer kept the preceding image for them); the lists have been regrown, the context stays usable",
+                    k);
     }
     return GSR_OK;
+}
+
+int gsr_overflow_pending(gsr_ctx* c) { return c && overflow_pending(c) ? 1 : 0; }
+
+int gsr_set_list_capacity(gsr_ctx* c, uint32_t entries)
+{
+    if (!c) return GSR_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->bin_capacity = std::max<uint32_t>(entries, 1024u);
+    if (int r = dev_alloc(c, &c->bin_list, c->bin_capacity)) return r;
+    c->max_items = 0;
+    drop_graph(c);
+    return alloc_bins(c);
 }
 
 int gsr_render(gsr_ctx* c)
@@ -861,6 +957,8 @@ int gsr_get_timings(gsr_ctx* c, gsr_timings* out)
     if (!c || !out) return GSR_ERR_ARG;
     if (c->ev_recorded) { if (int r = finish_frame(c)) return r; }
     *out = c->tm;
+    out->overflow_frames = c->overflow_frames;
+    out->dropped_frames = c->dropped_frames;
     return GSR_OK;
 }
 
@@ -1015,31 +1113,61 @@ int gsr_device_info(gsr_ctx* c, char* name, int32_t name_len, int32_t* cus, int3
 }
 
 // ---- wasm `sort` drop-in (wasm/wasm.cpp:8-13; call site Worker.ts:39) ----
+// Like the wasm export it keeps nothing of the caller's between calls: the positions are copied to the device on
+// every call (12 bytes per splat over PCIe; a caller that sorts one scene many times uses gsr_set_scene + gsr_sort,
+// which is what the renderer does).  An earlier version cached the upload by buffer address and size; JS hosts
+// transform positions in place (Scene.translate/rotate/scale) and a collected Float32Array can come back at the same
+// address, so that cache returned stale orders.  On failure depthIndex is zero-filled and the error goes to stderr
+// (the reference's signature has no error channel).
 void gsplat_sort_host(const float* viewProj, uint32_t vertexCount, const float* fBuffer, uint32_t* depthBuffer,
                       uint32_t* depthIndex, uint32_t* starts, uint32_t* counts)
 {
     (void)starts; (void)counts;
     static std::mutex mu;
     static gsr_ctx* ctx = nullptr;
-    static const float* last_buf = nullptr;
-    static uint32_t last_n = 0;
     std::lock_guard<std::mutex> lock(mu);
+    auto failed = [&](const char* what) {
+        fprintf(stderr, "gsplat_sort_host: %s\n", what);
+        if (depthIndex && vertexCount) memset(depthIndex, 0, (size_t)vertexCount * sizeof(uint32_t));
+    };
+    if (!viewProj || !depthIndex || (vertexCount && !fBuffer)) return failed("NULL argument");
     if (!ctx) {
         gsr_options o{};
-        if (gsr_create(&ctx, &o) != GSR_OK) { fprintf(stderr, "gsplat_sort_host: %s\n", gsr_last_error(nullptr)); return; }
+        if (gsr_create(&ctx, &o) != GSR_OK) { ctx = nullptr; return failed(gsr_last_error(nullptr)); }
     }
-    // The worker copies positions once per scene (Worker.ts:26-27); here the scene is re-uploaded
-    // whenever the buffer identity or size changes.
-    if (fBuffer != last_buf || vertexCount != last_n) {
-        std::vector<uint32_t> data((size_t)vertexCount * 8, 0u);
-        for (uint32_t i = 0; i < vertexCount; i++) memcpy(&data[(size_t)8 * i], fBuffer + (size_t)3 * i, 12);
-        if (gsr_set_scene(ctx, data.data(), fBuffer, vertexCount) != GSR_OK) { fprintf(stderr, "gsplat_sort_host: %s\n", gsr_last_error(ctx)); return; }
-        last_buf = fBuffer; last_n = vertexCount;
+    gsr_ctx* c = ctx;
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return failed("device unavailable");
+    if (vertexCount != c->n || !c->px) {
+        if (vertexCount > 0x7fffffffu / 8) return failed("too many splats");
+        if (alloc_scene(c, vertexCount, false) != GSR_OK) return failed(gsr_last_error(c));
+        c->n = vertexCount;
+    }
+    c->have_sort = false; c->have_frame = false;
+    if (vertexCount) {
+        float* d_pos = nullptr;
+        if (dev_alloc(c, &d_pos, (size_t)vertexCount * 3) != GSR_OK) return failed(gsr_last_error(c));
+        hipError_t e1 = hipMemcpyAsync(d_pos, fBuffer, (size_t)vertexCount * 12, hipMemcpyHostToDevice, c->stream);
+        launch_repack_positions(d_pos, vertexCount, c->px, c->py, c->pz, c->stream);
+        hipError_t e2 = hipStreamSynchronize(c->stream);
+        dev_free(&d_pos);
+        for (hipError_t e : {e1, e2, hipGetLastError()})
+            if (e != hipSuccess) return failed(hipGetErrorString(e));
     }
     float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-    if (gsr_set_camera(ctx, ident, ident, viewProj, 1.f, 1.f) != GSR_OK || gsr_sort(ctx) != GSR_OK ||
-        gsr_read_depth_index(ctx, depthIndex) != GSR_OK || (depthBuffer && gsr_read_keys(ctx, depthBuffer, nullptr) != GSR_OK))
-        fprintf(stderr, "gsplat_sort_host: %s\n", gsr_last_error(ctx));
+    if (gsr_set_camera(c, ident, ident, viewProj, 1.f, 1.f) != GSR_OK || gsr_sort(c) != GSR_OK ||
+        gsr_read_depth_index(c, depthIndex) != GSR_OK || (depthBuffer && gsr_read_keys(c, depthBuffer, nullptr) != GSR_OK))
+        return failed(gsr_last_error(c));
+}
+
+// Identifies the device code this library was built from (a hash of the kernel sources, set by the Makefile):
+// measurements taken on one build (profiles/blend_traffic.json) are not attributed to another.
+const char* gsr_build_id(void)
+{
+#ifdef GSR_BUILD_ID
+    return GSR_BUILD_ID;
+#else
+    return "unknown";
+#endif
 }
 
 }  // extern "C"

@@ -71,6 +71,8 @@ void launch_scene_limit_box(uint32_t n, const SceneDev& src, const SceneDev& dst
 void launch_repack_scene(const uint32_t* data, const float* positions, uint32_t n, float* px, float* py, float* pz,
                          uint32_t* cov0, uint32_t* cov1, uint32_t* cov2, uint32_t* rgba, uint32_t* mismatch, hipStream_t s);
 
+void launch_repack_positions(const float* positions, uint32_t n, float* px, float* py, float* pz, hipStream_t s);
+
 // frame_words: the context's per-frame device words, [0] = minDepth, [1] = maxDepth, the rest zero at frame start
 void launch_begin_frame(const CamParams& cam, CamParams* dst, uint32_t* frame_words, uint32_t nwords, hipStream_t s);
 void launch_project_key(const SceneSoA& sc, uint32_t n, const CamParams* cam_dev, int do_project, int32_t* depth,
@@ -115,7 +117,9 @@ struct BinBuffers {
     uint32_t* overflow;          // bit 0: list too small, bit 1: item table too small
     uint64_t* visible;           // V counter
     uint64_t* tile_entries;      // D counter (16x16 tiles overlapped by visible bboxes)
-    uint64_t* accum;             // [5] running sums over frames: visible, bin entries, tile entries, frames; [4] = entries the last frame needs
+    uint64_t* accum;             // [8] running sums over frames: visible, bin entries, tile entries, frames; [4] = entries the last frame needs;
+                                 // sticky: [5] = frames that did not fit (never composited), [6] / [7] = most entries / items one of them needed
+    uint64_t* mailbox;           // host-mapped word: accum[5] is stored here whenever it changes
     uint64_t* report;            // [6] per-frame copy for the host: accum[0..4] after this frame, [5] = this frame's bin entries
     uint32_t capacity;
     uint32_t max_items;

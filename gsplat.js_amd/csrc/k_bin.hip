@@ -198,7 +198,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_bin_finalize(const uint32_t* __
                                                               uint32_t* __restrict__ overflow, uint64_t* __restrict__ visible,
                                                               uint64_t* __restrict__ tile_entries, uint64_t* __restrict__ accum,
                                                               uint64_t* __restrict__ report, uint32_t* __restrict__ queue,
-                                                              uint32_t queue_start)
+                                                              uint32_t queue_start, uint64_t* __restrict__ mailbox)
 {
     __shared__ uint32_t s_w[5][FIN_WAVES];
     const int per = (nbins + FIN_THREADS - 1) / FIN_THREADS;
@@ -264,8 +264,17 @@ __global__ __launch_bounds__(FIN_THREADS) void k_bin_finalize(const uint32_t* __
         *seg_len_out = seg_len;
         bin_start[nbins] = fits ? tot.v[0] : 0u;
         seg_start[nbins] = fits ? tot.v[1] : 0u;
-        if (!fits) atomicOr(overflow, tot.v[0] > capacity ? 1u : 2u);
         accum[4] = tot.v[0];  // entries this frame needs (the host sizes the regrowth from it)
+        if (!fits) {
+            atomicOr(overflow, tot.v[0] > capacity ? 1u : 2u);
+            // sticky (never reset by k_begin_frame): frames that were not composited, and the most entries any
+            // of them needed; the count also goes to a host-mapped word so that the host notices an overflow in
+            // the middle of an asynchronous run without a copy or a sync (gsr_render_async polls it)
+            accum[5] += 1;
+            accum[6] = max(accum[6], (uint64_t)tot.v[0]);
+            accum[7] = max(accum[7], (uint64_t)tot.v[1]);
+            __hip_atomic_store(mailbox, accum[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         *visible = ctot.v[0];
         *tile_entries = ctot.v[1];
         accum[0] += ctot.v[0]; accum[1] += tot.v[0]; accum[2] += ctot.v[1]; accum[3] += 1;
@@ -439,7 +448,8 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
     }
     hipLaunchKernelGGL(k_bin_finalize, dim3(1), dim3(FIN_THREADS), 0, s, (const uint32_t*)b.bin_total, nbins, b.seg_len,
                        b.seg_target_items, b.items_by_size, b.seg_len_dev, b.max_items, b.capacity, (const uint2*)b.blk_counts, n ? b.nblocks : 0u,
-                       b.bin_start, b.seg_start, b.items, b.overflow, b.visible, b.tile_entries, b.accum, b.report, b.queue, b.queue_start);
+                       b.bin_start, b.seg_start, b.items, b.overflow, b.visible, b.tile_entries, b.accum, b.report, b.queue, b.queue_start,
+                       b.mailbox);
     if (n)
         hipLaunchKernelGGL(k_bin_scatter, dim3(b.nblocks, sl.sx * sl.sy), dim3(SCAT_THREADS), lds, s, b.depth_index,
                            (const uint32_t*)b.rects, b.count, g, sl, (const uint32_t*)b.table, (const uint32_t*)b.bin_start, b.list,

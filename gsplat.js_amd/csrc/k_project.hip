@@ -37,6 +37,21 @@ void launch_repack_scene(const uint32_t* data, const float* positions, uint32_t 
                        pz, cov0, cov1, cov2, rgba, mismatch);
 }
 
+// positions only (the wasm drop-in gsplat_sort_host: Worker.ts:26-27 copies nothing else): AoS xyz -> SoA
+__global__ __launch_bounds__(256) void k_repack_positions(const float* __restrict__ positions, uint32_t n, float* __restrict__ px,
+                                                          float* __restrict__ py, float* __restrict__ pz)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    px[i] = positions[3 * (size_t)i]; py[i] = positions[3 * (size_t)i + 1]; pz[i] = positions[3 * (size_t)i + 2];
+}
+
+void launch_repack_positions(const float* positions, uint32_t n, float* px, float* py, float* pz, hipStream_t s)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_repack_positions, dim3((n + 255) / 256), dim3(256), 0, s, positions, n, px, py, pz);
+}
+
 // ---------------------------------------------------------------------------
 // helpers (column-major 3x3, GLSL conventions: m[c*3+r])
 // ---------------------------------------------------------------------------

@@ -203,7 +203,7 @@ napi_value SceneTransform(napi_env env, napi_callback_info info)
     else if (kind == 2) rc = gsr_scene_scale(c, d);
     else rc = gsr_scene_limit_box(c, d, &count);
     if (rc) return throw_gsr(env, c, rc, "gsr_scene transform");
-    if (kind != 3) gsr_read_scene(c, nullptr, nullptr, nullptr, nullptr, &count);
+    if (kind != 3) gsr_scene_count(c, &count);   // no copy: the transforms exist to keep the scene on the device
     napi_value n;
     napi_create_uint32(env, count, &n);
     return n;
@@ -220,7 +220,7 @@ napi_value ReadScene(napi_env env, napi_callback_info info)
     if (!c || !get_typed(env, argv[1], napi_uint32_array, &data, &nd, true) || !get_typed(env, argv[2], napi_float32_array, &pos, &np, true))
         return nullptr;
     uint32_t count = 0;
-    int rc = gsr_read_scene(c, nullptr, nullptr, nullptr, nullptr, &count);
+    int rc = gsr_scene_count(c, &count);
     if (!rc) {
         if ((data && nd < (size_t)count * 8) || (pos && np < (size_t)count * 3)) {
             napi_throw_range_error(env, nullptr, "output arrays are smaller than the scene");
@@ -306,9 +306,9 @@ napi_value ReadDepthIndex(napi_env env, napi_callback_info info)
     void* out;
     size_t len;
     if (!c || !get_typed(env, argv[1], napi_uint32_array, &out, &len)) return nullptr;
-    gsr_timings t;
-    gsr_get_timings(c, &t);
-    if (len < t.n) { napi_throw_range_error(env, nullptr, "output array is smaller than vertexCount"); return nullptr; }
+    uint32_t n = 0;
+    gsr_scene_count(c, &n);
+    if (len < n) { napi_throw_range_error(env, nullptr, "output array is smaller than vertexCount"); return nullptr; }
     const int rc = gsr_read_depth_index(c, (uint32_t*)out);
     return rc ? throw_gsr(env, c, rc, "gsr_read_depth_index") : undefined(env);
 }
@@ -359,7 +359,39 @@ napi_value GetTimings(napi_env env, napi_callback_info info)
     put("tileEntries", (double)t.tile_entries); put("n", t.n); put("frames", t.frames);
     put("sumMsProjectKey", t.sum_ms_project_key); put("sumMsSort", t.sum_ms_sort); put("sumMsBin", t.sum_ms_bin);
     put("sumMsBlend", t.sum_ms_blend); put("sumMsCombine", t.sum_ms_combine); put("sumMsTotal", t.sum_ms_total);
+    put("overflowFrames", (double)t.overflow_frames); put("droppedFrames", (double)t.dropped_frames);
     return o;
+}
+
+// overflowPending(handle) -> boolean
+napi_value OverflowPending(napi_env env, napi_callback_info info)
+{
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return nullptr;
+    gsr_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return nullptr;
+    napi_value b;
+    napi_get_boolean(env, gsr_overflow_pending(c) != 0, &b);
+    return b;
+}
+
+// setListCapacity(handle, entries): tuning/test hook
+napi_value SetListCapacity(napi_env env, napi_callback_info info)
+{
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return nullptr;
+    gsr_ctx* c = get_ctx(env, argv[0]);
+    double v;
+    if (!c || !get_f64(env, argv[1], &v)) return nullptr;
+    const int rc = gsr_set_list_capacity(c, v < 0 ? 0u : (uint32_t)v);
+    return rc ? throw_gsr(env, c, rc, "gsr_set_list_capacity") : undefined(env);
+}
+
+napi_value BuildId(napi_env env, napi_callback_info)
+{
+    napi_value s;
+    napi_create_string_utf8(env, gsr_build_id(), NAPI_AUTO_LENGTH, &s);
+    return s;
 }
 
 napi_value DeviceInfo(napi_env env, napi_callback_info info)
@@ -412,7 +444,8 @@ napi_value Init(napi_env env, napi_value exports)
         {"setCamera", SetCamera}, {"sort", Call0<gsr_sort>}, {"render", Call0<gsr_render>},
         {"renderAsync", Call0<gsr_render_async>}, {"sync", Call0<gsr_sync>}, {"resetTimings", Call0<gsr_reset_timings>},
         {"readDepthIndex", ReadDepthIndex}, {"readPixels", ReadPixels}, {"getTimings", GetTimings},
-        {"deviceInfo", DeviceInfo}, {"sortHost", SortHost},
+        {"deviceInfo", DeviceInfo}, {"sortHost", SortHost}, {"overflowPending", OverflowPending},
+        {"setListCapacity", SetListCapacity}, {"buildId", BuildId},
     };
     for (auto& f : fns) {
         napi_value fn;

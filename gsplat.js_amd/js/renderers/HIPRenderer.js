@@ -103,7 +103,11 @@ class HIPRenderer {
             for (const p of passes) p.render();
             this._n.renderAsync(this._h);
         };
+        // sync() throws once (code GSPLAT_HIP, "... frame(s) were not composited") when asynchronous frames were lost
+        // to a list overflow; the renderer stays usable and the last frame has been rendered again.
         this.sync = () => this._n.sync(this._h);
+        this.overflowPending = () => this._n.overflowPending(this._h);
+        this.setListCapacity = (entries) => this._n.setListCapacity(this._h, entries);
         this.sort = (camera) => {                // the worker's job alone (Worker.ts:36-43)
             if (camera) { activeCamera = camera; pushCamera(); }
             this._n.sort(this._h);

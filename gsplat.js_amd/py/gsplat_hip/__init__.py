@@ -37,7 +37,8 @@ class GsrTimings(ctypes.Structure):
                 ("sum_ms_bin", ctypes.c_double), ("sum_ms_blend", ctypes.c_double), ("sum_ms_combine", ctypes.c_double),
                 ("sum_ms_total", ctypes.c_double),
                 ("sum_visible", ctypes.c_uint64), ("sum_bin_entries", ctypes.c_uint64),
-                ("sum_tile_entries", ctypes.c_uint64), ("sum_frames", ctypes.c_uint64)]
+                ("sum_tile_entries", ctypes.c_uint64), ("sum_frames", ctypes.c_uint64),
+                ("overflow_frames", ctypes.c_uint64), ("dropped_frames", ctypes.c_uint64)]
 
 
 def edge_arrays(edges):
@@ -61,7 +62,22 @@ EXPORTS = [
     "gsr_read_bin_totals", "gsr_convert_rgba8_async", "gsr_framebuffer8_device_ptr",
     "gsr_pack_band_rgba8_async", "gsr_unpack_slabs_rgba8_async",
     "gsr_framebuffer_device_ptr", "gsr_stream_handle", "gsr_stream_order", "gsr_device_info", "gsplat_sort_host",
+    "gsr_overflow_pending", "gsr_set_list_capacity", "gsr_scene_count", "gsr_build_id",
 ]
+
+
+def _assert_one_hip_runtime():
+    """The library and torch must share ONE libamdhip64 (streams, events and device pointers cross between them).
+    Which copy that is depends on load order (see load_library); two mapped copies mean two runtimes in the process,
+    which fails in obscure ways later, so fail here with the reason."""
+    try:
+        with open("/proc/self/maps") as f:
+            paths = {line.split()[-1] for line in f if "libamdhip64" in line}
+    except OSError:
+        return
+    if len(paths) > 1:
+        raise GsplatError("two HIP runtimes are mapped into this process (%s): import torch before gsplat_hip, or set "
+                          "GSPLAT_HIP_NO_TORCH=1 in a process that never uses torch" % ", ".join(sorted(paths)))
 
 
 def load_library(path=None):
@@ -84,6 +100,7 @@ def load_library(path=None):
         except Exception:
             pass
     L = ctypes.CDLL(p)
+    _assert_one_hip_runtime()
     vp = ctypes.c_void_p
     L.gsr_create.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(GsrOptions)]
     L.gsr_destroy.argtypes = [vp]
@@ -126,6 +143,11 @@ def load_library(path=None):
                                   ctypes.POINTER(ctypes.c_int32)]
     L.gsplat_sort_host.argtypes = [vp, ctypes.c_uint32, vp, vp, vp, vp, vp]
     L.gsplat_sort_host.restype = None
+    L.gsr_overflow_pending.argtypes = [vp]
+    L.gsr_set_list_capacity.argtypes = [vp, ctypes.c_uint32]
+    L.gsr_scene_count.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32)]
+    L.gsr_build_id.argtypes = []
+    L.gsr_build_id.restype = ctypes.c_char_p
     for name in EXPORTS:
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int and name not in ("gsplat_sort_host",):
@@ -367,7 +389,22 @@ class HIPRenderer:
         self._check(self._L.gsr_render_async(self._ctx))
 
     def sync(self):
+        """Wait for the enqueued frames.  Raises GsplatError (code -5) once if asynchronous frames were lost to a list
+        overflow; the lists have been regrown by then and the renderer stays usable."""
         self._check(self._L.gsr_sync(self._ctx))
+
+    def overflow_pending(self):
+        """True while the device has reported a list overflow that the host has not handled (no copy, no sync)."""
+        return bool(self._L.gsr_overflow_pending(self._ctx))
+
+    def set_list_capacity(self, entries):
+        """Tuning/test hook: capacity of the bin-list buffer in entries (call after the scene is uploaded)."""
+        self._check(self._L.gsr_set_list_capacity(self._ctx, int(entries)))
+
+    def scene_count(self):
+        n = ctypes.c_uint32(0)
+        self._check(self._L.gsr_scene_count(self._ctx, ctypes.byref(n)))
+        return n.value
 
     def sort(self, camera=None):
         if camera is not None:
@@ -465,6 +502,11 @@ class HIPRenderer:
 
     def stream_handle(self):
         return self._L.gsr_stream_handle(self._ctx)
+
+
+def build_id():
+    """Hash of the kernel sources the loaded library was built from."""
+    return load_library().gsr_build_id().decode()
 
 
 WebGLRenderer = HIPRenderer  # the name callers of the reference use (src/index.ts:5)

@@ -84,6 +84,11 @@ typedef struct gsr_timings {
     double sum_ms_project_key, sum_ms_sort, sum_ms_bin, sum_ms_blend, sum_ms_combine, sum_ms_total;
     /* device-side sums over every frame rendered since gsr_reset_timings (valid after gsr_sync) */
     uint64_t sum_visible, sum_bin_entries, sum_tile_entries, sum_frames;
+    /* sticky since gsr_create (gsr_reset_timings does not clear them): */
+    uint64_t overflow_frames; /* frames whose bin lists did not fit the list capacity (each made the lists regrow) */
+    uint64_t dropped_frames;  /* of those, frames that were never composited: asynchronous frames behind which later
+                                 frames had been enqueued before the host noticed (gsr_sync reports them once with
+                                 GSR_ERR_OVERFLOW); 0 for callers of the blocking gsr_render */
 } gsr_timings;
 
 /* ---- lifetime ---- */
@@ -108,12 +113,14 @@ int gsr_scene_scale(gsr_ctx *ctx, const double *s /* 3 */);
 int gsr_scene_limit_box(gsr_ctx *ctx, const double *box /* 6 */, uint32_t *new_count);
 /* Any of the outputs may be NULL.  data: 8 u32 per splat; rotations (w,x,y,z) / scales only for scenes built from rows. */
 int gsr_read_scene(gsr_ctx *ctx, uint32_t *data, float *positions, float *rotations, float *scales, uint32_t *count);
+int gsr_scene_count(gsr_ctx *ctx, uint32_t *count); /* splats in the device scene (changes with gsr_scene_limit_box); no copy */
 
 /* Spherical-harmonics colour (the fork's SH textures): sh_r/g/b = Scene.shs_rgb (8 u32 = 16 truncated halves per
  * SH-carrying splat and channel, src/core/Scene.ts:108-124; uploaded by setShTextures, WebGLRenderer.ts:321-366),
  * band_index = Scene.bandsIndices (uniform u_bandIndex, WebGLRenderer.ts:209-211): splat i > band_index[0] takes its
  * colour from eval_sh_rgb (vertex.glsl.ts:57-104,180-204) with degree 1/2/3 by band_index[1], band_index[2].
- * sh_count must be n - (band_index[0] + 1).  Call after gsr_set_scene (which clears any SH state); sh_count 0 clears. */
+ * sh_count must be n - (band_index[0] + 1).  Call after gsr_set_scene (which clears any SH state); sh_count 0 clears.
+ * gsr_scene_limit_box renumbers the splats and therefore also clears the SH state. */
 int gsr_set_scene_sh(gsr_ctx *ctx, const uint32_t *sh_r, const uint32_t *sh_g, const uint32_t *sh_b, uint32_t sh_count,
                      const int32_t *band_index /* 3 */);
 
@@ -135,6 +142,17 @@ int gsr_sort(gsr_ctx *ctx);         /* depth key + sort only (blocking)         
 int gsr_render(gsr_ctx *ctx);       /* sort + project + bin + composite (blocking)         */
 int gsr_render_async(gsr_ctx *ctx); /* enqueue one frame on the context's stream           */
 int gsr_sync(gsr_ctx *ctx);         /* wait for the stream; reports deferred errors        */
+/* List overflow.  The per-bin splat lists live in one device buffer sized from the scene (6 entries per splat + 1 M);
+ * a frame that needs more publishes no compositor work (its framebuffer keeps the preceding image), bumps a sticky
+ * device counter and stores it in a host-mapped word.  The blocking gsr_render regrows and renders the frame again, so
+ * its caller never sees this.  With gsr_render_async the host learns of it later: gsr_render_async polls the word
+ * (a host memory read) and regrows before enqueuing the next frame; gsr_sync regrows, renders the LAST frame again if
+ * it was among them, and returns GSR_ERR_OVERFLOW once if earlier frames were lost (gsr_timings.dropped_frames counts
+ * them; the context stays usable).  gsr_overflow_pending: 1 while the device has reported an overflow that the host
+ * has not handled yet -- a caller about to ship the frame it just enqueued (multi-GPU exchange) calls gsr_sync first. */
+int gsr_overflow_pending(gsr_ctx *ctx);
+/* Tuning/test hook: set the list capacity in entries (>= 1024).  Call after gsr_set_scene* (which sizes it anew). */
+int gsr_set_list_capacity(gsr_ctx *ctx, uint32_t entries);
 
 /* ---- results ---- */
 /* The whole permutation (wasm's depthIndex).  On a band context the frame sorted only the band's survivors; this
@@ -179,11 +197,17 @@ void *gsr_stream_handle(gsr_ctx *ctx);          /* hipStream_t */
  * ctx_waits = 1: the context's later work waits for everything enqueued on `other_stream` so far. */
 int gsr_stream_order(gsr_ctx *ctx, void *other_stream, int32_t ctx_waits);
 int gsr_device_info(gsr_ctx *ctx, char *name, int32_t name_len, int32_t *compute_units, int32_t *clock_khz);
+/* Hash of the kernel sources this library was built from (hex string; "unknown" for an ad-hoc build): profiler
+ * measurements are stamped with it so that they are never attributed to a different build. */
+const char *gsr_build_id(void);
 
 /* ---- drop-in for the wasm export, same argument list as wasm/wasm.cpp:8-13.
  * Host pointers; depthBuffer/starts/counts may be NULL (depthBuffer, when given,
  * receives the 17-bit keys like the reference leaves them).  Uses a process-wide
- * context on device 0; returns nothing, like the reference. */
+ * context on device 0; returns nothing, like the reference.  The positions are copied
+ * to the device on every call (nothing of the caller's is remembered between calls:
+ * Worker.ts:23-27 re-copies them on every scene message, and JS hosts edit them in place);
+ * on failure depthIndex is zero-filled and the reason is printed to stderr. */
 void gsplat_sort_host(const float *viewProj, uint32_t vertexCount, const float *fBuffer, uint32_t *depthBuffer,
                       uint32_t *depthIndex, uint32_t *starts, uint32_t *counts);
 

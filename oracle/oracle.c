@@ -584,6 +584,13 @@ void orc_tile_stats(const int32_t *bbox, uint32_t n, int tile, uint64_t *V, uint
  *                    expression the HIP kernel uses (explicit fmaf = v_fma_f32,
  *                    everything else unfused), so the discard decision
  *                    (A < -4) is bit-identical; weight and sums in f64.
+ * mode 2 "RGBA8 ROP": geometry of mode 0, but the destination is re-quantised to
+ *                    8-bit UNORM after EVERY fragment, like the reference's default
+ *                    drawing buffer (RGBA8, premultipliedAlpha; WebGLRenderer.ts:38,
+ *                    139-142,282-285): dst = round(clamp(dst + (1-dst.a)*src, 0, 1)*255)/255.
+ *                    A model of a fixed-function ROP (real hardware differs in the last
+ *                    bit of the blend arithmetic); used only to QUANTIFY the gap between
+ *                    the browser's canvas and the fp32 image this build defines parity on.
  * out: W*H*4 floats, premultiplied RGBA, row 0 = top.
  * y_begin/y_end restrict rows (lets callers thread over row bands).
  * ---------------------------------------------------------------------- */
@@ -609,7 +616,7 @@ void orc_render(uint32_t n, const uint32_t *depth_index, const float *raw, const
         for (int y = y0; y <= y1; y++) {
             for (int x = b[0]; x <= b[2]; x++) {
                 double B;
-                if (mode == 0) {
+                if (mode == 0 || mode == 2) {
                     double dx = (x + 0.5) - (double)rw[0];
                     double dy = ((double)H - (y + 0.5)) - (double)rw[1];
                     double vx = 2.0 * (dx * rw[2] + dy * rw[3]) / M2;
@@ -636,6 +643,11 @@ void orc_render(uint32_t n, const uint32_t *depth_index, const float *raw, const
                 double *px = acc + ((size_t)(y - y_begin) * W + x) * 4;
                 double t = 1.0 - px[3];
                 px[0] += t * B * cr; px[1] += t * B * cg; px[2] += t * B * cb; px[3] += t * B;
+                if (mode == 2)
+                    for (int ch = 0; ch < 4; ch++) {
+                        double v = px[ch] < 0.0 ? 0.0 : (px[ch] > 1.0 ? 1.0 : px[ch]);
+                        px[ch] = floor(v * 255.0 + 0.5) / 255.0;
+                    }
             }
         }
         (void)rgb8;

@@ -248,7 +248,74 @@ def _full_size_checks(gh, oracle, scenes, name, k, image=True, eps=0.0):
         assert err <= (TOL_EARLY if eps > 0 else TOL_EXACT), err
         a = img[..., 3]
         assert a.min() >= 0.0 and a.max() <= 1.0 + 1e-6
+        if eps == 0:
+            _check_against_ideal_mode(img, oracle.render(odi, oraw, orec, obbox, cfg["width"], cfg["height"], 0))
     r.dispose()
+
+
+def _check_against_ideal_mode(img, ideal):
+    """The kernel against the oracle's mode 0 (vPosition solved in f64 from the shader's f32 varyings, window
+    coordinates: nothing of k_blend's bin-relative f32 expression in it).  The two can differ only where a pixel
+    centre lies within f32 rounding of an ellipse edge (|vPosition|^2 = 4), where one side draws a fragment of weight
+    <= e^-4 * opacity and the other does not.  Measured on the CPU (mode 1 vs mode 0): 37 such pixels on C2 pose 13,
+    69 on C3 pose 21, of 2 073 600; largest difference 0.010."""
+    d = np.abs(img.astype(np.float64) - ideal.astype(np.float64)).max(axis=2)
+    flips = int((d > TOL_EXACT).sum())
+    assert flips <= 2e-4 * d.size, flips
+    assert d.max() < np.exp(-4.0) + 1e-3, d.max()
+
+
+@pytest.mark.parametrize("name,k", [("C1", 40), ("C2", 13)])
+def test_image_vs_ideal_mode(gh, oracle, scenes, name, k):
+    cfg = gh.synth.CONFIGS[name]
+    rows, data, pos = scenes(name)
+    cam = _camera(gh, k, cfg)
+    r = gh.HIPRenderer(cfg["width"], cfg["height"])
+    r.set_raw_scene(data, pos)
+    r.set_camera(cam)
+    r.render_async(); r.sync()
+    img = r.readPixelsFloat()
+    r.dispose()
+    v, p, vp = cam.f32()
+    ideal = oracle.render_scene(data, pos, v, p, vp, cam.fx, cam.fy, cfg["width"], cfg["height"], mode=0)[0]
+    _check_against_ideal_mode(img, ideal)
+
+
+def test_offaxis_splats_match_independent_closed_form(gh, oracle):
+    """The HIP path against tests/independent_math.py (float64 linear algebra from the meaning of the shader's
+    expressions: (J'W)(4 Sigma)(J'W)^T + 0.3 I, weight = opacity * exp(-2 d^T C^-1 d)), on off-axis, rotated,
+    anisotropic splats: neither oracle.c nor the kernels' operation order is involved in the expected values."""
+    import independent_math as im
+    from test_oracle_render import _offaxis_case, _usable
+    W, H, fx, fy = 160, 120, 260.0, 240.0
+    rng = np.random.default_rng(77)
+    r = gh.HIPRenderer(W, H)
+    checked = 0
+    for _ in range(200):
+        case = _offaxis_case(oracle, rng, W, H, fx, fy)
+        if not _usable(case, W, H) or max(case["C"][0, 0], case["C"][1, 1]) < 6.0:
+            continue
+        r.set_raw_scene(case["data"], case["pos"])
+        r.set_camera_arrays(case["view"], case["proj"], case["vp"], fx, fy)
+        r.render_async(); r.sync()
+        img = r.readPixelsFloat().astype(np.float64)
+        rec, bbox = r.read_records()
+        major, minor, lam = im.axes_from_cov(case["C"])
+        flip = np.array([1.0, -1.0])
+        u, w = 2 * (major * flip) / (major @ major), 2 * (minor * flip) / (minor @ minor)
+        assert abs(rec[0, 0] - case["centre"][0]) < 2e-3 and abs(rec[0, 1] - (H - case["centre"][1])) < 2e-3
+        assert np.linalg.norm(rec[0, 2:4] - u) <= 1.2e-3 * np.linalg.norm(u)
+        assert np.linalg.norm(rec[0, 4:6] - w) <= 1.2e-3 * np.linalg.norm(w)
+        rgba = [v / 255.0 for v in case["rgba"]]
+        want, edge = im.splat_image(case["centre"], case["C"], rgba[3], rgba[:3], W, H)
+        err = np.abs(img - want).max(axis=2)
+        err[edge] = 0.0
+        assert err.max() < 1e-4, err.max()
+        checked += 1
+        if checked == 8:
+            break
+    r.dispose()
+    assert checked == 8
 
 
 def test_full_size_c3_1m_1080p(gh, oracle, scenes):
@@ -645,4 +712,91 @@ def test_on_device_scene_build_and_transforms(gh, oracle):
     r.set_raw_scene(st.data, st.positions)
     with pytest.raises(gh.GsplatError, match="gsr_set_scene_rows"):
         r.scene_translate([1, 0, 0])
+    r.dispose()
+
+
+def test_list_overflow_is_sticky_counted_and_repaired(gh, oracle, scenes):
+    """VERDICT r1 / ADVICE: a frame whose bin lists do not fit publishes no compositor work; with frames enqueued
+    asynchronously the host used to see only the LAST frame's overflow word.  Now: a sticky device counter mirrored
+    into a host-mapped word, regrowth at the next enqueue or sync, the last frame rendered again, and one
+    GSR_ERR_OVERFLOW from gsr_sync that says how many earlier frames were lost."""
+    rows, data, pos = scenes(60000, 21)
+    W, H = 640, 480
+    cams = [gh.orbit_camera(k, width=W, height=H) for k in (3, 9, 15)]
+    ref = gh.HIPRenderer(W, H)
+    ref.set_raw_scene(data, pos)
+    ref.set_camera(cams[2])
+    ref.render_async(); ref.sync()
+    want = ref.readPixelsFloat()
+    assert ref.stats()["overflow_frames"] == 0 and ref.stats()["bin_entries"] > 4096
+    ref.dispose()
+
+    # blocking render: overflow -> regrow -> same frame again, invisible to the caller apart from the counter
+    r = gh.HIPRenderer(W, H)
+    r.set_raw_scene(data, pos)
+    r.set_list_capacity(2048)
+    r.set_camera(cams[2])
+    r._check(r._L.gsr_render(r._ctx))
+    st = r.stats()
+    assert st["overflow_frames"] == 1 and st["dropped_frames"] == 0 and not r.overflow_pending()
+    assert np.array_equal(r.readPixelsFloat(), want)
+
+    # three asynchronous frames into a list that is far too small
+    r.set_list_capacity(2048)
+    for cam in cams:
+        r.set_camera(cam)
+        r.render_async()
+    with pytest.raises(gh.GsplatError, match="not composited"):
+        r.sync()
+    st = r.stats()
+    assert st["overflow_frames"] >= 2 and 1 <= st["dropped_frames"] <= 2, st
+    assert not r.overflow_pending()
+    r.sync()                                   # reported once; the context stays usable
+    assert np.array_equal(r.readPixelsFloat(), want), "the last frame was rendered again after the regrowth"
+    r.set_camera(cams[0])
+    r.render_async(); r.sync()
+    assert r.stats()["overflow_frames"] == st["overflow_frames"]
+    r.dispose()
+
+
+def test_sort_host_sees_positions_edited_in_place(gh, oracle, scenes):
+    """gsplat_sort_host cached the upload by buffer address + count; a JS Scene.translate edits the same
+    Float32Array in place, so the second call sorted the old positions.  It now copies the positions on every call."""
+    rows, data, pos = scenes(20000, 31)
+    L = gh.load_library()
+    vp = gh.orbit_camera(5, width=640, height=480).f32()[2]
+    buf = np.array(pos, dtype=np.float32, copy=True)
+    out = np.empty(buf.size // 3, dtype=np.uint32)
+    keys = np.empty_like(out)
+    L.gsplat_sort_host(vp.ctypes.data, out.size, buf.ctypes.data, keys.ctypes.data, out.ctypes.data, None, None)
+    odi, okeys, _ = oracle.sort(vp, buf)
+    assert np.array_equal(out, odi) and np.array_equal(keys, okeys)
+    buf.reshape(-1, 3)[:, 2] *= -1.0            # same address, same count, other scene
+    buf.reshape(-1, 3)[:, 0] += 0.25
+    L.gsplat_sort_host(vp.ctypes.data, out.size, buf.ctypes.data, None, out.ctypes.data, None, None)
+    odi2, _, _ = oracle.sort(vp, buf)
+    assert not np.array_equal(odi, odi2)
+    assert np.array_equal(out, odi2)
+    # other size through the same process-wide context, then back
+    m = 777
+    out2 = np.empty(m, dtype=np.uint32)
+    L.gsplat_sort_host(vp.ctypes.data, m, buf.ctypes.data, None, out2.ctypes.data, None, None)
+    assert np.array_equal(out2, oracle.sort(vp, buf[:3 * m])[0])
+
+
+def test_limit_box_clears_sh_state(gh):
+    """limitBox renumbers the splats; SH rows addressed by the old numbering must not survive it."""
+    n = 4096
+    rows = gh.synth.synth_rows(n, 17)
+    r = gh.HIPRenderer(320, 240)
+    r.set_scene_rows(rows)
+    band = np.array([-1, n // 4, n // 2], dtype=np.int32)
+    tex = [np.zeros(8 * n, dtype=np.uint32) for _ in range(3)]
+    r.set_sh(tex, band)
+    kept = r.scene_limit_box([-1.0, 1.0, -1.0, 1.0, -1.0, 1.0])
+    assert 0 < kept < n and r.scene_count() == kept
+    r.set_camera(gh.orbit_camera(2, width=320, height=240))
+    r.render_async(); r.sync()
+    with pytest.raises(gh.GsplatError):
+        r.read_sh_colors()                      # no SH state any more: the scene renders with its rgba8 colours
     r.dispose()

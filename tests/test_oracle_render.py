@@ -124,3 +124,109 @@ def test_restated_and_ideal_modes_agree_except_boundary_flips(oracle, scenes):
 def test_tile_stats(oracle):
     bbox = np.array([[0, 0, 15, 15], [15, 15, 16, 16], [1, 1, 0, 0], [0, 0, 639, 0]], dtype=np.int32)
     assert oracle.tile_stats(bbox, 16) == (3, 1 + 4 + 40)
+
+
+# ---------------------------------------------------------------------------
+# Off-axis, rotated, anisotropic splats against an INDEPENDENT float64 statement of the mathematics
+# (tests/independent_math.py: linear algebra from what the shader's expressions mean, numpy eigensolver /
+# matrix inverse; no shared operation sequence with oracle.c).  The centred isotropic KAT above cannot see a
+# transposition or sign slip in J, transpose(mat3(view)) * J or Vrk (cam.x = cam.y = 0 zeroes J's third column and
+# b = 0); these can: vertex.glsl.ts:146-175.
+# ---------------------------------------------------------------------------
+def _offaxis_case(oracle, rng, W, H, fx, fy):
+    import independent_math as im
+    eye = rng.normal(size=3)
+    eye *= rng.uniform(5.0, 9.0) / np.linalg.norm(eye)
+    target = rng.uniform(-0.5, 0.5, size=3)
+    R = im.look_at_rotation(eye, target, rng.uniform(-np.pi, np.pi))
+    view, proj, vp = im.camera_matrices(R, eye, fx, fy, W, H)
+    p = target + rng.uniform(-1.2, 1.2, size=3)             # off the optical axis
+    scale = np.exp(rng.uniform(np.log(0.02), np.log(0.35), size=3))
+    scale[rng.integers(3)] *= 4.0                            # clearly anisotropic
+    rot = tuple(int(v) for v in rng.integers(0, 256, size=4))
+    rgba = tuple(int(v) for v in rng.integers(40, 256, size=4))
+    data, pos = make_scene(oracle, [dict(pos=p, scale=scale, rgba=rgba, rot=rot)])
+    p32 = pos[:3].astype(np.float64)
+    centre, C, pc = im.footprint(p32, im.decode_cov4(data[:8]), view, fx, fy, W, H)
+    return dict(view=view, proj=proj, vp=vp, data=data, pos=pos, centre=centre, C=C, pc=pc, rgba=rgba)
+
+
+def _usable(case, W, H):
+    a, b, c = case["C"][0, 0], case["C"][0, 1], case["C"][1, 1]
+    cx, cy = case["centre"]
+    return (case["pc"][2] > 1.0 and 0.15 * W < cx < 0.85 * W and 0.15 * H < cy < 0.85 * H and
+            (a - c) ** 2 / 4 + b * b > 1.0 and abs(b) > 0.05 * (a + c) and 2 * max(a, c) < 900.0 ** 2 / 4)
+
+
+def test_projection_matches_independent_f64_math(oracle):
+    import independent_math as im
+    W, H, fx, fy = 640, 480, 700.0, 650.0     # fx != fy on purpose
+    rng = np.random.default_rng(2024)
+    checked = 0
+    for _ in range(200):
+        case = _offaxis_case(oracle, rng, W, H, fx, fy)
+        if not _usable(case, W, H):
+            continue
+        rec, bbox, raw = oracle.project(case["data"], case["view"], case["proj"], fx, fy, W, H)
+        assert raw[0, 11] == 1.0
+        major, minor, lam = im.axes_from_cov(case["C"])
+        tol = 3e-4       # f32 chain of ~90 flops with cancellation in cov2d; a wrong sign or transposition is O(1)
+        assert np.allclose(raw[0, 0:2], case["centre"], rtol=0, atol=2e-3), (raw[0, 0:2], case["centre"])
+        assert np.linalg.norm(raw[0, 2:4] - major) <= tol * np.linalg.norm(major), (raw[0, 2:4], major)
+        assert np.linalg.norm(raw[0, 4:6] - minor) <= tol * np.linalg.norm(major), (raw[0, 4:6], minor)
+        # the derived record (image rows top-down): centre, and u / w with vPosition(p) = (dot(p-c,u), dot(p-c,w))
+        flip = np.array([1.0, -1.0])
+        u = 2 * (major * flip) / (major @ major)
+        w = 2 * (minor * flip) / (minor @ minor)
+        assert abs(rec[0, 0] - case["centre"][0]) < 2e-3 and abs(rec[0, 1] - (H - case["centre"][1])) < 2e-3
+        assert np.linalg.norm(rec[0, 2:4] - u) <= tol * np.linalg.norm(u) * 4
+        assert np.linalg.norm(rec[0, 4:6] - w) <= tol * np.linalg.norm(w) * 4
+        assert abs(raw[0, 6] - case["rgba"][3] / 255.0) < 1e-7
+        checked += 1
+    assert checked >= 24, checked
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_offaxis_anisotropic_image_matches_closed_form(oracle, mode):
+    import independent_math as im
+    W, H, fx, fy = 160, 120, 260.0, 240.0
+    rng = np.random.default_rng(77)
+    checked = 0
+    for _ in range(200):
+        case = _offaxis_case(oracle, rng, W, H, fx, fy)
+        a, c = case["C"][0, 0], case["C"][1, 1]
+        if not _usable(case, W, H) or max(a, c) < 6.0:
+            continue
+        img, di, V, D = oracle.render_scene(case["data"], case["pos"], case["view"], case["proj"], case["vp"], fx, fy, W, H,
+                                            mode=mode, threads=2)
+        r, g, b, al = [v / 255.0 for v in case["rgba"]]
+        want, edge = im.splat_image(case["centre"], case["C"], al, (r, g, b), W, H)
+        err = np.abs(img.astype(np.float64) - want).max(axis=2)
+        err[edge] = 0.0
+        assert want[..., 3].max() > 0.3 * al and (want[..., 3] > 0).sum() > 40
+        assert err.max() < 1e-4, (err.max(), case["C"])
+        checked += 1
+        if checked == 8:
+            break
+    assert checked == 8
+
+
+def test_rgba8_rop_mode_quantifies_the_canvas_gap(oracle, scenes):
+    """oracle mode 2 re-quantises the destination to RGBA8 after every fragment, like the reference's default drawing
+    buffer (WebGLRenderer.ts:38,139-142,282-285).  It is a model used to QUANTIFY how far a browser canvas is from the
+    fp32 image parity is defined on (scripts/rop_gap_report.py), not a parity target."""
+    from gsplat_hip import orbit_camera, synth
+    cfg = synth.CONFIGS["C1"]
+    rows, data, pos = scenes("C1")
+    cam = orbit_camera(40, width=cfg["width"], height=cfg["height"], fx=cfg["fx"])
+    a = render(oracle, data, pos, cam, cfg["width"], cfg["height"], 0)[0].astype(np.float64)
+    b = render(oracle, data, pos, cam, cfg["width"], cfg["height"], 2)[0].astype(np.float64)
+    assert np.abs(b * 255 - np.round(b * 255)).max() < 1e-4          # every value is an 8-bit level
+    d = np.abs(a - b) * 255
+    assert 0.2 < d.mean() < 1.0 and 2.0 < d.max() < 12.0             # C1: mean ~0.5 LSB, max ~4-5 LSB
+    # a single fragment is quantised exactly once: within half an LSB of the fp32 value
+    d1, p1 = make_scene(oracle, [dict(pos=(0.2, 0.1, 0), scale=(0.2, 0.05, 0.1), rgba=(200, 100, 50, 180), rot=(200, 160, 90, 130))])
+    c1 = front_camera(96, 96, 300.0)
+    x = render(oracle, d1, p1, c1, 96, 96, 0)[0].astype(np.float64)
+    y = render(oracle, d1, p1, c1, 96, 96, 2)[0].astype(np.float64)
+    assert np.abs(x - y).max() <= 0.5 / 255 + 1e-7 and y.max() > 0.3
