@@ -213,16 +213,30 @@ def main():
         raise SystemExit("rank %d has an empty band (more ranks than 32-px bin columns)" % rank)
     band = (x0, x1) if eworld > 1 else None
     F = max(1, args.frames_in_flight)
+    # N>1 over RCCL: the exchange lives in the library (gsr_comm_init / gsr_allgather_frame_async), torch.distributed is
+    # only the launcher's rendezvous: it carries the communicator ids once and does the barrier / max-over-ranks of the
+    # timing.  N>1 over gloo is the rehearsal on a box without peers: ranks may share a GPU (RCCL refuses that), so the
+    # slabs go through the harness (bands.FrameExchange, host staged).
+    in_library = world > 1 and args.backend == "nccl"
+    if in_library and args.exchange != "rgba8":
+        raise SystemExit("bench.py: the in-library RCCL exchange ships RGBA8 slabs; --exchange f32 exists only for the gloo rehearsal")
     rs = []
     for _ in range(F):   # every context owns its buffers and its stream; frames are independent of each other
-        rr = gh.HIPRenderer(W, H, device=local_rank, early_out_eps=args.early_out_eps, band=band, timing=True, throughput=F > 1)
+        rr = gh.HIPRenderer(W, H, device=local_rank, early_out_eps=args.early_out_eps, band=None if in_library else band,
+                            timing=True, throughput=F > 1)
+        rs.append(rr)
+    if in_library:
+        ids = [[gh.new_group_id() for _ in range(F)] if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        for rr, cid in zip(rs, ids[0]):      # one communicator per context: frames in flight exchange independently
+            rr.join_group(cid, rank, world, edges)
+    for rr in rs:
         rr.render(scene, gh.orbit_camera(0, ORBIT_FRAMES, W, H, cfg["fx"]))  # uploads the scene, first frame
         rr.set_timing_interval(max(1, args.timing_interval))
-        rs.append(rr)
     r = rs[0]
 
     fbs = links = xchg = None
-    if world > 1:
+    if world > 1 and not in_library:
         dev = "cuda:%d" % local_rank
         if args.exchange == "rgba8":
             fbs = [bands.framebuffer8_tensor(torch, rr, dev) for rr in rs]
@@ -242,7 +256,9 @@ def main():
         rr = rs[c]
         rr.set_camera_arrays(v, p, vp, cfg["fx"], cfg["fx"])
         rr.render_async()
-        if world > 1:
+        if in_library:
+            rr.allgather_frame_async()   # pack -> ncclAllGather -> de-slab on the context's exchange stream, device-ordered
+        elif world > 1:
             # device-side ordering only (no host round trip): the collective and the de-slab on torch's stream overlap the
             # following frames' projection, sort, binning and compositing on the renderers' streams
             if args.exchange == "rgba8":
@@ -395,7 +411,7 @@ def main():
             "config": {"workload": "%s: %d synthetic gaussians (seed %d), %dx%d, 120-pose orbit, full render(scene,camera) "
                                    "= depth key + 17-bit sort + projection + binning + composite"
                                    % (args.config, N, cfg["seed"], W, H),
-                       "early_out_eps": args.early_out_eps, "frames_in_flight": F, "stage_events_every": max(1, args.timing_interval), "emulated_rank": args.emulate_rank, "backend": (args.backend if world > 1 else None), "world_size": world, "parallelism": "tile-column bands x%d%s" % (world, "" if world == 1 else (", %s all-gather, %s edges" % (args.exchange, "equal" if args.equal_bands else "cost-balanced"))),
+                       "early_out_eps": args.early_out_eps, "frames_in_flight": F, "stage_events_every": max(1, args.timing_interval), "emulated_rank": args.emulate_rank, "backend": (args.backend if world > 1 else None), "world_size": world, "parallelism": "tile-column bands x%d%s" % (world, "" if world == 1 else (", %s all-gather %s, %s edges" % (args.exchange, "inside the library (RCCL)" if in_library else "in the harness (gloo rehearsal, host staged)", "equal" if args.equal_bands else "cost-balanced"))),
                        "output": "RGBA f32 premultiplied, left in HBM"},
             "sorted_splats_per_sec": N / ((sm["project_key"] + sm["sort"]) * 1e-3) if (sm["project_key"] + sm["sort"]) > 0 else None,
             "stage_ms": ms,

@@ -5,6 +5,9 @@
 #include "../../include/gsplat_hip.h"
 #include "gsr_internal.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and constants only: the entry points are resolved with dlsym (gsr_comm_*)
+
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -91,6 +94,15 @@ struct gsr_ctx {
     float4* fb = nullptr;
     uint32_t* fb8 = nullptr;
     size_t fb_pixels = 0;
+
+    // multi-GPU exchange (gsr_comm_init): RCCL communicator, its stream, the RGBA8 slab / gathered slabs / full frame
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 0, slab_w = 0;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_packed = nullptr, ev_slab_free = nullptr;
+    uint32_t *slab = nullptr, *gathered = nullptr, *frame8 = nullptr;
+    SlabEdges comm_edges{};
+    bool frame8_valid = false;
 
     CamParams cam{};
     CamParams* cam_dev = nullptr;     // the frame's camera in device memory (k_begin_frame)
@@ -248,6 +260,7 @@ int alloc_fb(gsr_ctx* c)
 }
 
 int finish_frame(gsr_ctx* c);
+void comm_release(gsr_ctx* c);
 int handle_overflow(gsr_ctx* c, uint64_t* newly);
 inline bool overflow_pending(const gsr_ctx* c);
 
@@ -534,6 +547,7 @@ int gsr_destroy(gsr_ctx* c)
     if (!c) return GSR_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    comm_release(c);
     dev_free(&c->px); dev_free(&c->py); dev_free(&c->pz);
     dev_free(&c->cov0); dev_free(&c->cov1); dev_free(&c->cov2); dev_free(&c->rgba);
     dev_free(&c->sh_r); dev_free(&c->sh_g); dev_free(&c->sh_b); dev_free(&c->shcol);
@@ -807,6 +821,7 @@ int gsr_resize(gsr_ctx* c, int32_t w, int32_t h)
     if (w <= 0 || h <= 0 || w > 8192 || h > 8192) return fail(c, GSR_ERR_ARG, "bad framebuffer size %dx%d (1..8192)", w, h);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->comm && (w != c->W || h != c->H)) comm_release(c);   // slabs and band edges belong to the old size: join again
     c->W = w; c->H = h;
     c->band_x0 = c->band_x1 = 0;
     c->have_frame = false;
@@ -855,10 +870,10 @@ int gsr_render_async(gsr_ctx* c)
     return enqueue_frame(c, true);
 }
 
-int gsr_sync(gsr_ctx* c)
+// wait for the context's stream; if frames overflowed, regrow and render the last frame again (when it was one of
+// them); lost frames are added to dropped_unreported, which gsr_sync turns into one GSR_ERR_OVERFLOW
+static int sync_and_repair(gsr_ctx* c)
 {
-    if (!c) return GSR_ERR_ARG;
-    HIP_TRY(c, hipSetDevice(c->device));
     if (int r = finish_frame(c)) return r;
     bool last_ov = false;
     if (c->have_frame && c->ev_render) {
@@ -878,6 +893,15 @@ int gsr_sync(gsr_ctx* c)
         c->dropped_frames += newly;
         c->dropped_unreported += newly;
     }
+    return GSR_OK;
+}
+
+int gsr_sync(gsr_ctx* c)
+{
+    if (!c) return GSR_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (int r = sync_and_repair(c)) return r;
+    if (c->comm_stream) HIP_TRY(c, hipStreamSynchronize(c->comm_stream));   // the frame exchange, if one is in flight
     if (c->dropped_unreported) {
         const unsigned long long k = c->dropped_unreported;
         c->dropped_unreported = 0;
@@ -1111,6 +1135,175 @@ int gsr_device_info(gsr_ctx* c, char* name, int32_t name_len, int32_t* cus, int3
     if (clock_khz) *clock_khz = p.clockRate;
     return GSR_OK;
 }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// Multi-GPU: the framebuffer all-gather of SURVEY 8(e), issued by the library itself.  One process per GPU; every
+// rank renders its band of tile columns and the RGBA8 slabs are exchanged with ONE ncclAllGather over xGMI (RCCL),
+// so the per-frame path needs no Python and no torch: renderer.render(scene, camera) on a Node host returns the full
+// frame.  RCCL is opened at run time (dlopen "librccl.so.1": in a process that already holds one -- a torch build
+// bundles its own -- the loader hands back that copy, so a process never ends up with two), which also keeps
+// libgsplat_hip.so loadable on single-GPU hosts without RCCL installed.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+struct RcclApi {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+    bool ok = false;
+};
+
+RcclApi& rccl()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* h = nullptr;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        if (!h) { api.error = std::string("RCCL is not available: ") + dlerror(); return; }
+        api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+        api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
+        api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
+        api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
+        api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
+        api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather && api.GetErrorString;
+        if (!api.ok) api.error = "librccl.so lacks an expected entry point";
+    });
+    return api;
+}
+
+#define RCCL_TRY(c, expr)                                                                              \
+    do {                                                                                               \
+        ncclResult_t r_ = (expr);                                                                      \
+        if (r_ != ncclSuccess) return fail((c), GSR_ERR_COMM, "%s failed: %s", #expr, rccl().GetErrorString(r_)); \
+    } while (0)
+
+void comm_release(gsr_ctx* c)
+{
+    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
+    if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
+    c->comm = nullptr;
+    if (c->ev_packed) (void)hipEventDestroy(c->ev_packed);
+    if (c->ev_slab_free) (void)hipEventDestroy(c->ev_slab_free);
+    c->ev_packed = c->ev_slab_free = nullptr;
+    if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+    c->comm_stream = nullptr;
+    dev_free(&c->slab); dev_free(&c->gathered); dev_free(&c->frame8);
+    c->comm_world = 0; c->frame8_valid = false;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gsr_comm_unique_id(uint8_t* id)
+{
+    if (!id) return GSR_ERR_ARG;
+    static_assert(GSR_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "the id is passed through as bytes");
+    if (!rccl().ok) return fail(nullptr, GSR_ERR_COMM, "%s", rccl().error.c_str());
+    ncclUniqueId u;
+    const ncclResult_t r = rccl().GetUniqueId(&u);
+    if (r != ncclSuccess) return fail(nullptr, GSR_ERR_COMM, "ncclGetUniqueId failed: %s", rccl().GetErrorString(r));
+    memcpy(id, u.internal, GSR_COMM_ID_BYTES);
+    return GSR_OK;
+}
+
+int gsr_comm_init(gsr_ctx* c, const uint8_t* id, int32_t rank, int32_t world, const int32_t* x0, const int32_t* x1)
+{
+    if (!c) return GSR_ERR_ARG;
+    if (!id || !x0 || !x1 || world < 1 || world > MAX_SLABS || rank < 0 || rank >= world)
+        return fail(c, GSR_ERR_ARG, "gsr_comm_init: bad argument (1 <= world <= %d, 0 <= rank < world)", MAX_SLABS);
+    if (!c->W || !c->H) return fail(c, GSR_ERR_ARG, "gsr_comm_init: set the framebuffer size first");
+    if (!rccl().ok) return fail(c, GSR_ERR_COMM, "%s", rccl().error.c_str());
+    int sw = BIN_PX;
+    for (int q = 0; q < world; q++) {
+        // every rank must hold the same edges: whole 32-px bin columns, contiguous, covering the image
+        const int want0 = q ? x1[q - 1] : 0;
+        if (x0[q] != want0 || x1[q] <= x0[q] || x0[q] % BIN_PX || (x1[q] % BIN_PX && x1[q] != c->W) || x1[q] > c->W)
+            return fail(c, GSR_ERR_ARG, "gsr_comm_init: band %d = [%d,%d) (bands are contiguous runs of whole %d-px columns)", q, x0[q], x1[q], BIN_PX);
+        sw = std::max(sw, x1[q] - x0[q]);
+    }
+    if (x1[world - 1] != c->W) return fail(c, GSR_ERR_ARG, "gsr_comm_init: the bands end at %d, the image is %d wide", x1[world - 1], c->W);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    comm_release(c);
+    if (int r = gsr_set_band(c, world == 1 ? 0 : x0[rank], world == 1 ? 0 : x1[rank])) return r;
+    c->slab_w = sw;
+    for (int q = 0; q < world; q++) { c->comm_edges.x0[q] = x0[q]; c->comm_edges.x1[q] = x1[q]; }
+    const size_t slab_px = (size_t)sw * c->H;
+    int r;
+    if ((r = dev_alloc(c, &c->slab, slab_px)) || (r = dev_alloc(c, &c->gathered, slab_px * world)) ||
+        (r = dev_alloc(c, &c->frame8, (size_t)c->W * c->H)))
+        return r;
+    HIP_TRY(c, hipMemsetAsync(c->slab, 0, slab_px * 4, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_slab_free, hipEventDisableTiming));
+    ncclUniqueId u;
+    memcpy(u.internal, id, GSR_COMM_ID_BYTES);
+    RCCL_TRY(c, rccl().CommInitRank(&c->comm, world, u, rank));   // collective: returns when every rank has joined
+    c->comm_rank = rank; c->comm_world = world;
+    return GSR_OK;
+}
+
+int gsr_comm_destroy(gsr_ctx* c)
+{
+    if (!c) return GSR_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    comm_release(c);
+    return GSR_OK;
+}
+
+int gsr_allgather_frame_async(gsr_ctx* c)
+{
+    if (!c) return GSR_ERR_ARG;
+    if (!c->comm) return fail(c, GSR_ERR_ARG, "gsr_allgather_frame_async: gsr_comm_init has not been called");
+    if (!c->have_frame) return fail(c, GSR_ERR_ARG, "gsr_allgather_frame_async: nothing rendered yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    // never ship a band the compositor did not draw: if the device has reported a list overflow, regrow and render
+    // the frame again first (lost earlier frames stay counted and are reported by the next gsr_sync)
+    if (overflow_pending(c)) { if (int r = sync_and_repair(c)) return r; }
+    const BinGrid g = make_grid(c);
+    const int x0 = g.bx_lo * BIN_PX, x1 = std::min(g.bx_hi * BIN_PX, c->W);
+    // render stream: the previous all-gather must have read the slab before it is overwritten; then pack the band
+    if (c->frame8_valid) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_slab_free, 0));
+    launch_pack_band_rgba8(c->fb, c->slab, c->W, c->H, x0, x1, c->slab_w, c->stream);
+    HIP_TRY(c, hipEventRecord(c->ev_packed, c->stream));
+    // exchange stream: collective + de-slab, overlapping the next frame's kernels on the render stream
+    HIP_TRY(c, hipStreamWaitEvent(c->comm_stream, c->ev_packed, 0));
+    RCCL_TRY(c, rccl().AllGather(c->slab, c->gathered, (size_t)c->slab_w * c->H * 4, ncclUint8, c->comm, c->comm_stream));
+    HIP_TRY(c, hipEventRecord(c->ev_slab_free, c->comm_stream));
+    launch_unpack_slabs_rgba8(c->gathered, c->frame8, c->W, c->H, c->slab_w, c->comm_world, c->comm_edges, c->comm_stream);
+    HIP_TRY(c, hipGetLastError());
+    c->frame8_valid = true;
+    return GSR_OK;
+}
+
+int gsr_read_frame_rgba8(gsr_ctx* c, uint8_t* out)
+{
+    if (!c || !out) return c ? fail(c, GSR_ERR_ARG, "out is NULL") : GSR_ERR_ARG;
+    if (!c->frame8_valid) return fail(c, GSR_ERR_ARG, "gsr_read_frame_rgba8: no gathered frame yet (gsr_allgather_frame_async)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(out, c->frame8, (size_t)c->W * c->H * 4, hipMemcpyDeviceToHost, c->comm_stream));
+    HIP_TRY(c, hipStreamSynchronize(c->comm_stream));
+    return GSR_OK;
+}
+
+void* gsr_frame8_device_ptr(gsr_ctx* c) { return c ? (void*)c->frame8 : nullptr; }
+void* gsr_comm_stream_handle(gsr_ctx* c) { return c ? (void*)c->comm_stream : nullptr; }
+
+}  // extern "C"
+
+extern "C" {
 
 // ---- wasm `sort` drop-in (wasm/wasm.cpp:8-13; call site Worker.ts:39) ----
 // Like the wasm export it keeps nothing of the caller's between calls: the positions are copied to the device on

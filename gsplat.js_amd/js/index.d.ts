@@ -102,7 +102,18 @@ export class HIPRenderer {
     render(scene: Scene, camera: Camera): void;
     /** enqueue the frame and return; pair with sync() (several `throughput` renderers used round-robin keep the GPU full) */
     renderAsync(scene: Scene, camera: Camera): void;
+    /** waits for the enqueued frames; throws once if asynchronous frames were lost to a list overflow (the renderer stays usable) */
     sync(): void;
+    overflowPending(): boolean;
+    setListCapacity(entries: number): void;
+    /** multi-GPU, one process per GPU. Collective: same id (createGroupId() on rank 0), world and edges on every rank.
+     *  Afterwards render() draws this rank's tile-column band and all-gathers the RGBA8 frame over xGMI inside the
+     *  library (RCCL); readPixels() returns the whole frame on every rank. */
+    joinGroup(group: { id: Uint8Array; rank: number; world: number; edges: Array<[number, number]> }): void;
+    leaveGroup(): void;
+    group(): { rank: number; world: number } | null;
+    static createGroupId(): Uint8Array;
+    static bandEdges(width: number, world: number): Array<[number, number]>;
     sort(camera?: Camera): void;
     setSize(width: number, height: number): void;
     resize(): void;
@@ -133,7 +144,7 @@ export class Loader {
     static LoadSync(file: string, scene: Scene): Scene;
 }
 export class PLYLoader {
-    /** format: "" | "polycam"; useShs: also read the 45 f_rest_* floats; quantized PLY is not supported */
+    /** format: "" | "polycam"; useShs: also read the 45 f_rest_* floats; quantized (with useShs): the codebook variant */
     static LoadAsync(file: string, scene: Scene, onProgress?: (p: number, done?: boolean) => void, format?: string,
                      useShs?: boolean, quantized?: boolean): Promise<Scene>;
     static LoadFromFileAsync(file: string, scene: Scene, onProgress?: (p: number, done?: boolean) => void, format?: string,

@@ -69,54 +69,57 @@ class PLYLoader {
         rot[0] = n.w * 128 + 128; rot[1] = n.x * 128 + 128; rot[2] = n.y * 128 + 128; rot[3] = n.z * 128 + 128;
     }
 
-    // PLYLoader.ts:389-538
+    // Rows only (what PLYLoader.ts:389-538 produces).  The header is compiled once into a list of field writers --
+    // (byte offset, reader for the property's type, destination field, slot, value transform) for every property the
+    // .splat row has a use for, in FILE order, which is what decides the outcome when two properties feed one byte
+    // (red and f_dc_0, opacity and f_dc_3) -- and the vertex loop just runs that list.  Byte fields go through
+    // Uint8ClampedArray stores (round half to even, clamp), floats through Float32Array stores.
+    static _rowWriters(properties) {
+        const ident = (v) => v, dcToByte = (v) => (0.5 + SH_C0 * v) * 255;
+        const POS = 0, SCALE = 1, RGBA = 2, QUAT = 3;
+        const families = [   // name pattern -> destination field, transform; the slot is the axis letter or trailing digit
+            [/^[xyz]$/, POS, ident], [/^scale_[012]$/, SCALE, Math.exp], [/^rot_[0123]$/, QUAT, ident],
+            [/^f_dc_[0123]$/, RGBA, dcToByte],
+        ];
+        const singles = { red: [RGBA, 0, ident], green: [RGBA, 1, ident], blue: [RGBA, 2, ident],
+                          opacity: [RGBA, 3, (v) => (1 / (1 + Math.exp(-v))) * 255] };
+        const readers = { float: DataView.prototype.getFloat32, int: DataView.prototype.getInt32 };
+        const writers = [];
+        for (const p of properties) {
+            if (!readers[p.type]) throw new Error("Unsupported property type: " + p.type);
+            let target = singles.hasOwnProperty(p.name) ? singles[p.name] : null;
+            for (let k = 0; !target && k < families.length; k++) {
+                if (!families[k][0].test(p.name)) continue;
+                const last = p.name[p.name.length - 1];
+                target = [families[k][1], last >= "x" ? last.charCodeAt(0) - 120 : Number(last), families[k][2]];
+            }
+            if (target) writers.push({ offset: p.offset, read: readers[p.type], field: target[0], slot: target[1], xf: target[2] });
+        }
+        return writers;
+    }
+
     static _parseRows(ab, format) {
         if (format !== "" && format !== "polycam") throw new Error("Unsupported format: " + format);
         const h = PLYLoader._parseHeader(ab);
+        const writers = PLYLoader._rowWriters(h.properties);
         const view = new DataView(ab, h.size);
         const out = new ArrayBuffer(Scene.RowLength * h.vertexCount);
-        const qPolycam = Quaternion.FromEuler(new Vector3(Math.PI / 2, 0, 0));
+        const polycam = format === "polycam" ? Quaternion.FromEuler(new Vector3(Math.PI / 2, 0, 0)) : null;
+        const quat = new Float64Array(4);   // rot_0..rot_3 = (w, x, y, z)
         for (let i = 0; i < h.vertexCount; i++) {
-            const position = new Float32Array(out, i * Scene.RowLength, 3);
-            const scale = new Float32Array(out, i * Scene.RowLength + 12, 3);
-            const rgba = new Uint8ClampedArray(out, i * Scene.RowLength + 24, 4);
-            const rot = new Uint8ClampedArray(out, i * Scene.RowLength + 28, 4);
-            let r0 = 255, r1 = 0, r2 = 0, r3 = 0;
-            for (const p of h.properties) {
-                let v;
-                if (p.type === "float") v = view.getFloat32(p.offset + i * h.rowOffset, true);
-                else if (p.type === "int") v = view.getInt32(p.offset + i * h.rowOffset, true);
-                else throw new Error("Unsupported property type: " + p.type);
-                switch (p.name) {
-                    case "x": position[0] = v; break;
-                    case "y": position[1] = v; break;
-                    case "z": position[2] = v; break;
-                    case "scale_0": scale[0] = Math.exp(v); break;
-                    case "scale_1": scale[1] = Math.exp(v); break;
-                    case "scale_2": scale[2] = Math.exp(v); break;
-                    case "red": rgba[0] = v; break;
-                    case "green": rgba[1] = v; break;
-                    case "blue": rgba[2] = v; break;
-                    case "f_dc_0": rgba[0] = (0.5 + SH_C0 * v) * 255; break;
-                    case "f_dc_1": rgba[1] = (0.5 + SH_C0 * v) * 255; break;
-                    case "f_dc_2": rgba[2] = (0.5 + SH_C0 * v) * 255; break;
-                    case "f_dc_3": rgba[3] = (0.5 + SH_C0 * v) * 255; break;
-                    case "opacity": rgba[3] = (1 / (1 + Math.exp(-v))) * 255; break;
-                    case "rot_0": r0 = v; break;
-                    case "rot_1": r1 = v; break;
-                    case "rot_2": r2 = v; break;
-                    case "rot_3": r3 = v; break;
-                    default: break;
-                }
-            }
-            let q = new Quaternion(r1, r2, r3, r0);
-            if (format === "polycam") {
-                const t = position[1];
+            const base = i * Scene.RowLength;
+            const position = new Float32Array(out, base, 3);
+            const fields = [position, new Float32Array(out, base + 12, 3), new Uint8ClampedArray(out, base + 24, 4), quat];
+            quat[0] = 255; quat[1] = quat[2] = quat[3] = 0;   // a file without rot_* gets these (:443)
+            for (const w of writers) fields[w.field][w.slot] = w.xf(w.read.call(view, w.offset + i * h.rowOffset, true));
+            let q = new Quaternion(quat[1], quat[2], quat[3], quat[0]);
+            if (polycam) {   // y/z swap and a quarter turn about x (:513-520)
+                const y = position[1];
                 position[1] = -position[2];
-                position[2] = t;
-                q = qPolycam.multiply(q);
+                position[2] = y;
+                q = polycam.multiply(q);
             }
-            PLYLoader._writeRotation(rot, q);
+            PLYLoader._writeRotation(new Uint8ClampedArray(out, base + 28, 4), q);
         }
         return out;
     }

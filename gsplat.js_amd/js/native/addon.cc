@@ -387,6 +387,56 @@ napi_value SetListCapacity(napi_env env, napi_callback_info info)
     return rc ? throw_gsr(env, c, rc, "gsr_set_list_capacity") : undefined(env);
 }
 
+// commUniqueId() -> Uint8Array(128): rank 0 makes it, the host hands it to the other ranks
+napi_value CommUniqueId(napi_env env, napi_callback_info)
+{
+    uint8_t id[GSR_COMM_ID_BYTES];
+    const int rc = gsr_comm_unique_id(id);
+    if (rc) return throw_gsr(env, nullptr, rc, "gsr_comm_unique_id");
+    napi_value ab, out;
+    void* data = nullptr;
+    NAPI_OK_OR_NULL(env, napi_create_arraybuffer(env, GSR_COMM_ID_BYTES, &data, &ab));
+    memcpy(data, id, GSR_COMM_ID_BYTES);
+    NAPI_OK_OR_NULL(env, napi_create_typedarray(env, napi_uint8_array, GSR_COMM_ID_BYTES, ab, 0, &out));
+    return out;
+}
+
+// commInit(handle, Uint8Array id, rank, world, Int32Array x0, Int32Array x1): collective
+napi_value CommInit(napi_env env, napi_callback_info info)
+{
+    napi_value argv[6];
+    if (!get_args(env, info, 6, argv)) return nullptr;
+    gsr_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return nullptr;
+    void *id, *x0, *x1;
+    size_t nid, n0, n1;
+    int32_t rank, world;
+    if (!get_typed(env, argv[1], napi_uint8_array, &id, &nid) || !get_i32(env, argv[2], &rank) || !get_i32(env, argv[3], &world) ||
+        !get_typed(env, argv[4], napi_int32_array, &x0, &n0) || !get_typed(env, argv[5], napi_int32_array, &x1, &n1))
+        return nullptr;
+    if (nid < GSR_COMM_ID_BYTES || world < 1 || n0 < (size_t)world || n1 < (size_t)world) {
+        napi_throw_range_error(env, nullptr, "commInit: id needs 128 bytes, x0/x1 one entry per rank");
+        return nullptr;
+    }
+    const int rc = gsr_comm_init(c, (const uint8_t*)id, rank, world, (const int32_t*)x0, (const int32_t*)x1);
+    return rc ? throw_gsr(env, c, rc, "gsr_comm_init") : undefined(env);
+}
+
+// readFrame(handle, Uint8Array out, width, height): the gathered RGBA8 frame
+napi_value ReadFrame(napi_env env, napi_callback_info info)
+{
+    napi_value argv[4];
+    if (!get_args(env, info, 4, argv)) return nullptr;
+    gsr_ctx* c = get_ctx(env, argv[0]);
+    void* out;
+    size_t len;
+    int32_t w, h;
+    if (!c || !get_typed(env, argv[1], napi_uint8_array, &out, &len) || !get_i32(env, argv[2], &w) || !get_i32(env, argv[3], &h)) return nullptr;
+    if (len < (size_t)w * h * 4) { napi_throw_range_error(env, nullptr, "output array is smaller than width*height*4"); return nullptr; }
+    const int rc = gsr_read_frame_rgba8(c, (uint8_t*)out);
+    return rc ? throw_gsr(env, c, rc, "gsr_read_frame_rgba8") : undefined(env);
+}
+
 napi_value BuildId(napi_env env, napi_callback_info)
 {
     napi_value s;
@@ -445,7 +495,8 @@ napi_value Init(napi_env env, napi_value exports)
         {"renderAsync", Call0<gsr_render_async>}, {"sync", Call0<gsr_sync>}, {"resetTimings", Call0<gsr_reset_timings>},
         {"readDepthIndex", ReadDepthIndex}, {"readPixels", ReadPixels}, {"getTimings", GetTimings},
         {"deviceInfo", DeviceInfo}, {"sortHost", SortHost}, {"overflowPending", OverflowPending},
-        {"setListCapacity", SetListCapacity}, {"buildId", BuildId},
+        {"setListCapacity", SetListCapacity}, {"buildId", BuildId}, {"commUniqueId", CommUniqueId}, {"commInit", CommInit},
+        {"commDestroy", Call0<gsr_comm_destroy>}, {"allgatherFrameAsync", Call0<gsr_allgather_frame_async>}, {"readFrame", ReadFrame},
     };
     for (auto& f : fns) {
         napi_value fn;

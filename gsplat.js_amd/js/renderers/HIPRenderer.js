@@ -75,6 +75,22 @@ class HIPRenderer {
             this._n.setSceneSh(this._h, t[0], t[1], t[2], activeScene.vertexCount - (band[0] + 1), band);
         };
 
+        // ---- multi-GPU (one process per GPU): joinGroup() is collective -- every rank calls it with the same id
+        // (HIPRenderer.createGroupId() on rank 0, passed on by the host: a file, a socket, an env var), its rank, the
+        // world size and the same band edges [[x0, x1], ...] (contiguous runs of whole 32-px columns covering the
+        // width; HIPRenderer.bandEdges(width, world) gives equal ones).  After that render(scene, camera) draws this
+        // rank's band and all-gathers the RGBA8 slabs over xGMI (RCCL) inside the library, and readPixels() returns the
+        // whole frame on every rank.
+        let group = null;
+        this.joinGroup = (g) => {
+            const x0 = new Int32Array(g.world), x1 = new Int32Array(g.world);
+            for (let q = 0; q < g.world; q++) { x0[q] = g.edges[q][0]; x1[q] = g.edges[q][1]; }
+            this._n.commInit(this._h, g.id, g.rank, g.world, x0, x1);
+            group = { rank: g.rank, world: g.world };
+        };
+        this.leaveGroup = () => { this._n.commDestroy(this._h); group = null; };
+        this.group = () => group;
+
         // WebGLRenderer.ts:241-296
         this.render = (scene, camera) => {
             activeCamera = camera;
@@ -86,7 +102,12 @@ class HIPRenderer {
             }
             pushCamera();
             for (const p of passes) p.render();
-            this._n.render(this._h);
+            if (group) {   // band frame + framebuffer all-gather, ordered on the device; readPixels() waits for it
+                this._n.renderAsync(this._h);
+                this._n.allgatherFrameAsync(this._h);
+            } else {
+                this._n.render(this._h);
+            }
         };
         // Frames in flight (no counterpart in the reference, whose render() is one synchronous draw): renderAsync()
         // enqueues the frame and returns; sync() waits for it.  Several renderers created with { throughput: true }
@@ -102,6 +123,7 @@ class HIPRenderer {
             pushCamera();
             for (const p of passes) p.render();
             this._n.renderAsync(this._h);
+            if (group) this._n.allgatherFrameAsync(this._h);
         };
         // sync() throws once (code GSPLAT_HIP, "... frame(s) were not composited") when asynchronous frames were lost
         // to a list overflow; the renderer stays usable and the last frame has been rendered again.
@@ -148,13 +170,26 @@ class HIPRenderer {
 
         // ---- results ----
         this.lastDepthIndex = () => { const a = new Uint32Array(vertexCount); this._n.readDepthIndex(this._h, a); return a; };
-        this.readPixels = () => { const a = new Uint8Array(this.width * this.height * 4); this._n.readPixels(this._h, a, this.width, this.height); return a; };
+        this.readPixels = () => {
+            const a = new Uint8Array(this.width * this.height * 4);
+            if (group) this._n.readFrame(this._h, a, this.width, this.height);   // the gathered frame of all ranks
+            else this._n.readPixels(this._h, a, this.width, this.height);
+            return a;
+        };
         this.readPixelsFloat = () => { const a = new Float32Array(this.width * this.height * 4); this._n.readPixels(this._h, a, this.width, this.height); return a; };
         this.stats = () => this._n.getTimings(this._h);
         this.deviceInfo = () => this._n.deviceInfo(this._h);
         this.isInitialized = () => initialized;
     }
 }
+
+HIPRenderer.createGroupId = () => loadNative().commUniqueId();
+// equal bands of whole 32-px compositor columns, the tail clipped to the image (same rule as gsplat_hip.bands.band_edges)
+HIPRenderer.bandEdges = (width, world) => {
+    const nbx = Math.ceil(width / 32), per = Math.ceil(nbx / world), e = [];
+    for (let q = 0; q < world; q++) e.push([Math.min(q * per * 32, width), Math.min((q + 1) * per * 32, width)]);
+    return e;
+};
 
 // the wasm export's drop-in (wasm/wasm.cpp:8-13, call site Worker.ts:39)
 function sortHost(viewProj, vertexCount, fBuffer, depthBuffer, depthIndex) {

@@ -63,7 +63,10 @@ EXPORTS = [
     "gsr_pack_band_rgba8_async", "gsr_unpack_slabs_rgba8_async",
     "gsr_framebuffer_device_ptr", "gsr_stream_handle", "gsr_stream_order", "gsr_device_info", "gsplat_sort_host",
     "gsr_overflow_pending", "gsr_set_list_capacity", "gsr_scene_count", "gsr_build_id",
+    "gsr_comm_unique_id", "gsr_comm_init", "gsr_comm_destroy", "gsr_allgather_frame_async", "gsr_read_frame_rgba8",
+    "gsr_frame8_device_ptr", "gsr_comm_stream_handle",
 ]
+GSR_COMM_ID_BYTES = 128
 
 
 def _assert_one_hip_runtime():
@@ -148,6 +151,15 @@ def load_library(path=None):
     L.gsr_scene_count.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32)]
     L.gsr_build_id.argtypes = []
     L.gsr_build_id.restype = ctypes.c_char_p
+    L.gsr_comm_unique_id.argtypes = [vp]
+    L.gsr_comm_init.argtypes = [vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+    L.gsr_comm_destroy.argtypes = [vp]
+    L.gsr_allgather_frame_async.argtypes = [vp]
+    L.gsr_read_frame_rgba8.argtypes = [vp, vp]
+    L.gsr_frame8_device_ptr.argtypes = [vp]
+    L.gsr_frame8_device_ptr.restype = vp
+    L.gsr_comm_stream_handle.argtypes = [vp]
+    L.gsr_comm_stream_handle.restype = vp
     for name in EXPORTS:
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int and name not in ("gsplat_sort_host",):
@@ -502,6 +514,39 @@ class HIPRenderer:
 
     def stream_handle(self):
         return self._L.gsr_stream_handle(self._ctx)
+
+    # -- multi-GPU frame exchange inside the library (RCCL all-gather; see include/gsplat_hip.h) --
+    def join_group(self, comm_id, rank, world, edges):
+        """Collective: every rank calls it with the same 128-byte id (new_group_id() on rank 0, handed round by the
+        host) and the same band edges [(x0, x1)] per rank.  Afterwards render_async() + allgather_frame_async()
+        leave the whole RGBA8 frame on every rank (read_frame())."""
+        cid = (ctypes.c_uint8 * GSR_COMM_ID_BYTES).from_buffer_copy(bytes(comm_id))
+        x0, x1 = edge_arrays(edges)
+        self._check(self._L.gsr_comm_init(self._ctx, cid, rank, world, x0, x1))
+
+    def leave_group(self):
+        self._check(self._L.gsr_comm_destroy(self._ctx))
+
+    def allgather_frame_async(self):
+        self._check(self._L.gsr_allgather_frame_async(self._ctx))
+
+    def read_frame(self):
+        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        self._check(self._L.gsr_read_frame_rgba8(self._ctx, out.ctypes.data))
+        return out
+
+    def frame8_ptr(self):
+        return self._L.gsr_frame8_device_ptr(self._ctx)
+
+
+def new_group_id():
+    """128 bytes identifying a new RCCL communicator (rank 0 creates it; the host distributes it)."""
+    buf = (ctypes.c_uint8 * GSR_COMM_ID_BYTES)()
+    L = load_library()
+    rc = L.gsr_comm_unique_id(buf)
+    if rc:
+        raise GsplatError("gsr_comm_unique_id failed (%d): %s" % (rc, L.gsr_last_error(None).decode()))
+    return bytes(buf)
 
 
 def build_id():

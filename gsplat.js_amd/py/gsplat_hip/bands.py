@@ -129,6 +129,14 @@ class FrameExchange:
             from . import edge_arrays
             self._edge_arrays = edge_arrays(self.edges)
             self._ptrs = (self.slab.data_ptr(), self._flat.data_ptr(), self.full.data_ptr())
+        if renderer.overflow_pending():
+            # never ship a band the compositor did not draw (a frame whose lists did not fit publishes no work):
+            # sync regrows the lists and renders the frame again; frames lost earlier stay counted in stats()
+            try:
+                renderer.sync()
+            except Exception as e:
+                if "not composited" not in str(e):
+                    raise
         if self._exchanged:
             link.renderer_waits_for_torch()      # the previous collective (and de-slab) has read the slab
         self._exchanged = True

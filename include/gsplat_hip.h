@@ -42,7 +42,8 @@ extern "C" {
 #define GSR_ERR_HIP (-2)      /* a HIP runtime call failed */
 #define GSR_ERR_NO_DEVICE (-3)/* no usable AMD GPU */
 #define GSR_ERR_SCENE (-4)    /* scene buffers inconsistent */
-#define GSR_ERR_OVERFLOW (-5) /* internal list capacity exceeded even after regrowth */
+#define GSR_ERR_OVERFLOW (-5) /* internal list capacity exceeded even after regrowth; or: asynchronous frames were lost (gsr_sync) */
+#define GSR_ERR_COMM (-6)     /* RCCL is unavailable or a collective call failed */
 
 typedef struct gsr_ctx gsr_ctx;
 
@@ -188,6 +189,29 @@ int gsr_pack_band_rgba8_async(gsr_ctx *ctx, void *slab, int32_t slab_width_px);
  * the collective was issued on, e.g. torch's current stream), device = the context's.  world <= 16. */
 int gsr_unpack_slabs_rgba8_async(gsr_ctx *ctx, const void *gathered, void *image, int32_t slab_width_px, int32_t world,
                                  const int32_t *x0, const int32_t *x1, void *stream);
+
+/* ---- multi-GPU frame exchange inside the library: RCCL all-gather over xGMI ----
+ * One process per GPU, one context per process (or per frame in flight).  Rank 0 makes an id and hands its 128 bytes
+ * to the other ranks by whatever the host has (a file, a socket, a torch/gloo broadcast); then EVERY rank calls
+ * gsr_comm_init with the same id, world and band edges (x0[q], x1[q]) = pixel columns of rank q: contiguous, whole
+ * 32-px bin columns, covering [0, width).  gsr_comm_init is collective (returns when all ranks have joined), sets this
+ * context's band to its own columns and allocates the exchange buffers.  Per frame:
+ *     gsr_render_async(ctx);            band: project all, sort/bin/composite the band's splats
+ *     gsr_allgather_frame_async(ctx);   band -> RGBA8 slab (render stream), ONE ncclAllGather of equal slabs + one
+ *                                       de-slab kernel on the context's exchange stream; device-side ordering only,
+ *                                       so the next frame's kernels overlap the collective
+ * and every rank holds the whole RGBA8 frame: gsr_read_frame_rgba8 (waits for the exchange, copies to the host) or
+ * gsr_frame8_device_ptr.  The replaced reference entry is still renderer.render(scene, camera)
+ * (src/renderers/WebGLRenderer.ts:241-296): the JS HIPRenderer calls exactly this sequence when it has joined a group.
+ * world == 1 is allowed (self test; the band is the whole image). */
+#define GSR_COMM_ID_BYTES 128
+int gsr_comm_unique_id(uint8_t *id /* GSR_COMM_ID_BYTES */);
+int gsr_comm_init(gsr_ctx *ctx, const uint8_t *id, int32_t rank, int32_t world, const int32_t *x0, const int32_t *x1);
+int gsr_comm_destroy(gsr_ctx *ctx);
+int gsr_allgather_frame_async(gsr_ctx *ctx);
+int gsr_read_frame_rgba8(gsr_ctx *ctx, uint8_t *out /* w*h*4: the gathered frame */);
+void *gsr_frame8_device_ptr(gsr_ctx *ctx);    /* uint8[h][w][4], the gathered frame on the device */
+void *gsr_comm_stream_handle(gsr_ctx *ctx);   /* hipStream_t the exchange runs on */
 
 /* ---- device interop (torch / RCCL plumbing in the harness) ---- */
 void *gsr_framebuffer_device_ptr(gsr_ctx *ctx); /* float4[h][w] on the device */

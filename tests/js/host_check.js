@@ -104,6 +104,42 @@ if (mode === "pack") {                     // pack <splat> <outprefix> <W> <H> <
     for (let slot = 0; slot < 3; slot++) check(slot);
     fs.writeFileSync(out + ".json", JSON.stringify({ same, frames }));
     rs.forEach((r) => r.dispose()); ref.dispose();
+} else if (mode === "group") {
+    // group <splat> <outprefix> <W> <H> <fx> <rank> <world> <idfile>: renderer.render(scene, camera) with the framebuffer
+    // all-gather inside the library (RCCL).  Rank 0 writes the communicator id to <idfile>, the others wait for it: the id
+    // travels by whatever the host has.  world 1 = the self test the one-GPU box can run; on a multi-GPU node start one
+    // process per rank with HIP_VISIBLE_DEVICES=<rank> (or { device: rank }).
+    const [file, out, W, H, fx, rank, world, idfile] = a;
+    const scene = new G.Scene();
+    G.Loader.LoadSync(file, scene);
+    let id;
+    if (+rank === 0) {
+        id = G.WebGLRenderer.createGroupId();
+        fs.writeFileSync(idfile + ".tmp", Buffer.from(id));
+        fs.renameSync(idfile + ".tmp", idfile);
+    } else {
+        const t0 = Date.now();
+        while (!fs.existsSync(idfile)) { if (Date.now() - t0 > 60000) throw new Error("no communicator id after 60 s"); }
+        id = new Uint8Array(fs.readFileSync(idfile));
+    }
+    const r = new G.WebGLRenderer({ width: +W, height: +H, device: +world > 1 ? +rank : 0 }, []);
+    r.joinGroup({ id: id, rank: +rank, world: +world, edges: G.WebGLRenderer.bandEdges(+W, +world) });
+    const ref = +rank === 0 ? new G.WebGLRenderer({ width: +W, height: +H }, []) : null;
+    let worst = 0;
+    for (const pose of [3, 47, 91]) {
+        const cam = orbitCamera(pose, 120, +fx);
+        r.render(scene, cam);
+        const got = r.readPixels();
+        if (ref) {
+            ref.render(scene, cam);
+            const want = ref.readPixels();
+            for (let i = 0; i < want.length; i++) worst = Math.max(worst, Math.abs(got[i] - want[i]));
+        }
+    }
+    if (ref) fs.writeFileSync(out + ".json", JSON.stringify({ worst: worst, world: +world, group: r.group() }));
+    r.leaveGroup();
+    r.dispose();
+    if (ref) ref.dispose();
 } else if (mode === "renderfade") {       // renderfade <splat> <outprefix> <W> <H> <fx> <pose> <frames>: default passes = [FadeInPass]
     const [file, out, W, H, fx, pose, frames] = a;
     const scene = new G.Scene();

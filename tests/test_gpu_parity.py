@@ -800,3 +800,39 @@ def test_limit_box_clears_sh_state(gh):
     with pytest.raises(gh.GsplatError):
         r.read_sh_colors()                      # no SH state any more: the scene renders with its rgba8 colours
     r.dispose()
+
+
+def test_rccl_allgather_inside_the_library_single_rank(gh, scenes):
+    """The product's multi-GPU exchange (gsr_comm_init / gsr_allgather_frame_async): pack -> ncclAllGather -> de-slab on
+    the library's own streams.  A one-GPU box can form a communicator of ONE rank (RCCL refuses two ranks on one
+    device); that still runs every call of the path, the stream/event ordering with frames enqueued back to back, and
+    the id hand-over.  The gathered RGBA8 frame must equal the plain renderer's RGBA8 image byte for byte."""
+    cfg = gh.synth.CONFIGS["C1"]
+    rows, data, pos = scenes("C1")
+    W, H = cfg["width"], cfg["height"]
+    ref = gh.HIPRenderer(W, H)
+    ref.set_raw_scene(data, pos)
+    r = gh.HIPRenderer(W, H)
+    r.set_raw_scene(data, pos)
+    with pytest.raises(gh.GsplatError):
+        r.allgather_frame_async()                           # not in a group yet
+    with pytest.raises(gh.GsplatError):
+        r.join_group(gh.new_group_id(), 0, 1, [(0, W - 32)])   # edges must cover the image
+    r.join_group(gh.new_group_id(), 0, 1, [(0, W)])
+    cams = [_camera(gh, k, cfg) for k in (5, 41, 77, 113)]
+    for cam in cams:                                        # back to back: the next frame must not overtake the exchange
+        r.set_camera(cam)
+        r.render_async()
+        r.allgather_frame_async()
+    got = r.read_frame()
+    ref.set_camera(cams[-1])
+    ref.render_async(); ref.sync()
+    assert np.array_equal(got, ref.readPixels())
+    r.sync()
+    r.leave_group()
+    r.set_camera(cams[0])
+    r.render_async(); r.sync()                              # usable as a plain renderer again
+    ref.set_camera(cams[0])
+    ref.render_async(); ref.sync()
+    assert np.array_equal(r.readPixels(), ref.readPixels())
+    r.dispose(); ref.dispose()

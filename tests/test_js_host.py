@@ -201,6 +201,21 @@ def test_js_frames_in_flight(tmp_path):
 
 
 @pytest.mark.gpu
+def test_js_render_with_in_library_allgather(tmp_path):
+    # renderer.render(scene, camera) on a renderer that has joined a group: band frame + RCCL all-gather of the RGBA8
+    # slabs inside the library, no torch anywhere in the process.  One rank is what a one-GPU box can run; the gathered
+    # frame must be the plain renderer's frame (same kernels, RGBA8 conversion in the pack kernel instead of k_to_rgba8).
+    import gsplat_hip as gh
+    cfg = gh.synth.CONFIGS["C1"]
+    f = tmp_path / "c1.splat"
+    gh.synth.config_rows("C1").tofile(f)
+    out = str(tmp_path / "g")
+    run("group", f, out, cfg["width"], cfg["height"], cfg["fx"], 0, 1, tmp_path / "comm.id")
+    got = json.load(open(out + ".json"))
+    assert got["worst"] == 0 and got["world"] == 1 and got["group"] == {"rank": 0, "world": 1}
+
+
+@pytest.mark.gpu
 def test_js_render_matches_oracle(tmp_path, oracle):
     import gsplat_hip as gh
     cfg = gh.synth.CONFIGS["C1"]
