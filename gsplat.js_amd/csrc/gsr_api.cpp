@@ -42,6 +42,7 @@ struct FrameState {  // small per-frame device words, reset by k_begin_frame (mi
 
 struct gsr_ctx {
     int device = 0;
+    int cu_count = 256;               // compute units of the device (the compositor's persistent grid is sized from it)
     hipStream_t stream = nullptr;
     std::string error;
     gsr_options opt{};
@@ -188,8 +189,13 @@ constexpr uint32_t SEG_LEN_MIN = 512;            // shortest segment; k_bin_fina
 constexpr uint32_t SEG_TARGET_EXACT = 5000;      // one frame at a time: concurrency from the frame's own segments (C3: 512)
 constexpr uint32_t SEG_TARGET_THROUGHPUT = 1300; // GSR_FLAG_THROUGHPUT: concurrency comes from the other frames in flight
                                                  // (C3: 2048-entry segments; a 1/8-screen band stays at 512)
-constexpr uint32_t BLEND_GRID_EXACT = 2048;      // persistent compositor workgroups (8 per CU requested, 7 resident)
-constexpr uint32_t BLEND_GRID_THROUGHPUT = 1536; // 6 per CU: leaves room for the other contexts' kernels
+// Persistent compositor workgroups per CU.  k_blend is built for 7 waves per SIMD (72 VGPRs), so 7 four-wave
+// workgroups are resident per CU and the grid must not exceed that: a workgroup that is not resident at launch still
+// owns its first work item by index (a heavy one: the queue is ordered heaviest first) and starts it only when a
+// resident workgroup exits.  With 8 per CU, one item in eight began at 222 us of a 270 us kernel (in-kernel stamps,
+// scripts/blend_stamps.py): k_blend 271 -> 252 us on C3 at 7 per CU.
+constexpr uint32_t BLEND_WG_PER_CU_EXACT = 7;
+constexpr uint32_t BLEND_WG_PER_CU_THROUGHPUT = 6;  // leaves room for the other contexts' kernels
 constexpr uint32_t SEG_LEN_WHOLE_BIN = 0x7fffff00u;
 
 int alloc_bins(gsr_ctx* c)
@@ -223,7 +229,7 @@ int alloc_bins(gsr_ctx* c)
     const bool throughput = (c->opt.flags & GSR_FLAG_THROUGHPUT) != 0;
     c->seg_len = c->opt.early_out_eps > 0.0f ? SEG_LEN_WHOLE_BIN : SEG_LEN_MIN;
     c->seg_target_items = throughput ? SEG_TARGET_THROUGHPUT : SEG_TARGET_EXACT;
-    c->blend_grid = throughput ? BLEND_GRID_THROUGHPUT : BLEND_GRID_EXACT;
+    c->blend_grid = (throughput ? BLEND_WG_PER_CU_THROUGHPUT : BLEND_WG_PER_CU_EXACT) * (uint32_t)std::max(c->cu_count, 1);
     if (const char* e = getenv("GSR_SEG_TARGET")) {  // tuning knob: full segments a frame is cut into at least
         const long v = atol(e);
         if (v >= 1) c->seg_target_items = (uint32_t)v;
@@ -510,6 +516,10 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
     } while (0)
     CREATE_TRY(hipSetDevice(c->device));
     CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0) c->cu_count = cus;
+    }
     CREATE_TRY(hipMalloc((void**)&c->fstate, sizeof(FrameState)));
     CREATE_TRY(hipMalloc((void**)&c->cam_dev, sizeof(CamParams)));
     if (const char* e = getenv("GSR_NO_GRAPH")) c->graphs_enabled = atoi(e) == 0;

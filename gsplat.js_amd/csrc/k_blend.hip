@@ -36,6 +36,18 @@ constexpr int CHUNK = BLEND_THREADS;
 constexpr int BIN_PIXELS = BIN_PX * BIN_PX;
 constexpr float LOG2E = 1.4426950408889634f;
 
+#ifdef GSR_BLEND_STAMPS
+// Diagnostic build only (scripts/build_exp.sh stamps "-DGSR_BLEND_STAMPS", read by scripts/blend_stamps.py): where a
+// compositor wave spends its cycles and when it starts and ends.  Per wave: [0] lifetime, [1] barrier at chunk start,
+// [2] staging, [3] barrier after staging, [4] composite loop (shader cycles), [5] start, [6] end (s_memrealtime,
+// 100 MHz, common to all XCDs), [7] entry visits, [8] items, [9] start of the last item, [10] longest item (ticks),
+// [11] its entries, [12] its entry visits, [13] its bin.  Never compiled into the shipped library.
+__device__ unsigned int g_blend_stamps[4096 * 4 * 16];
+#define STAMP(v) const unsigned int v = (unsigned int)__builtin_readcyclecounter()
+#else
+#define STAMP(v)
+#endif
+
 // 7 waves per SIMD: the kernel needs 74 VGPRs unconstrained (6 waves); capped at 72 it spills one register pair that is
 // stored once per workgroup and reloaded once per work item, and the seventh wave hides more of the LDS/barrier
 // waits (measured: k_blend -5.7 % alone; 8 waves = 64 VGPRs spills inside the loops and is no better).
@@ -65,6 +77,12 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
     // that drew light items simply draws more: no static assignment, no long pole.
     // The first item of a workgroup is its own index (the queue starts at gridDim.x, k_bin_finalize sets it): a
     // kernel start with ~2000 workgroups drawing from one counter serialises ~2000 same-address atomics.
+#ifdef GSR_BLEND_STAMPS
+    unsigned int a_waitA = 0, a_stage = 0, a_waitB = 0, a_comp = 0, a_entries = 0;
+    unsigned int a_items = 0, a_last_start = 0, a_max_dur = 0, a_max_len = 0, a_max_vis = 0, a_max_bin = 0, a_item_t0 = 0, a_item_vis0 = 0, a_item_len = 0, a_item_bin = 0;
+    const unsigned int t_kernel0 = (unsigned int)__builtin_readcyclecounter();
+    const unsigned int t_real0 = (unsigned int)__builtin_amdgcn_s_memrealtime();
+#endif
     bool first = true;
     for (;;) {
         __syncthreads();  // the previous item no longer uses the LDS words
@@ -78,6 +96,9 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
         if (qi >= total_items) break;
         const uint32_t it = items[qi];
         const int bin = (int)(it & 0xffffu);
+#ifdef GSR_BLEND_STAMPS
+        a_items++; a_item_t0 = (unsigned int)__builtin_amdgcn_s_memrealtime(); a_last_start = a_item_t0; a_item_vis0 = a_entries; a_item_bin = (unsigned int)bin;
+#endif
         const uint32_t seg = it >> 16;
         const uint32_t nseg = seg_start[bin + 1] - seg_start[bin];
         const int by = bin / nbxb, bxl = bin - by * nbxb;
@@ -97,9 +118,14 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
         const uint32_t begin = min(bin_start[bin] + seg * seg_len, bin_end);
         const uint32_t end = min(begin + seg_len, bin_end);
         bool done = false;
+#ifdef GSR_BLEND_STAMPS
+        a_item_len = end - begin;
+#endif
 
         for (uint32_t base = begin; base < end; base += CHUNK) {
+            STAMP(t_c0);
             __syncthreads();  // previous chunk fully consumed (and s_done visible)
+            STAMP(t_cA);
             if (s_done == BLEND_THREADS / WAVE) break;  // every tile of the bin is saturated
             // ---- stage one entry per thread: record, unpacked colour, and a 16-bit mask of the bin's
             //      8x8-pixel quadrants the splat can touch (bit = tile*4 + quadrant).  The mask is a
@@ -150,13 +176,18 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
                 *reinterpret_cast<float2*>(&s_rec[2][threadIdx.x]) = make_float2(cr, cg);
             }
             s_mask[threadIdx.x] = mask;
+            STAMP(t_cS);
             __syncthreads();
+            STAMP(t_cB);
 
             if (!done) {
                 const uint32_t cnt = min((uint32_t)CHUNK, end - base);
                 for (uint32_t c0 = 0; c0 < cnt; c0 += WAVE) {
                     const uint32_t mine = (s_mask[c0 + lane] >> (wave * 4)) & 15u;  // entry (c0+lane) vs my tile
                     uint64_t bal = __ballot(mine != 0u);
+#ifdef GSR_BLEND_STAMPS
+                    a_entries += __popcll(bal);
+#endif
 #define GSR_QUAD(BIT, PX, UR, WR, T, R, G, B_)                                                     \
     if (qm & (BIT)) {                                                                              \
         const float vx_ = __builtin_fmaf(ux, (PX), (UR)), vy_ = __builtin_fmaf(wx, (PX), (WR));    \
@@ -213,8 +244,20 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
                     }
                 }
             }
+#ifdef GSR_BLEND_STAMPS
+            {
+                const unsigned int t_cC = (unsigned int)__builtin_readcyclecounter();
+                a_waitA += t_cA - t_c0; a_stage += t_cS - t_cA; a_waitB += t_cB - t_cS; a_comp += t_cC - t_cB;
+            }
+#endif
         }
 
+#ifdef GSR_BLEND_STAMPS
+        {
+            const unsigned int d = (unsigned int)__builtin_amdgcn_s_memrealtime() - a_item_t0;
+            if (d > a_max_dur) { a_max_dur = d; a_max_len = a_item_len; a_max_vis = a_entries - a_item_vis0; a_max_bin = a_item_bin; }
+        }
+#endif
         if (nseg == 1) {
             // ---- the only segment: write the tile, premultiplied RGBA, alpha = 1 - T ----
             const int x0 = X0 + lx, x1 = x0 + 8, y0 = Y0 + ly, y1 = y0 + 8;
@@ -235,7 +278,22 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
             p[192] = make_float4(r11, g11, b11, T11);
         }
     }
+#ifdef GSR_BLEND_STAMPS
+    if (lane == 0 && blockIdx.x < 4096) {
+        unsigned int* o = g_blend_stamps + ((size_t)blockIdx.x * 4 + wave) * 16;
+        o[0] = (unsigned int)__builtin_readcyclecounter() - t_kernel0; o[1] = a_waitA; o[2] = a_stage; o[3] = a_waitB; o[4] = a_comp;
+        o[5] = t_real0; o[6] = (unsigned int)__builtin_amdgcn_s_memrealtime(); o[7] = a_entries;
+        o[8] = a_items; o[9] = a_last_start; o[10] = a_max_dur; o[11] = a_max_len; o[12] = a_max_vis; o[13] = a_max_bin;
+    }
+#endif
 }
+
+#ifdef GSR_BLEND_STAMPS
+extern "C" int gsr_debug_blend_stamps(unsigned int* out /* 4096*4*16 */)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blend_stamps), sizeof g_blend_stamps) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // Fold the per-segment partials of every multi-segment bin, front to back.  A thread folds its four
 // pixels as four independent chains and the segment loop is unrolled, so 16 loads are in flight per

@@ -63,7 +63,7 @@ typedef struct gsr_options {
 #define GSR_FLAG_THROUGHPUT 2 /* the caller keeps several frames in flight on this device (one
                                context per frame): the compositor then cuts a frame into ~1300
                                work items instead of ~5000 (2048 list entries per item instead of
-                               512 on a 1 M-splat 1080p frame) and launches 6 instead of 8
+                               512 on a 1 M-splat 1080p frame) and launches 6 instead of 7
                                persistent workgroups per CU, because the other contexts' kernels,
                                not extra segments of this frame, fill the GPU.  Same pixels within
                                float rounding (the segments are combined associatively). */
