@@ -67,15 +67,15 @@ struct gsr_ctx {
     uint32_t* block_hist = nullptr;
     Record* rec = nullptr;
     uint2* bbox = nullptr;
-    int2* blk_minmax = nullptr;   // per-workgroup (min, max) depth of k_project_key, folded by k_minmax_reduce
+    int32_t* slots = nullptr;     // FRAME_SLOTS x 128 B: partial depth (min, max), visible and tile sums of k_project_key
+    uint32_t* rect_idx = nullptr; // per splat: packed bin rectangle (k_project_key); bin_rects holds them in depth order
     uint32_t sort_blocks = 0, sort_kpb = 0;
     // binning
     uint32_t *bin_table = nullptr, *bin_total = nullptr, *bin_start = nullptr, *bin_list = nullptr;
     uint32_t *seg_start = nullptr, *items = nullptr;
-    uint2* blk_counts = nullptr;
     uint32_t* bin_rects = nullptr;
     float4* partial = nullptr;
-    uint32_t bin_blocks = 0, bin_capacity = 0, bin_table_elems = 0, bin_nbins_alloc = 0, blk_counts_alloc = 0;
+    uint32_t bin_blocks = 0, bin_capacity = 0, bin_table_elems = 0, bin_nbins_alloc = 0;
     uint32_t max_items = 0, seg_len = 0, blend_grid = 2048;
     uint32_t seg_target_items = 5000;
     uint32_t timing_every = 1, frame_no = 0;
@@ -209,10 +209,6 @@ int alloc_bins(gsr_ctx* c)
         if (int r = dev_alloc(c, &c->bin_table, table)) return r;
         c->bin_table_elems = (uint32_t)table;
     }
-    if (c->bin_blocks > c->blk_counts_alloc || !c->blk_counts) {
-        if (int r = dev_alloc(c, &c->blk_counts, std::max(c->bin_blocks, 1u))) return r;
-        c->blk_counts_alloc = c->bin_blocks;
-    }
     bool items_dirty = false;
     if (nbins > c->bin_nbins_alloc) {
         if (int r = dev_alloc(c, &c->bin_total, nbins)) return r;
@@ -277,16 +273,15 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BEGIN], s));
     if (c->n) {
         SceneSoA sc{c->px, c->py, c->pz, c->cov0, c->cov1, c->cov2, c->rgba, c->sh_r, c->sh_g, c->sh_b, c->shcol};
-        launch_project_key(sc, c->n, c->cam_dev, render ? 1 : 0, c->depth, c->blk_minmax, c->fstate->minmax, c->rec, c->bbox, s);
+        launch_project_key(sc, c->n, c->cam_dev, render ? 1 : 0, c->depth, c->slots, c->rec, c->bbox, c->rect_idx, s);
     }
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_PROJECT], s));
     if (c->n) {
         // band mode (a context that composites only part of the screen): sort and bin only the splats whose box
         // touches the band; the full depthIndex is produced on demand (gsr_read_depth_index)
         const bool cull = render && band_is_partial(c);
-        SortBuffers sb{c->depth, c->fstate->minmax, c->keys, c->keys_tmp, c->idx_tmp, c->depth_index,
-                       c->block_hist, c->fstate->digit_total, cull ? c->bbox : nullptr, &c->fstate->sorted_count,
-                       c->sort_kpb, c->sort_blocks};
+        SortBuffers sb{c->depth, c->slots, c->fstate->minmax, c->keys, c->keys_tmp, c->idx_tmp, c->depth_index,
+                       c->block_hist, c->fstate->digit_total, c->rect_idx, cull ? 1 : 0, &c->fstate->sorted_count, c->sort_kpb, c->sort_blocks};
         c->sort_culled = cull;
         launch_sort(sb, c->n, s);
     }
@@ -295,7 +290,7 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
         const BinGrid g = make_grid(c);
         const int nbins = (g.bx_hi - g.bx_lo) * g.nby;
         if (!c->n) HIP_TRY(c, hipMemsetAsync(c->bin_total, 0, sizeof(uint32_t) * nbins, s));
-        BinBuffers bb{c->depth_index, &c->fstate->sorted_count, c->bbox, c->bin_table, c->blk_counts, c->bin_rects, c->bin_total, c->bin_start, c->seg_start,
+        BinBuffers bb{c->depth_index, &c->fstate->sorted_count, c->bin_table, c->slots, c->rect_idx, c->bin_rects, c->bin_total, c->bin_start, c->seg_start,
                       c->items, c->bin_list, &c->fstate->overflow, &c->fstate->visible, &c->fstate->tile_entries,
                       c->accum, c->mailbox_dev, c->fstate->report, c->bin_capacity, c->max_items, c->seg_len, &c->fstate->seg_len, (c->opt.flags & GSR_FLAG_THROUGHPUT) ? 0 : 1, &c->fstate->queue, std::min<uint32_t>(c->max_items, c->blend_grid), c->seg_target_items, c->bin_blocks};
         launch_bin(bb, g, c->n, s);
@@ -328,7 +323,7 @@ static std::vector<uint64_t> chain_signature(const gsr_ctx* c)
     auto U = [&v](uint64_t x) { v.push_back(x); };
     P(c->px); P(c->py); P(c->pz); P(c->cov0); P(c->cov1); P(c->cov2); P(c->rgba); P(c->sh_r); P(c->sh_g); P(c->sh_b); P(c->shcol);
     P(c->depth); P(c->keys); P(c->keys_tmp); P(c->idx_tmp); P(c->depth_index); P(c->block_hist); P(c->fstate);
-    P(c->rec); P(c->bbox); P(c->blk_minmax); P(c->bin_table); P(c->blk_counts); P(c->bin_rects); P(c->bin_total); P(c->bin_start); P(c->seg_start);
+    P(c->rec); P(c->bbox); P(c->slots); P(c->rect_idx); P(c->bin_table); P(c->bin_rects); P(c->bin_total); P(c->bin_start); P(c->seg_start);
     P(c->items); P(c->bin_list); P(c->partial); P(c->fb); P(c->accum); P(c->cam_dev);
     U(c->n); U((uint64_t)c->W); U((uint64_t)c->H); U((uint64_t)g.bx_lo); U((uint64_t)g.bx_hi); U(c->sort_kpb); U(c->sort_blocks);
     U(c->bin_capacity); U(c->max_items); U(c->seg_len); U(c->seg_target_items); U(c->blend_grid); U(c->bin_blocks);
@@ -370,7 +365,7 @@ int enqueue_frame(gsr_ctx* c, bool render)
     c->cam.sh_on = c->sh_count ? 1 : 0;
     c->cam.band[0] = c->band[0]; c->cam.band[1] = c->band[1]; c->cam.band[2] = c->band[2];
     static_assert(offsetof(FrameState, minmax) == 0 && sizeof(FrameState) % 4 == 0, "k_begin_frame resets the frame words");
-    launch_begin_frame(c->cam, c->cam_dev, reinterpret_cast<uint32_t*>(c->fstate), (uint32_t)(sizeof(FrameState) / 4), s);
+    launch_begin_frame(c->cam, c->cam_dev, reinterpret_cast<uint32_t*>(c->fstate), (uint32_t)(sizeof(FrameState) / 4), c->slots, s);
 
     bool replayed = false;
     if (c->graphs_enabled && render && !timing) {
@@ -522,6 +517,8 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
     }
     CREATE_TRY(hipMalloc((void**)&c->fstate, sizeof(FrameState)));
     CREATE_TRY(hipMalloc((void**)&c->cam_dev, sizeof(CamParams)));
+    CREATE_TRY(hipMalloc((void**)&c->slots, sizeof(int32_t) * FRAME_SLOTS * FRAME_SLOT_WORDS));
+    CREATE_TRY(hipMemset(c->slots, 0, sizeof(int32_t) * FRAME_SLOTS * FRAME_SLOT_WORDS));
     if (const char* e = getenv("GSR_NO_GRAPH")) c->graphs_enabled = atoi(e) == 0;
     CREATE_TRY(hipMalloc((void**)&c->accum, 8 * sizeof(uint64_t)));
     CREATE_TRY(hipMemset(c->accum, 0, 8 * sizeof(uint64_t)));
@@ -563,9 +560,9 @@ int gsr_destroy(gsr_ctx* c)
     dev_free(&c->sh_r); dev_free(&c->sh_g); dev_free(&c->sh_b); dev_free(&c->shcol);
     dev_free(&c->rotv); dev_free(&c->sclv);
     dev_free(&c->depth); dev_free(&c->keys); dev_free(&c->keys_tmp); dev_free(&c->idx_tmp); dev_free(&c->depth_index);
-    dev_free(&c->block_hist); dev_free(&c->rec); dev_free(&c->bbox); dev_free(&c->blk_minmax);
+    dev_free(&c->block_hist); dev_free(&c->rec); dev_free(&c->bbox); dev_free(&c->slots); dev_free(&c->rect_idx);
     dev_free(&c->bin_table); dev_free(&c->bin_total); dev_free(&c->bin_start); dev_free(&c->bin_list);
-    dev_free(&c->seg_start); dev_free(&c->items); dev_free(&c->blk_counts); dev_free(&c->partial); dev_free(&c->bin_rects);
+    dev_free(&c->seg_start); dev_free(&c->items); dev_free(&c->partial); dev_free(&c->bin_rects);
     drop_graph(c);
     dev_free(&c->cam_dev);
     dev_free(&c->fstate); dev_free(&c->accum); dev_free(&c->fb); dev_free(&c->fb8);
@@ -596,10 +593,16 @@ int alloc_scene(gsr_ctx* c, uint32_t n, bool with_rows)
         (r = dev_alloc(c, &c->rgba, n)) || (r = dev_alloc(c, &c->depth, n)) || (r = dev_alloc(c, &c->keys, n)) ||
         (r = dev_alloc(c, &c->keys_tmp, n)) || (r = dev_alloc(c, &c->idx_tmp, n)) ||
         (r = dev_alloc(c, &c->depth_index, n)) || (r = dev_alloc(c, &c->rec, n)) || (r = dev_alloc(c, &c->bbox, n)) ||
-        (r = dev_alloc(c, &c->bin_rects, n)) || (r = dev_alloc(c, &c->blk_minmax, (n + 255) / 256)))
+        (r = dev_alloc(c, &c->bin_rects, n)) || (r = dev_alloc(c, &c->rect_idx, n)))
         return r;
     if (with_rows && ((r = dev_alloc(c, &c->rotv, n)) || (r = dev_alloc(c, &c->sclv, n)))) return r;
-    c->sort_kpb = 2048;
+    // keys per radix workgroup: the scatter stores runs of keys_per_block / 2^bits keys, so larger scenes take larger
+    // blocks (whole cache lines per run) while small ones keep enough workgroups to fill the chip
+    c->sort_kpb = n <= (3u << 20) ? 2048 : n <= (12u << 20) ? 4096 : 8192;
+    if (const char* e = getenv("GSR_SORT_KPB")) {   // tuning knob: 2048, 4096 or 8192
+        const long v = atol(e);
+        if (v == 2048 || v == 4096 || v == 8192) c->sort_kpb = (uint32_t)v;
+    }
     c->sort_blocks = (n + c->sort_kpb - 1) / c->sort_kpb;
     return dev_alloc(c, &c->block_hist, (size_t)std::max(c->sort_blocks, 1u) * RADIX_HI_BINS);
 }

@@ -46,6 +46,21 @@ static_assert(sizeof(Record) == 32, "record must be 32 bytes");
 constexpr uint32_t BBOX_INVISIBLE_X = 1u;  // x0 = 1, x1 = 0
 constexpr uint32_t BBOX_INVISIBLE_Y = 1u;
 
+// Bin rectangle of a splat's pixel box inside a context's band of bin columns [bx_lo, bx_hi), packed in 4 bytes:
+// x0 | x1 << 8 | y0 << 16 | y1 << 24 (inclusive bin coordinates, x relative to the band; at most 256 bins per axis);
+// 1 = nothing to draw.  Written once per splat by k_project_key; k_bin_count gathers them into depth order (4-byte
+// gathers; carrying them through the last radix pass instead moved the same cost into that kernel: measured, dropped).
+constexpr uint32_t RECT_NONE = 1u;
+__host__ __device__ inline uint32_t pack_bin_rect(uint32_t bbx, uint32_t bby, int bx_lo, int bx_hi)
+{
+    const int px0 = (int)(bbx & 0xffffu), px1 = (int)(bbx >> 16), py0 = (int)(bby & 0xffffu), py1 = (int)(bby >> 16);
+    if (px0 > px1) return RECT_NONE;
+    const int x0 = (px0 / BIN_PX > bx_lo ? px0 / BIN_PX : bx_lo) - bx_lo;
+    const int x1 = (px1 / BIN_PX < bx_hi - 1 ? px1 / BIN_PX : bx_hi - 1) - bx_lo;
+    if (x0 > x1) return RECT_NONE;
+    return (uint32_t)x0 | ((uint32_t)x1 << 8) | ((uint32_t)(py0 / BIN_PX) << 16) | ((uint32_t)(py1 / BIN_PX) << 24);
+}
+
 struct SceneSoA {
     const float *px, *py, *pz;
     const uint32_t *cov0, *cov1, *cov2, *rgba;
@@ -74,21 +89,33 @@ void launch_repack_scene(const uint32_t* data, const float* positions, uint32_t 
 void launch_repack_positions(const float* positions, uint32_t n, float* px, float* py, float* pz, hipStream_t s);
 
 // frame_words: the context's per-frame device words, [0] = minDepth, [1] = maxDepth, the rest zero at frame start
-void launch_begin_frame(const CamParams& cam, CamParams* dst, uint32_t* frame_words, uint32_t nwords, hipStream_t s);
+void launch_begin_frame(const CamParams& cam, CamParams* dst, uint32_t* frame_words, uint32_t nwords, int32_t* slots, hipStream_t s);
+// Frame-wide reductions of k_project_key -- depth min / max over ALL splats (wasm.cpp:14-31), visible splats and the
+// 16x16 tiles their boxes overlap (V and D of the byte model) -- go through FRAME_SLOTS accumulators, one 128-byte line
+// each: a workgroup folds its values into slot (blockIdx & 63) with four atomics.  ~60 workgroups share a slot over the
+// kernel's ~20 us, far from the ~90 same-address atomics per microsecond at which one word saturates (with ONE pair of
+// words for 4000 workgroups the kernel stayed alive ~17 us after its last store).  The consumers fold the 64 slots
+// themselves (k_quantise_hist, k_bin_finalize): no reduction kernel.
+constexpr uint32_t PROJ_THREADS = 256;
+constexpr int FRAME_SLOTS = 64;
+constexpr int FRAME_SLOT_WORDS = 32;   // words per slot (one 128-byte line): [0] min depth, [1] max depth, [2] visible, [3] tiles
 void launch_project_key(const SceneSoA& sc, uint32_t n, const CamParams* cam_dev, int do_project, int32_t* depth,
-                        int2* blk_minmax /* ceil(n/256) */, int32_t* minmax, Record* rec, uint2* bbox, hipStream_t s);
+                        int32_t* slots /* FRAME_SLOTS * FRAME_SLOT_WORDS, reset by k_begin_frame */, Record* rec, uint2* bbox,
+                        uint32_t* rect /* n: packed bin rectangle per splat */, hipStream_t s);
 
 // radix sort of the 17-bit keys; see k_sort.hip
 struct SortBuffers {
     const int32_t* depth;      // n
-    const int32_t* minmax;     // 2
+    const int32_t* slots;      // FRAME_SLOTS partial (min, max) pairs of k_project_key
+    int32_t* minmax;           // 2: folded by k_quantise_hist (workgroup 0 stores it for the host / read-backs)
     uint32_t* keys;            // n   17-bit keys, original order
     uint32_t* keys_tmp;        // n   keys after pass 1
     uint32_t* idx_tmp;         // n   indices after pass 1
     uint32_t* depth_index;     // n   result
     uint32_t* block_hist;      // nblocks * RADIX_HI_BINS
     uint32_t* digit_total;     // RADIX_LO_BINS + RADIX_HI_BINS
-    const uint2* cull_bbox;    // band mode: boxes of the projection (empty box = absent from the sort); null = sort all n
+    const uint32_t* rect;      // per splat: packed bin rectangle of the projection (read only when cull is set)
+    int cull;                  // band mode: splats with rect == RECT_NONE are absent from the sort
     uint32_t* count;           // out: keys the first pass kept (n, or the band's survivors) = entries of depth_index
     uint32_t keys_per_block;
     uint32_t nblocks;
@@ -105,10 +132,10 @@ struct BinGrid {
 struct BinBuffers {
     const uint32_t* depth_index; // *count entries
     const uint32_t* count;       // ranks to bin (SortBuffers::count)
-    const uint2* bbox;           // n
     uint32_t* table;             // nblocks * nbins  (counts, then per-workgroup offsets inside each bin)
-    uint2* blk_counts;           // nblocks: (visible splats, 16x16 tile overlaps) per counting workgroup
-    uint32_t* rects;             // n: packed bin rectangle of every rank (count pass -> scatter pass)
+    const int32_t* slots;        // FRAME_SLOTS partial (visible splats, 16x16 tile overlaps) sums of k_project_key
+    const uint32_t* rect_idx;    // n: packed bin rectangle of every splat (k_project_key)
+    uint32_t* rects;             // n: the same in depth order (count pass -> scatter pass)
     uint32_t* bin_total;         // nbins (zeroed by the caller when n == 0)
     uint32_t* bin_start;         // nbins + 1
     uint32_t* seg_start;         // nbins + 1: first compositor work item of each bin; [nbins] = item count

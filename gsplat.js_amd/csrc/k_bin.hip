@@ -20,30 +20,23 @@
 
 namespace gsr {
 
+#ifdef GSR_KSTAMPS
+// Diagnostic build only: per-workgroup phase times of k_bin_scatter (s_memrealtime ticks, 10 ns), read by
+// scripts/kernel_stamps.py through gsr_debug_bin_stamps.
+__device__ unsigned int g_bin_stamps[4096 * 8];
+#define KSTAMP(slot) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) g_bin_stamps[blockIdx.x * 8 + (slot)] = (unsigned int)__builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int gsr_debug_bin_stamps(unsigned int* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bin_stamps), sizeof g_bin_stamps) == hipSuccess ? 0 : -1; }
+#else
+#define KSTAMP(slot)
+#endif
+
 constexpr int BIN_THREADS = 256;
 constexpr int BIN_STEPS = 8;                                  // 64-rank steps per wave
 constexpr uint32_t BIN_RANKS_PER_BLOCK = BIN_THREADS * BIN_STEPS;  // 2048
 
 struct BinRect { int x0, x1, y0, y1; };  // inclusive bin coordinates relative to the band; x0 > x1: none
 
-__device__ __forceinline__ BinRect bin_rect(uint2 bb, const BinGrid& g)
-{
-    BinRect r;
-    const int px0 = bb.x & 0xffff, px1 = bb.x >> 16, py0 = bb.y & 0xffff, py1 = bb.y >> 16;
-    if (px0 > px1) { r.x0 = 1; r.x1 = 0; r.y0 = 1; r.y1 = 0; return r; }
-    r.x0 = max(px0 / BIN_PX, g.bx_lo) - g.bx_lo;
-    r.x1 = min(px1 / BIN_PX, g.bx_hi - 1) - g.bx_lo;
-    r.y0 = py0 / BIN_PX;
-    r.y1 = py1 / BIN_PX;
-    return r;
-}
-
-// bin rectangle of one rank in 4 bytes (x0 | x1<<8 | y0<<16 | y1<<24; bins per axis <= 256): the count pass
-// gathers the boxes once and leaves the rectangles in rank order, the scatter pass reads them coalesced
-__device__ __forceinline__ uint32_t pack_rect(const BinRect& r)
-{
-    return (r.x0 <= r.x1) ? ((uint32_t)r.x0 | ((uint32_t)r.x1 << 8) | ((uint32_t)r.y0 << 16) | ((uint32_t)r.y1 << 24)) : 1u;
-}
+// (the packed form, pack_bin_rect, is in gsr_internal.h: k_project_key writes it, the last radix pass sorts it)
 __device__ __forceinline__ BinRect unpack_rect(uint32_t p)
 {
     BinRect r;
@@ -58,72 +51,50 @@ __device__ __forceinline__ uint32_t lanes_below64(uint64_t mask)
 }
 
 // ---------------------------------------------------------------------------
-// count: table[block][bin] = entries this workgroup contributes to bin;
-// blk_counts[block] = (visible splats, 16x16 tiles their boxes overlap).
-// No global atomics: hundreds of workgroups hitting the same few words cost
-// more than the whole pass.
+// count: table[block][bin] = entries this workgroup's 2048 ranks contribute to bin.  The ranks' packed bin rectangles
+// (4 bytes per splat, k_project_key) are gathered through depth_index and left in depth order for the scatter pass.
+// No global atomics: hundreds of workgroups hitting the same few words cost more than the whole pass.
 // ---------------------------------------------------------------------------
 constexpr int CNT_THREADS = 1024;
 constexpr int CNT_STEPS = (int)BIN_RANKS_PER_BLOCK / CNT_THREADS;  // 2
 constexpr int CNT_MAX_BINS = 12288;  // LDS counters per workgroup (48 KiB); larger grids are cut into row slices (blockIdx.y)
 
-__global__ __launch_bounds__(CNT_THREADS) void k_bin_count(const uint32_t* __restrict__ depth_index,
-                                                           const uint2* __restrict__ bbox, const uint32_t* __restrict__ count,
-                                                           BinGrid g, int slice_rows, uint32_t* __restrict__ table,
-                                                           uint2* __restrict__ blk_counts, uint32_t* __restrict__ rects)
+__global__ __launch_bounds__(CNT_THREADS) void k_bin_count(const uint32_t* __restrict__ depth_index, const uint32_t* __restrict__ rect_idx,
+                                                           const uint32_t* __restrict__ count, BinGrid g, int slice_rows,
+                                                           uint32_t* __restrict__ table, uint32_t* __restrict__ rects)
 {
     const uint32_t n = *count;  // ranks the sort produced (all splats, or the band's survivors)
     extern __shared__ uint32_t s_cnt[];  // this slice's bins
-    __shared__ uint32_t s_red[2 * (CNT_THREADS / WAVE)];
     const int nbxb = g.bx_hi - g.bx_lo, nbins = nbxb * g.nby;
     const int y_lo = blockIdx.y * slice_rows, y_hi = min(y_lo + slice_rows, g.nby);  // bin rows of this slice
     const int nb_s = (y_hi - y_lo) * nbxb;
-    const bool first = blockIdx.y == 0;  // slice 0 also leaves the rectangles and the frame counters
     for (int b = threadIdx.x; b < nb_s; b += CNT_THREADS) s_cnt[b] = 0;
     __syncthreads();
     const uint32_t begin = blockIdx.x * BIN_RANKS_PER_BLOCK;
-    uint32_t vis = 0, tiles = 0;
-    uint32_t idx[CNT_STEPS];
+    uint32_t idx[CNT_STEPS], rc[CNT_STEPS];
 #pragma unroll
     for (int st = 0; st < CNT_STEPS; st++) {
         const uint32_t r = begin + st * CNT_THREADS + threadIdx.x;
         idx[st] = (r < n) ? depth_index[r] : 0xffffffffu;
     }
-    uint2 bbs[CNT_STEPS];
 #pragma unroll
-    for (int st = 0; st < CNT_STEPS; st++)
-        bbs[st] = (idx[st] != 0xffffffffu) ? bbox[idx[st]] : make_uint2(BBOX_INVISIBLE_X, BBOX_INVISIBLE_Y);
+    for (int st = 0; st < CNT_STEPS; st++) rc[st] = (idx[st] != 0xffffffffu) ? rect_idx[idx[st]] : RECT_NONE;
+    if (blockIdx.y == 0) {   // slice 0 also leaves the rectangles in depth order
+#pragma unroll
+        for (int st = 0; st < CNT_STEPS; st++) {
+            const uint32_t r = begin + st * CNT_THREADS + threadIdx.x;
+            if (r < n) rects[r] = rc[st];
+        }
+    }
 #pragma unroll
     for (int st = 0; st < CNT_STEPS; st++) {
-        const uint2 bb = bbs[st];
-        const BinRect br = bin_rect(bb, g);
-        if (first) {
-            const uint32_t r = begin + st * CNT_THREADS + threadIdx.x;
-            if (r < n) rects[r] = pack_rect(br);
-        }
-        if (br.x0 <= br.x1) {
-            vis++;
-            const int tx0 = max((int)(bb.x & 0xffff) / TILE, g.bx_lo * BIN_TILES);
-            const int tx1 = min((int)(bb.x >> 16) / TILE, g.bx_hi * BIN_TILES - 1);
-            tiles += (uint32_t)((tx1 - tx0 + 1) * ((int)(bb.y >> 16) / TILE - (int)(bb.y & 0xffff) / TILE + 1));
+        const BinRect br = unpack_rect(rc[st]);
+        if (br.x0 <= br.x1)
             for (int y = max(br.y0, y_lo); y <= min(br.y1, y_hi - 1); y++)
                 for (int x = br.x0; x <= br.x1; x++) atomicAdd(&s_cnt[(y - y_lo) * nbxb + x], 1u);
-        }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        vis += __shfl_xor(vis, off);
-        tiles += __shfl_xor(tiles, off);
-    }
-    constexpr int NW = CNT_THREADS / WAVE;
-    if ((threadIdx.x & 63) == 0) { s_red[threadIdx.x >> 6] = vis; s_red[NW + (threadIdx.x >> 6)] = tiles; }
     __syncthreads();
     for (int b = threadIdx.x; b < nb_s; b += CNT_THREADS) table[(size_t)blockIdx.x * nbins + y_lo * nbxb + b] = s_cnt[b];
-    if (first && threadIdx.x == 0) {
-        uint32_t v = 0, t = 0;
-        for (int w = 0; w < NW; w++) { v += s_red[w]; t += s_red[NW + w]; }
-        blk_counts[blockIdx.x] = make_uint2(v, t);
-    }
 }
 
 // (the scan of table[block][bin] down the blocks, and bin_total[], is launch_column_scan of k_sort.hip)
@@ -192,7 +163,7 @@ __device__ __forceinline__ int partial_class(uint32_t r, uint32_t seg_len, bool 
 __global__ __launch_bounds__(FIN_THREADS) void k_bin_finalize(const uint32_t* __restrict__ bin_total, int nbins,
                                                               uint32_t seg_len_min, uint32_t seg_target_items, int by_size,
                                                               uint32_t* __restrict__ seg_len_out, uint32_t max_items, uint32_t capacity,
-                                                              const uint2* __restrict__ blk_counts, uint32_t nblocks,
+                                                              const int32_t* __restrict__ slots, uint32_t have_counts,
                                                               uint32_t* __restrict__ bin_start,
                                                               uint32_t* __restrict__ seg_start, uint32_t* __restrict__ items,
                                                               uint32_t* __restrict__ overflow, uint64_t* __restrict__ visible,
@@ -256,7 +227,10 @@ __global__ __launch_bounds__(FIN_THREADS) void k_bin_finalize(const uint32_t* __
     }
     // frame counters
     UN<2> cnt = {{0, 0}};
-    for (uint32_t b = threadIdx.x; b < nblocks; b += FIN_THREADS) { cnt.v[0] += blk_counts[b].x; cnt.v[1] += blk_counts[b].y; }
+    if (have_counts && threadIdx.x < FRAME_SLOTS) {   // the projection's visible-splat and tile-overlap sums
+        cnt.v[0] = (uint32_t)slots[(size_t)threadIdx.x * FRAME_SLOT_WORDS + 2];
+        cnt.v[1] = (uint32_t)slots[(size_t)threadIdx.x * FRAME_SLOT_WORDS + 3];
+    }
     UN<2> ctot;
     block_exclusive_scan<2>(cnt, s_w, &ctot);
     if (threadIdx.x == 0) {
@@ -350,10 +324,12 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_bin_scatter(const uint32_t* __
     unsigned long long* gmask = masks + (size_t)group * BIN_STEPS * nmask;   // step s of my group: gmask + s*nmask
     uint32_t* mypair = pair + (size_t)(group >> 1) * cap_s;
     const int myshift = (group & 1) * 16;
+    KSTAMP(0);
 
     for (int b = threadIdx.x; b < 2 * cap_s; b += SCAT_THREADS) pair[b] = 0;
     for (int b = threadIdx.x; b < SCAT_GROUPS * BIN_STEPS * nmask; b += SCAT_THREADS) masks[b] = 0;
     __syncthreads();
+    KSTAMP(1);
 
     // this wave's 2 steps of 64 consecutive ranks; rectangles clipped to the sub-grid, in sub-grid coordinates
     const uint32_t gbegin = blockIdx.x * BIN_RANKS_PER_BLOCK + group * (BIN_STEPS * WAVE);
@@ -367,7 +343,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_bin_scatter(const uint32_t* __
 #pragma unroll
     for (int k = 0; k < SCAT_STEPS_PER_WAVE; k++) {
         const uint32_t r = gbegin + (sub * SCAT_STEPS_PER_WAVE + k) * WAVE + lane;
-        BinRect b = unpack_rect((r < n) ? rects[r] : 1u);
+        BinRect b = unpack_rect((r < n) ? rects[r] : RECT_NONE);
         if (b.x0 <= b.x1) {
             b.x0 = max(b.x0, sx0) - sx0; b.x1 = min(b.x1, sx1 - 1) - sx0;
             b.y0 = max(b.y0, sy0) - sy0; b.y1 = min(b.y1, sy1 - 1) - sy0;
@@ -375,6 +351,14 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_bin_scatter(const uint32_t* __
         }
         br[k] = b;
     }
+    // the workgroup's first slot in every bin: two table reads that depend on nothing computed here, issued before
+    // the first barrier so that their round trip overlaps the rectangle loads and phase 1 (base[] is not touched there)
+    for (int b = threadIdx.x; b < nb_s; b += SCAT_THREADS) {
+        const int ly = b / sw, lx = b - ly * sw;
+        const int gb = (sy0 + ly) * nbxb + sx0 + lx;  // the bin's index in the band
+        base[b] = bin_start[gb] + table[(size_t)blockIdx.x * nbins + gb];
+    }
+    KSTAMP(2);
     // phase 1: per-group counts, and every lane ORs its bit into the column/row lane sets of its box
     const uint32_t one = 1u << myshift;
     const unsigned long long mybit = 1ull << lane;
@@ -390,17 +374,16 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_bin_scatter(const uint32_t* __
         }
     }
     __syncthreads();
-    // phase 2: counts -> offsets of each group inside the workgroup's run; workgroup base from the table
+    KSTAMP(3);
+    // phase 2: counts -> offsets of each group inside the workgroup's run
     for (int b = threadIdx.x; b < nb_s; b += SCAT_THREADS) {
-        const int ly = b / sw, lx = b - ly * sw;
-        const int gb = (sy0 + ly) * nbxb + sx0 + lx;  // the bin's index in the band
-        base[b] = bin_start[gb] + table[(size_t)blockIdx.x * nbins + gb];
         const uint32_t c01 = pair[b], c23 = pair[cap_s + b];
         const uint32_t o1 = c01 & 0xffffu, o2 = o1 + (c01 >> 16), o3 = o2 + (c23 & 0xffffu);
         pair[b] = o1 << 16;                // group 0: 0, group 1: o1
         pair[cap_s + b] = o2 | (o3 << 16); // group 2: o2, group 3: o3
     }
     __syncthreads();
+    KSTAMP(4);
     // phase 3: slots.  The set of lanes of step s covering bin (X,Y) is col[s][X] & row[s][Y]; a splat's slot is
     // base[bin] + its group's offset + the sizes of the sets of the group's earlier steps + the number of
     // lower lanes in its own step's set: input order, from ballot-style arithmetic on LDS words that are
@@ -421,6 +404,10 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_bin_scatter(const uint32_t* __
             }
         }
     }
+#ifdef GSR_KSTAMPS
+    __syncthreads();
+    KSTAMP(5);
+#endif
 }
 
 void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s)
@@ -442,12 +429,11 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
     const int cnt_rows = (g.nby + cnt_slices - 1) / cnt_slices;
     if (n) {
         hipLaunchKernelGGL(k_bin_count, dim3(b.nblocks, (g.nby + cnt_rows - 1) / cnt_rows), dim3(CNT_THREADS),
-                           (size_t)cnt_rows * nbxb * sizeof(uint32_t), s, b.depth_index, b.bbox, b.count, g, cnt_rows, b.table,
-                           b.blk_counts, b.rects);
+                           (size_t)cnt_rows * nbxb * sizeof(uint32_t), s, b.depth_index, b.rect_idx, b.count, g, cnt_rows, b.table, b.rects);
         launch_column_scan(b.table, b.bin_total, nbins, b.nblocks, s);
     }
     hipLaunchKernelGGL(k_bin_finalize, dim3(1), dim3(FIN_THREADS), 0, s, (const uint32_t*)b.bin_total, nbins, b.seg_len,
-                       b.seg_target_items, b.items_by_size, b.seg_len_dev, b.max_items, b.capacity, (const uint2*)b.blk_counts, n ? b.nblocks : 0u,
+                       b.seg_target_items, b.items_by_size, b.seg_len_dev, b.max_items, b.capacity, b.slots, n ? 1u : 0u,
                        b.bin_start, b.seg_start, b.items, b.overflow, b.visible, b.tile_entries, b.accum, b.report, b.queue, b.queue_start,
                        b.mailbox);
     if (n)

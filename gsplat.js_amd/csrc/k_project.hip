@@ -137,16 +137,20 @@ __device__ __forceinline__ float eval_sh_texture(const uint32_t* __restrict__ te
 // ---------------------------------------------------------------------------
 // The camera lives in device memory (written by k_begin_frame just before the frame) so that the frame's kernel
 // arguments do not change from frame to frame and the whole chain can be replayed as a HIP graph.
-__global__ __launch_bounds__(256) void k_project_key(SceneSoA sc, uint32_t n, const CamParams* __restrict__ camp,
-                                                     int do_project, int32_t* __restrict__ depth,
-                                                     int2* __restrict__ blk_minmax, Record* __restrict__ rec,
-                                                     uint2* __restrict__ bbox)
+__global__ __launch_bounds__(PROJ_THREADS) void k_project_key(SceneSoA sc, uint32_t n, const CamParams* __restrict__ camp,
+                                                              int do_project, int32_t* __restrict__ depth,
+                                                              int32_t* __restrict__ slots,
+                                                              Record* __restrict__ rec, uint2* __restrict__ bbox,
+                                                              uint32_t* __restrict__ rect)
 {
     const CamParams& cam = *camp;  // uniform address: scalar loads
     __shared__ int32_t s_min[4], s_max[4];
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t s_vis[4], s_til[4];
     int32_t dmin = 0x7fffffff, dmax = (int32_t)0x80000000;
+    uint32_t vis = 0, tiles = 0;   // this thread's visible splats and the 16x16 tiles their boxes overlap (V and D of the byte model)
+    const int bx_lo = cam.band_px0 / BIN_PX, bx_hi = (cam.band_px1 + BIN_PX - 1) / BIN_PX;   // this context's band of bin columns
 
+    const uint32_t i = blockIdx.x * PROJ_THREADS + threadIdx.x;
     if (i < n) {
         const float x = sc.px[i], y = sc.py[i], z = sc.pz[i];
         // ---- A1: three separate f32 multiplies, left-to-right adds, *4096 in f32, truncate ----
@@ -291,72 +295,66 @@ __global__ __launch_bounds__(256) void k_project_key(SceneSoA sc, uint32_t n, co
                 bb.y = (uint32_t)(int32_t)fy0 | ((uint32_t)(int32_t)fy1 << 16);
             } while (0);
             bbox[i] = bb;
+            rect[i] = pack_bin_rect(bb.x, bb.y, bx_lo, bx_hi);
+            if ((bb.x & 0xffffu) <= (bb.x >> 16)) {
+                vis++;
+                const int tx0 = max((int)(bb.x & 0xffffu) / TILE, bx_lo * BIN_TILES), tx1 = min((int)(bb.x >> 16) / TILE, bx_hi * BIN_TILES - 1);
+                tiles += (uint32_t)((tx1 - tx0 + 1) * ((int)(bb.y >> 16) / TILE - (int)(bb.y & 0xffffu) / TILE + 1));
+            }
         }
     }
 
-    // ---- block min/max -> one pair per workgroup; k_minmax_reduce folds the pairs.  Not atomics on the two global
-    //      words: the first wave of workgroups all see the initial bounds and ~4000 same-address atomics serialise at one
-    //      L2 channel, which kept this kernel alive for ~30 us after its last store (key-only call: 35 -> 8 us) ----
+    // ---- workgroup totals, folded into this workgroup's frame slot (see FRAME_SLOTS in gsr_internal.h) ----
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         dmin = min(dmin, __shfl_xor(dmin, off));
         dmax = max(dmax, __shfl_xor(dmax, off));
+        vis += __shfl_xor(vis, off);
+        tiles += __shfl_xor(tiles, off);
     }
     const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { s_min[wave] = dmin; s_max[wave] = dmax; }
-    __syncthreads();
-    if (threadIdx.x == 0)
-        blk_minmax[blockIdx.x] = make_int2(min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3])),
-                                           max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
-}
-
-// one workgroup: minmax[0..1] = min / max over the per-workgroup pairs (wasm/wasm.cpp:14-31's running min/max)
-__global__ __launch_bounds__(1024) void k_minmax_reduce(const int2* __restrict__ blk_minmax, uint32_t nblocks,
-                                                         int32_t* __restrict__ minmax)
-{
-    __shared__ int32_t s_min[16], s_max[16];
-    int32_t dmin = 0x7fffffff, dmax = (int32_t)0x80000000;
-    for (uint32_t b = threadIdx.x; b < nblocks; b += 1024) {
-        const int2 v = blk_minmax[b];
-        dmin = min(dmin, v.x); dmax = max(dmax, v.y);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        dmin = min(dmin, __shfl_xor(dmin, off));
-        dmax = max(dmax, __shfl_xor(dmax, off));
-    }
-    if ((threadIdx.x & 63) == 0) { s_min[threadIdx.x >> 6] = dmin; s_max[threadIdx.x >> 6] = dmax; }
+    if ((threadIdx.x & 63) == 0) { s_min[wave] = dmin; s_max[wave] = dmax; s_vis[wave] = vis; s_til[wave] = tiles; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 0; w < 16; w++) { dmin = min(dmin, s_min[w]); dmax = max(dmax, s_max[w]); }
-        minmax[0] = dmin; minmax[1] = dmax;
+        int32_t* slot = slots + (size_t)(blockIdx.x & (FRAME_SLOTS - 1)) * FRAME_SLOT_WORDS;
+        atomicMin(&slot[0], min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3])));
+        atomicMax(&slot[1], max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
+        if (do_project) {
+            atomicAdd(reinterpret_cast<uint32_t*>(&slot[2]), s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3]);
+            atomicAdd(reinterpret_cast<uint32_t*>(&slot[3]), s_til[0] + s_til[1] + s_til[2] + s_til[3]);
+        }
     }
 }
 
 void launch_project_key(const SceneSoA& sc, uint32_t n, const CamParams* cam, int do_project, int32_t* depth,
-                        int2* blk_minmax, int32_t* minmax, Record* rec, uint2* bbox, hipStream_t s)
+                        int32_t* slots, Record* rec, uint2* bbox, uint32_t* rect, hipStream_t s)
 {
     if (!n) return;
-    const uint32_t nblocks = (n + 255) / 256;
-    hipLaunchKernelGGL(k_project_key, dim3(nblocks), dim3(256), 0, s, sc, n, cam, do_project, depth, blk_minmax, rec, bbox);
-    hipLaunchKernelGGL(k_minmax_reduce, dim3(1), dim3(1024), 0, s, (const int2*)blk_minmax, nblocks, minmax);
+    hipLaunchKernelGGL(k_project_key, dim3((n + PROJ_THREADS - 1) / PROJ_THREADS), dim3(PROJ_THREADS), 0, s, sc, n, cam, do_project, depth,
+                       slots, rec, bbox, rect);
 }
 
 // Start of a frame, one small workgroup: the by-value camera goes to its device slot (kernarg -> global) and the
 // frame's device words are reset (minDepth / maxDepth to the values wasm/wasm.cpp:14-15 starts from, everything
 // else to zero).  One launch instead of a copy kernel plus a setter.
-__global__ void k_begin_frame(CamParams cam, CamParams* __restrict__ dst, uint32_t* __restrict__ frame_words, uint32_t nwords)
+__global__ void k_begin_frame(CamParams cam, CamParams* __restrict__ dst, uint32_t* __restrict__ frame_words, uint32_t nwords,
+                              int32_t* __restrict__ slots)
 {
+    // the frame slots: min <- INT_MAX, max <- INT_MIN (the values wasm/wasm.cpp:14-15 starts from), the counters <- 0
+    for (uint32_t t = threadIdx.x; t < (uint32_t)FRAME_SLOTS * 4; t += blockDim.x) {
+        const uint32_t k = t & 3u;
+        slots[(size_t)(t >> 2) * FRAME_SLOT_WORDS + k] = k == 0 ? 0x7fffffff : k == 1 ? (int32_t)0x80000000 : 0;
+    }
     constexpr uint32_t WORDS = sizeof(CamParams) / 4;
     const uint32_t* src = reinterpret_cast<const uint32_t*>(&cam);
     for (uint32_t w = threadIdx.x; w < WORDS; w += blockDim.x) reinterpret_cast<uint32_t*>(dst)[w] = src[w];
     for (uint32_t w = threadIdx.x; w < nwords; w += blockDim.x) frame_words[w] = w == 0 ? 0x7fffffffu : w == 1 ? 0x80000000u : 0u;
 }
 
-void launch_begin_frame(const CamParams& cam, CamParams* dst, uint32_t* frame_words, uint32_t nwords, hipStream_t s)
+void launch_begin_frame(const CamParams& cam, CamParams* dst, uint32_t* frame_words, uint32_t nwords, int32_t* slots, hipStream_t s)
 {
     static_assert(sizeof(CamParams) % 4 == 0, "camera is copied word by word");
-    hipLaunchKernelGGL(k_begin_frame, dim3(1), dim3(256), 0, s, cam, dst, frame_words, nwords);
+    hipLaunchKernelGGL(k_begin_frame, dim3(1), dim3(256), 0, s, cam, dst, frame_words, nwords, slots);
 }
 
 }  // namespace gsr

@@ -16,6 +16,15 @@ namespace gsr {
 
 constexpr int SORT_THREADS = 256;
 
+#ifdef GSR_KSTAMPS
+// Diagnostic build only: per-workgroup phase times of the two k_scatter passes (s_memrealtime ticks, 10 ns).
+__device__ unsigned int g_sort_stamps[2 * 4096 * 8];
+#define KSTAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_sort_stamps[((FIRST ? 0 : 1) * 4096 + blockIdx.x) * 8 + (slot)] = (unsigned int)__builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int gsr_debug_sort_stamps(unsigned int* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sort_stamps), sizeof g_sort_stamps) == hipSuccess ? 0 : -1; }
+#else
+#define KSTAMP(slot)
+#endif
+
 __device__ __forceinline__ uint32_t lanes_below(uint64_t mask)
 {
     // number of set bits of `mask` in lanes lower than this one (v_mbcnt)
@@ -40,22 +49,43 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t digit, bool valid)
 // A2: q = (uint32)((float)(uint32)(depth - minDepth) * depthInv), plus the
 // workgroup histogram of the pass-1 digit.
 //
-// Band mode (multi-GPU, `bbox` != null): a splat whose projected box is empty for this context's band (culled, or
+// The depth bounds arrive as the FRAME_SLOTS partial (min, max) pairs of k_project_key; every workgroup here folds
+// them itself (64 loads that hit L2) instead of waiting for a one-workgroup reduction kernel, and workgroup 0 stores
+// the result for read-backs.
+//
+// Band mode (multi-GPU, `cull`): a splat whose bin rectangle is empty for this context's band (culled, or
 // outside the band) gets the key 0xffffffff = "absent".  The first scatter drops absent keys, so everything after
 // it -- second radix pass, binning -- runs on the survivors only; their order is the restriction of the global
 // order, so the band's pixels are unchanged.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(SORT_THREADS) void k_quantise_hist(const int32_t* __restrict__ depth,
-                                                                const int32_t* __restrict__ minmax, uint32_t n,
-                                                                uint32_t keys_per_block, const uint2* __restrict__ bbox,
+                                                                const int32_t* __restrict__ slots,
+                                                                int32_t* __restrict__ minmax_out, uint32_t n,
+                                                                uint32_t keys_per_block, const uint32_t* __restrict__ rect, int cull,
                                                                 uint32_t* __restrict__ keys,
                                                                 uint32_t* __restrict__ block_hist)
 {
     __shared__ uint32_t h_lo[RADIX_LO_BINS];
+    __shared__ int32_t s_mm[2][SORT_THREADS / WAVE];
     for (int d = threadIdx.x; d < RADIX_LO_BINS; d += SORT_THREADS) h_lo[d] = 0;
+    // wasm.cpp:14-31's running min / max over ALL splats: fold the projection's per-workgroup pairs
+    int32_t mn = 0x7fffffff, mx = (int32_t)0x80000000;
+    if (threadIdx.x < FRAME_SLOTS) {
+        mn = slots[(size_t)threadIdx.x * FRAME_SLOT_WORDS];
+        mx = slots[(size_t)threadIdx.x * FRAME_SLOT_WORDS + 1];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = min(mn, __shfl_xor(mn, off));
+        mx = max(mx, __shfl_xor(mx, off));
+    }
+    if ((threadIdx.x & 63) == 0) { s_mm[0][threadIdx.x >> 6] = mn; s_mm[1][threadIdx.x >> 6] = mx; }
     __syncthreads();
+    int32_t minDepth = s_mm[0][0], maxDepth = s_mm[1][0];
+#pragma unroll
+    for (int w = 1; w < SORT_THREADS / WAVE; w++) { minDepth = min(minDepth, s_mm[0][w]); maxDepth = max(maxDepth, s_mm[1][w]); }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { minmax_out[0] = minDepth; minmax_out[1] = maxDepth; }
 
-    const int32_t minDepth = minmax[0], maxDepth = minmax[1];
     const bool degenerate = (maxDepth == minDepth);
     // wasm.cpp:34: (float)depthRange / (maxDepth - minDepth): int subtract, int->f32 RNE, f32 divide RNE
     const float depthInv = degenerate ? 0.0f : (float)DEPTH_RANGE / (float)(maxDepth - minDepth);
@@ -67,10 +97,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_quantise_hist(const int32_t* _
         const uint32_t rel = (uint32_t)depth[i] - (uint32_t)minDepth;
         uint32_t q = degenerate ? 0u : (uint32_t)((float)rel * depthInv);
         q = min(q, DEPTH_RANGE);
-        if (bbox) {
-            const uint32_t bx = bbox[i].x;
-            if ((bx & 0xffffu) > (bx >> 16)) q = 0xffffffffu;  // empty box: absent from this band's frame
-        }
+        if (cull && rect[i] == RECT_NONE) q = 0xffffffffu;  // nothing to draw in this band: absent from its frame
         keys[i] = q;
         if (q != 0xffffffffu) atomicAdd(&h_lo[q & (RADIX_LO_BINS - 1)], 1u);
     }
@@ -163,15 +190,31 @@ void launch_column_scan(uint32_t* table, uint32_t* total, int ncols, uint32_t nr
 }
 
 // ---------------------------------------------------------------------------
-// Stable scatter of one pass.  Workgroup = 16 waves over keys_per_block (2048) keys; wave w owns the w-th
-// sixteenth (contiguous, 2 steps of 64 keys), so the order of equal digits is: workgroup, then wave, then
-// step, then lane = input order.  Phase 1 counts per wave, phase 2 turns the counts into running destinations,
-// phase 3 ranks with ballot matching and scatters.  Sixteen waves (not four) because the pass is a chain of
-// dependent round trips: more waves in flight hide them.
+// Stable scatter of one pass.  Workgroup = 16 waves over keys_per_block keys (2048 .. 8192); wave w owns the w-th
+// sixteenth (contiguous, 2 .. 8 steps of 64 keys), so the order of equal digits is: workgroup, then wave, then step,
+// then lane = input order.
+//   phase 1  count digits per wave (LDS)
+//   phase 2  digit starts over all workgroups (scan of the column totals), this workgroup's run of every digit
+//            (from the scanned table), and the LOCAL layout: the workgroup's keys ordered by digit, wave, input order
+//   phase 3  rank with ballot matching and write (key, index) into LDS at the local position
+//   phase 4  stream the LDS image out: consecutive lanes hold consecutive local positions, so within a digit they store
+//            to consecutive addresses.
+// Phase 4 is what the pass is about.  Storing straight from phase 3 gave every lane of a wave its own destination
+// line: 64 cache lines per store instruction, and the address path -- not HBM -- set the kernel's time (in-kernel
+// stamps on C3: 4.4 of a workgroup's 7.1 us in the rank-and-store phase; at 20 M splats the pass reached 15 % of the
+// HBM roofline).  Staged, a store instruction covers one run per digit present among its 64 local positions:
+// keys_per_block / 2^BITS keys per run on average (8 for 2048 keys and 8 bits, 32 for 8192).  Larger scenes take
+// larger blocks (launch_sort) so that the runs are whole cache lines.
 // ---------------------------------------------------------------------------
 constexpr int SCAT_THREADS = 1024;
 constexpr int SCAT_WAVES = SCAT_THREADS / WAVE;
-constexpr int SCAT_MAX_STEPS = 4;  // keys_per_block <= SCAT_THREADS * SCAT_MAX_STEPS
+constexpr int SCAT_MAX_STEPS = 8;  // keys_per_block <= SCAT_THREADS * SCAT_MAX_STEPS = 8192
+
+template <int BITS>
+constexpr size_t scatter_lds_bytes(uint32_t keys_per_block)
+{
+    return (size_t)(SCAT_WAVES * (1 << BITS) + 2 * (1 << BITS) + 2 * ((1 << BITS) / WAVE) + 2 * keys_per_block) * sizeof(uint32_t);
+}
 
 template <int BITS, int SHIFT, bool FIRST>
 __global__ __launch_bounds__(SCAT_THREADS) void k_scatter(const uint32_t* __restrict__ keys_in,
@@ -182,87 +225,117 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter(const uint32_t* __rest
                                                           uint32_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out)
 {
     constexpr int BINS = 1 << BITS;
+    static_assert(BINS <= SCAT_THREADS, "one digit per thread");
     // the first pass reads all n_in keys (absent ones are skipped) and publishes how many it kept;
     // the second pass runs on that many
     const uint32_t n = FIRST ? n_in : *count;
-    __shared__ uint32_t cnt[SCAT_WAVES][BINS];
-    __shared__ uint32_t dstart[BINS];          // keys with a smaller digit, all workgroups
-    __shared__ uint32_t wsum[BINS / WAVE];
+    extern __shared__ uint32_t s_scat[];
+    uint32_t (*cnt)[BINS] = reinterpret_cast<uint32_t (*)[BINS]>(s_scat);   // [wave][digit]: counts, then local positions
+    uint32_t* gdelta = s_scat + SCAT_WAVES * BINS;   // [digit]: global destination of local position p is gdelta[digit] + p
+    uint32_t* lstart = gdelta + BINS;                // [digit]: first local position of the digit (phase 2 scratch)
+    uint32_t* wsum = lstart + BINS;                  // [2][BINS / WAVE]: per-wave sums of the two scans
+    uint32_t* lkey = wsum + 2 * (BINS / WAVE);       // [keys_per_block]
+    uint32_t* lidx = lkey + keys_per_block;          // [keys_per_block]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    KSTAMP(0);
+    // the two table reads of this workgroup do not depend on its keys: issued first
+    uint32_t tot = 0, wg_base = 0;
+    if (threadIdx.x < BINS) {
+        tot = total[threadIdx.x];
+        wg_base = base[(size_t)blockIdx.x * BINS + threadIdx.x];
+    }
     for (int d = threadIdx.x; d < SCAT_WAVES * BINS; d += SCAT_THREADS) (&cnt[0][0])[d] = 0;
     __syncthreads();
+    KSTAMP(1);
 
     const uint32_t per_wave = keys_per_block / SCAT_WAVES;  // multiple of 64
     const uint32_t steps = per_wave / WAVE;                 // <= SCAT_MAX_STEPS
     const uint32_t wbegin = blockIdx.x * keys_per_block + wave * per_wave;
     const uint32_t wend = min(wbegin + per_wave, n);
 
-    // phase 1: load this wave's keys (kept in registers) and count digits per wave
-    uint32_t key[SCAT_MAX_STEPS];
+    // phase 1: load this wave's keys (and, in the last pass, their indices) into registers; count digits per wave
+    uint32_t key[SCAT_MAX_STEPS], src[SCAT_MAX_STEPS];
 #pragma unroll
     for (int k = 0; k < SCAT_MAX_STEPS; k++) {
         const uint32_t i = wbegin + k * WAVE + lane;
-        key[k] = ((uint32_t)k < steps && i < wend) ? keys_in[i] : 0xffffffffu;
+        const bool in = (uint32_t)k < steps && i < wend;
+        key[k] = in ? keys_in[i] : 0xffffffffu;
+        src[k] = FIRST ? i : (in ? idx_in[i] : 0u);
     }
 #pragma unroll
     for (int k = 0; k < SCAT_MAX_STEPS; k++)
         if (key[k] != 0xffffffffu) atomicAdd(&cnt[wave][(key[k] >> SHIFT) & (BINS - 1)], 1u);
-    // digit starts: exclusive scan of total[0..BINS), one digit per thread on the first BINS threads
-    uint32_t tot = 0, incl = 0;
-    if (threadIdx.x < BINS) {
-        tot = total[threadIdx.x];
-        incl = tot;
-#pragma unroll
-        for (int off = 1; off < WAVE; off <<= 1) {
-            const uint32_t u = __shfl_up(incl, off);
-            if (lane >= off) incl += u;
-        }
-        if (lane == WAVE - 1) wsum[wave] = incl;
-    }
     __syncthreads();
+    KSTAMP(2);
+    // phase 2, one digit per thread: (a) cnt[w][d] -> keys of digit d in earlier waves, H = the workgroup's count;
+    // (b) two exclusive scans over the digits at once: the column totals (-> first destination of the digit over all
+    // workgroups) and H (-> first local position of the digit)
+    uint32_t H = 0, incl_t = 0, incl_h = 0;
     if (threadIdx.x < BINS) {
-        uint32_t run = incl - tot;
-        for (int w = 0; w < wave; w++) run += wsum[w];
-        dstart[threadIdx.x] = run;
-        if (FIRST && blockIdx.x == 0 && threadIdx.x == BINS - 1) *count = run + tot;
-    }
-    __syncthreads();
-    // phase 2: cnt[w][d] <- first destination of digit d for this workgroup + counts of earlier waves
-    for (int d = threadIdx.x; d < BINS; d += SCAT_THREADS) {
-        uint32_t run = dstart[d] + base[(size_t)blockIdx.x * BINS + d];
+        const int d = threadIdx.x;
 #pragma unroll
         for (int w = 0; w < SCAT_WAVES; w++) {
             const uint32_t c = cnt[w][d];
-            cnt[w][d] = run;
-            run += c;
+            cnt[w][d] = H;
+            H += c;
         }
+        incl_t = tot; incl_h = H;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const uint32_t u = __shfl_up(incl_t, off), v = __shfl_up(incl_h, off);
+            if (lane >= off) { incl_t += u; incl_h += v; }
+        }
+        if (lane == WAVE - 1) { wsum[wave] = incl_t; wsum[BINS / WAVE + wave] = incl_h; }
     }
     __syncthreads();
-    // phase 3: rank + scatter (cnt[wave][*] is private to this wave from here on)
-    uint32_t* wc = cnt[wave];
+    KSTAMP(3);
+    if (threadIdx.x < BINS) {
+        const int d = threadIdx.x;
+        uint32_t run_t = incl_t - tot, run_h = incl_h - H;
+        for (int w = 0; w < wave; w++) { run_t += wsum[w]; run_h += wsum[BINS / WAVE + w]; }
+        if (FIRST && blockIdx.x == 0 && d == BINS - 1) *count = run_t + tot;
+        lstart[d] = run_h;
+        gdelta[d] = run_t + wg_base - run_h;   // may wrap: only gdelta[d] + p is used
+    }
+    __syncthreads();
+    KSTAMP(4);
+    // phase 3: local position = digit start + keys of the digit in earlier waves + rank among this wave's earlier keys
+    uint32_t* wc = cnt[wave];   // private to this wave from here on
 #pragma unroll
     for (int k = 0; k < SCAT_MAX_STEPS; k++) {
         if ((uint32_t)k >= steps) break;  // wave-uniform
-        const uint32_t i = wbegin + k * WAVE + lane;
         const bool valid = key[k] != 0xffffffffu;
         const uint32_t digit = (key[k] >> SHIFT) & (BINS - 1);
         const uint64_t m = match_digit<BITS>(digit, valid);
         const uint32_t rank = lanes_below(m);
-        // All lanes read their digit's running destination, THEN the lowest lane of every group of
-        // equal digits advances it.  One wave, its own LDS words: LDS executes in order, and the
-        // wavefront-scope fences keep the compiler from moving the read below the write.
-        const uint32_t start = wc[valid ? digit : 0];
+        // All lanes read their digit's running count, THEN the lowest lane of every group of equal digits advances
+        // it.  One wave, its own LDS words: LDS executes in order, and the wavefront-scope fences keep the compiler
+        // from moving the read below the write.
+        const uint32_t before = wc[valid ? digit : 0];
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
-        if (valid && rank == 0) wc[digit] = start + (uint32_t)__popcll(m);
+        if (valid && rank == 0) wc[digit] = before + (uint32_t)__popcll(m);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
         if (valid) {
-            const uint32_t dst = start + rank;
-            if (keys_out) keys_out[dst] = key[k];
-            idx_out[dst] = FIRST ? i : idx_in[i];
+            const uint32_t p = lstart[digit] + before + rank;
+            lkey[p] = key[k];
+            lidx[p] = src[k];
         }
     }
+    __syncthreads();
+    // phase 4: the LDS image, in order, to its runs in global memory
+    const uint32_t nlocal = lstart[BINS - 1] + cnt[SCAT_WAVES - 1][BINS - 1];   // keys this workgroup holds (absent ones excluded)
+    for (uint32_t p = threadIdx.x; p < nlocal; p += SCAT_THREADS) {
+        const uint32_t kv = lkey[p];
+        const uint32_t dst = gdelta[(kv >> SHIFT) & (BINS - 1)] + p;
+        if (keys_out) keys_out[dst] = kv;
+        idx_out[dst] = lidx[p];
+    }
+#ifdef GSR_KSTAMPS
+    __syncthreads();
+    KSTAMP(5);
+#endif
 }
 
 void launch_sort(const SortBuffers& b, uint32_t n, hipStream_t s)
@@ -271,16 +344,31 @@ void launch_sort(const SortBuffers& b, uint32_t n, hipStream_t s)
     const dim3 grid(b.nblocks), block(SORT_THREADS);
     uint32_t* total_lo = b.digit_total;
     uint32_t* total_hi = b.digit_total + RADIX_LO_BINS;
-    hipLaunchKernelGGL(k_quantise_hist, grid, block, 0, s, b.depth, b.minmax, n, b.keys_per_block, b.cull_bbox, b.keys,
-                       b.block_hist);
+    const size_t lds_lo = scatter_lds_bytes<RADIX_LO_BITS>(b.keys_per_block), lds_hi = scatter_lds_bytes<RADIX_HI_BITS>(b.keys_per_block);
+    {   // the last pass needs more than the default 48 KiB of dynamic LDS even at 2048 keys: raise the limit once per
+        // device (the attribute belongs to the device's copy of the kernel), to what the largest block size needs
+        static unsigned done_mask = 0;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 0 && dev < 32 && !(done_mask & (1u << dev))) {
+            (void)hipFuncSetAttribute((const void*)k_scatter<RADIX_LO_BITS, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)scatter_lds_bytes<RADIX_LO_BITS>(SCAT_THREADS * SCAT_MAX_STEPS));
+            (void)hipFuncSetAttribute((const void*)k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)scatter_lds_bytes<RADIX_HI_BITS>(SCAT_THREADS * SCAT_MAX_STEPS));
+            (void)hipGetLastError();   // a failure shows up as the launch error
+            done_mask |= 1u << dev;
+        }
+    }
+    hipLaunchKernelGGL(k_quantise_hist, grid, block, 0, s, b.depth, b.slots, b.minmax, n, b.keys_per_block,
+                       b.rect, b.cull, b.keys, b.block_hist);
     launch_column_scan(b.block_hist, total_lo, RADIX_LO_BINS, b.nblocks, s);
-    hipLaunchKernelGGL((k_scatter<RADIX_LO_BITS, 0, true>), grid, dim3(SCAT_THREADS), 0, s, (const uint32_t*)b.keys,
+    hipLaunchKernelGGL((k_scatter<RADIX_LO_BITS, 0, true>), grid, dim3(SCAT_THREADS), lds_lo, s, (const uint32_t*)b.keys,
                        (const uint32_t*)nullptr, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
                        (const uint32_t*)total_lo, b.keys_tmp, b.idx_tmp);
     hipLaunchKernelGGL(k_hist_hi, grid, block, 0, s, (const uint32_t*)b.keys_tmp, (const uint32_t*)b.count, b.keys_per_block,
                        b.block_hist);
     launch_column_scan(b.block_hist, total_hi, RADIX_HI_BINS, b.nblocks, s);
-    hipLaunchKernelGGL((k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, false>), grid, dim3(SCAT_THREADS), 0, s, (const uint32_t*)b.keys_tmp,
+    hipLaunchKernelGGL((k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, false>), grid, dim3(SCAT_THREADS), lds_hi, s, (const uint32_t*)b.keys_tmp,
                        (const uint32_t*)b.idx_tmp, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
                        (const uint32_t*)total_hi, (uint32_t*)nullptr, b.depth_index);
 }
