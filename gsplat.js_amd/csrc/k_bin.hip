@@ -266,21 +266,28 @@ __global__ __launch_bounds__(FIN_THREADS) void k_bin_finalize(const uint32_t* __
 // latency hiding: the pass is a chain of dependent LDS / global round trips, not arithmetic.
 // ---------------------------------------------------------------------------
 constexpr int SCAT_THREADS = 1024;
-constexpr int SCAT_GROUPS = 4;                       // rank groups per workgroup (512 ranks each)
-constexpr int SCAT_WAVES_PER_GROUP = 4;
-constexpr int SCAT_STEPS_PER_WAVE = BIN_STEPS / SCAT_WAVES_PER_GROUP;  // 2
-static_assert(SCAT_GROUPS * BIN_STEPS * WAVE == (int)BIN_RANKS_PER_BLOCK, "scatter and count must cut the ranks alike");
-// Framebuffers above 4K: the LDS tables (12 B per bin + the lane sets) outgrow a CU's 160 KiB, so the bin grid is cut
-// into the fewest sub-grids that fit and blockIdx.y picks the sub-grid.  Every sub-grid workgroup reads the same
-// 2048 rectangles and places the entries of its own bins.  Up to 4K (8160 bins, 146 KiB) there is one sub-grid:
-// cutting earlier was measured slower (C4: 0.50 -> 0.66 ms for the binning), the per-workgroup fixed work dominates.
+constexpr int SCAT_WAVES = SCAT_THREADS / WAVE;               // 16 waves, each owns 2 steps of 64 ranks
+constexpr int SCAT_STEPS_PER_WAVE = 2;
+constexpr int SCAT_STEPS = SCAT_WAVES * SCAT_STEPS_PER_WAVE;  // 32 steps = 2048 ranks
+static_assert(SCAT_STEPS * WAVE == (int)BIN_RANKS_PER_BLOCK, "scatter and count must cut the ranks alike");
+// The ranks of a workgroup form GROUPS groups of consecutive steps.  A splat's slot needs the number of entries the
+// earlier steps of its group put into the bin -- one popcount of two LDS lane sets per earlier step -- plus the
+// group's offset, which costs 16 bits of LDS per (group, bin).  More groups = shorter step loops (the kernel is bound
+// by LDS instructions: ~11 reads per entry with 4 groups of 8 steps, ~6 with 8 groups of 4) but a larger table, so the
+// group count follows what fits: 8 groups at 1080p (64 KiB), 4 where the bin grid is large (4K: 146 KiB).
+//
+// Framebuffers above 4K: the LDS tables outgrow a CU's 160 KiB, so the bin grid is cut into the fewest sub-grids that
+// fit and blockIdx.y picks the sub-grid.  Every sub-grid workgroup reads the same 2048 rectangles and places the
+// entries of its own bins.  Up to 4K (8160 bins) there is one sub-grid: cutting earlier was measured slower (C4:
+// 0.50 -> 0.66 ms for the binning), the per-workgroup fixed work dominates.
 constexpr size_t SCAT_LDS_BUDGET = 150 * 1024;
+constexpr size_t SCAT_LDS_TWO_PER_CU = 72 * 1024;   // with at most this much, two workgroups share a CU
 
 struct BinSlices { int32_t sx, sy, w, h; };  // sx x sy sub-grids of w x h bins (the last ones may be smaller)
 
-inline size_t scatter_lds_bytes(int w, int h)
+inline size_t scatter_lds_bytes(int w, int h, int groups)
 {
-    return (size_t)((3 * w * h + 1) & ~1) * 4 + (size_t)SCAT_GROUPS * BIN_STEPS * (w + h) * 8;
+    return (size_t)(((1 + groups / 2) * w * h + 1) & ~1) * 4 + (size_t)SCAT_STEPS * (w + h) * 8;
 }
 
 inline BinSlices make_slices(int nbxb, int nby)
@@ -292,10 +299,11 @@ inline BinSlices make_slices(int nbxb, int nby)
             sl.sx = sx; sl.sy = t / sx;
             sl.w = (nbxb + sl.sx - 1) / sl.sx;
             sl.h = (nby + sl.sy - 1) / sl.sy;
-            if (scatter_lds_bytes(sl.w, sl.h) <= SCAT_LDS_BUDGET) return sl;
+            if (scatter_lds_bytes(sl.w, sl.h, 4) <= SCAT_LDS_BUDGET) return sl;
         }
 }
 
+template <int GROUPS>
 __global__ __launch_bounds__(SCAT_THREADS) void k_bin_scatter(const uint32_t* __restrict__ depth_index,
                                                               const uint32_t* __restrict__ rects,
                                                               const uint32_t* __restrict__ count, BinGrid g, BinSlices sl,
@@ -304,35 +312,38 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_bin_scatter(const uint32_t* __
                                                               uint32_t* __restrict__ list, uint32_t capacity,
                                                               uint32_t* __restrict__ overflow)
 {
+    constexpr int WAVES_PER_GROUP = SCAT_WAVES / GROUPS;            // 4 or 2
+    constexpr int GROUP_STEPS = SCAT_STEPS / GROUPS;                // 8 or 4
+    constexpr int PAIR_WORDS = GROUPS / 2;                          // two 16-bit per-group counts / offsets per word
     extern __shared__ uint32_t s_mem[];
     const uint32_t n = *count;
     const int nbxb = g.bx_hi - g.bx_lo, nbins = nbxb * g.nby;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int group = wave / SCAT_WAVES_PER_GROUP, sub = wave % SCAT_WAVES_PER_GROUP;
+    const int group = wave / WAVES_PER_GROUP, sub = wave % WAVES_PER_GROUP;
     // this workgroup's sub-grid: bin columns [sx0, sx1), rows [sy0, sy1) of the band
     const int sx0 = (int)(blockIdx.y % sl.sx) * sl.w, sx1 = min(sx0 + sl.w, nbxb);
     const int sy0 = (int)(blockIdx.y / sl.sx) * sl.h, sy1 = min(sy0 + sl.h, g.nby);
     const int sw = sx1 - sx0, sh = sy1 - sy0, nb_s = sw * sh;
-    // LDS: base[nb_s] (u32: the workgroup's first slot in each bin), pair[2][nb_s] (two 16-bit per-group
-    // counts/offsets per word: groups 0|1 and 2|3; a group holds 512 ranks, so 16 bits suffice), then the
-    // lane sets: per group, per step: [sw] column words + [sh] row words.  Sized for a full sl.w x sl.h sub-grid.
+    // LDS: base[nb_s] (u32: the workgroup's first slot in each bin), pair[PAIR_WORDS][nb_s] (16 bits per group: a group
+    // holds at most 512 ranks), then the lane sets: per step [sw] column words + [sh] row words.
+    // Sized for a full sl.w x sl.h sub-grid.
     const int cap_s = sl.w * sl.h;
     uint32_t* base = s_mem;
     uint32_t* pair = s_mem + cap_s;
     const int nmask = sl.w + sl.h;
-    unsigned long long* masks = reinterpret_cast<unsigned long long*>(s_mem + ((3 * cap_s + 1) & ~1));
-    unsigned long long* gmask = masks + (size_t)group * BIN_STEPS * nmask;   // step s of my group: gmask + s*nmask
+    unsigned long long* masks = reinterpret_cast<unsigned long long*>(s_mem + (((1 + PAIR_WORDS) * cap_s + 1) & ~1));
+    unsigned long long* gmask = masks + (size_t)group * GROUP_STEPS * nmask;   // step s of my group: gmask + s*nmask
     uint32_t* mypair = pair + (size_t)(group >> 1) * cap_s;
     const int myshift = (group & 1) * 16;
     KSTAMP(0);
 
-    for (int b = threadIdx.x; b < 2 * cap_s; b += SCAT_THREADS) pair[b] = 0;
-    for (int b = threadIdx.x; b < SCAT_GROUPS * BIN_STEPS * nmask; b += SCAT_THREADS) masks[b] = 0;
+    for (int b = threadIdx.x; b < PAIR_WORDS * cap_s; b += SCAT_THREADS) pair[b] = 0;
+    for (int b = threadIdx.x; b < SCAT_STEPS * nmask; b += SCAT_THREADS) masks[b] = 0;
     __syncthreads();
     KSTAMP(1);
 
     // this wave's 2 steps of 64 consecutive ranks; rectangles clipped to the sub-grid, in sub-grid coordinates
-    const uint32_t gbegin = blockIdx.x * BIN_RANKS_PER_BLOCK + group * (BIN_STEPS * WAVE);
+    const uint32_t gbegin = blockIdx.x * BIN_RANKS_PER_BLOCK + group * (GROUP_STEPS * WAVE);
     uint32_t idx[SCAT_STEPS_PER_WAVE];
     BinRect br[SCAT_STEPS_PER_WAVE];
 #pragma unroll
@@ -351,8 +362,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_bin_scatter(const uint32_t* __
         }
         br[k] = b;
     }
-    // the workgroup's first slot in every bin: two table reads that depend on nothing computed here, issued before
-    // the first barrier so that their round trip overlaps the rectangle loads and phase 1 (base[] is not touched there)
+    // the workgroup's first slot in every bin (base[] is not touched by phase 1, so no barrier is needed before it)
     for (int b = threadIdx.x; b < nb_s; b += SCAT_THREADS) {
         const int ly = b / sw, lx = b - ly * sw;
         const int gb = (sy0 + ly) * nbxb + sx0 + lx;  // the bin's index in the band
@@ -375,30 +385,43 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_bin_scatter(const uint32_t* __
     }
     __syncthreads();
     KSTAMP(3);
-    // phase 2: counts -> offsets of each group inside the workgroup's run
+    // phase 2: counts -> exclusive offsets of the groups inside the workgroup's run (16 bits each, in place)
     for (int b = threadIdx.x; b < nb_s; b += SCAT_THREADS) {
-        const uint32_t c01 = pair[b], c23 = pair[cap_s + b];
-        const uint32_t o1 = c01 & 0xffffu, o2 = o1 + (c01 >> 16), o3 = o2 + (c23 & 0xffffu);
-        pair[b] = o1 << 16;                // group 0: 0, group 1: o1
-        pair[cap_s + b] = o2 | (o3 << 16); // group 2: o2, group 3: o3
+        uint32_t run = 0;
+#pragma unroll
+        for (int wd = 0; wd < PAIR_WORDS; wd++) {
+            const uint32_t c = pair[wd * cap_s + b];
+            const uint32_t lo = run, hi = run + (c & 0xffffu);
+            run = hi + (c >> 16);
+            pair[wd * cap_s + b] = lo | (hi << 16);
+        }
     }
     __syncthreads();
     KSTAMP(4);
     // phase 3: slots.  The set of lanes of step s covering bin (X,Y) is col[s][X] & row[s][Y]; a splat's slot is
     // base[bin] + its group's offset + the sizes of the sets of the group's earlier steps + the number of
     // lower lanes in its own step's set: input order, from ballot-style arithmetic on LDS words that are
-    // read-only by now (no ordered atomics, no running counter).
+    // read-only by now (no ordered atomics, no running counter).  The row sets of a box row are read once per row.
 #pragma unroll
     for (int k = 0; k < SCAT_STEPS_PER_WAVE; k++) {
         const BinRect b = br[k];
         const int st = sub * SCAT_STEPS_PER_WAVE + k;
         const uint32_t myidx = idx[k];
         for (int y = b.y0; y <= b.y1; y++) {
+            unsigned long long rowm[GROUP_STEPS];
+#pragma unroll
+            for (int e = 0; e < GROUP_STEPS; e++) rowm[e] = (e <= st) ? gmask[e * nmask + sl.w + y] : 0ull;
             for (int x = b.x0; x <= b.x1; x++) {
                 uint32_t dst = base[y * sw + x] + ((mypair[y * sw + x] >> myshift) & 0xffffu);
-                for (int e = 0; e < st; e++)  // entries the earlier steps of this group put into the bin
-                    dst += (uint32_t)__popcll(gmask[e * nmask + x] & gmask[e * nmask + sl.w + y]);
-                dst += lanes_below64(gmask[st * nmask + x] & gmask[st * nmask + sl.w + y]);
+                unsigned long long own = 0ull;
+#pragma unroll
+                for (int e = 0; e < GROUP_STEPS; e++) {
+                    if (e > st) continue;                                 // wave-uniform
+                    const unsigned long long m = gmask[e * nmask + x] & rowm[e];
+                    if (e < st) dst += (uint32_t)__popcll(m);             // entries the earlier steps of this group put into the bin
+                    else own = m;
+                }
+                dst += lanes_below64(own);
                 if (dst < capacity) list[dst] = myidx;
                 else atomicOr(overflow, 1u);
             }
@@ -415,13 +438,16 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
     const int nbxb = g.bx_hi - g.bx_lo, nbins = nbxb * g.nby;
     if (nbins <= 0) return;
     const BinSlices sl = make_slices(nbxb, g.nby);
-    const size_t lds = scatter_lds_bytes(sl.w, sl.h);
+    // 8 groups of 4 steps where their table still lets two workgroups share a CU, else 4 groups of 8 steps
+    const bool eight = scatter_lds_bytes(sl.w, sl.h, 8) <= SCAT_LDS_TWO_PER_CU;
+    const size_t lds = scatter_lds_bytes(sl.w, sl.h, eight ? 8 : 4);
     // dynamic LDS above the 64 KiB default needs the attribute raised (4K: 8160 bins -> 146 KiB).  Set per call:
     // the attribute belongs to the current device's copy of the kernel, and this is off the per-frame fast path
-    // (1080p needs 49 KiB).
+    // for the common sizes (1080p needs 64 KiB).
     if (lds > 60 * 1024) {
         const int want = (int)std::min<size_t>(lds + 1024, 160 * 1024 - 256);
-        if (hipFuncSetAttribute((const void*)k_bin_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess)
+        const void* fn = eight ? (const void*)k_bin_scatter<8> : (const void*)k_bin_scatter<4>;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess)
             (void)hipGetLastError();  // the launch below then reports the real failure
     }
     // the count pass keeps one counter per bin in LDS and is cut into row slices only beyond 12288 bins (above 4K)
@@ -436,10 +462,16 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
                        b.seg_target_items, b.items_by_size, b.seg_len_dev, b.max_items, b.capacity, b.slots, n ? 1u : 0u,
                        b.bin_start, b.seg_start, b.items, b.overflow, b.visible, b.tile_entries, b.accum, b.report, b.queue, b.queue_start,
                        b.mailbox);
-    if (n)
-        hipLaunchKernelGGL(k_bin_scatter, dim3(b.nblocks, sl.sx * sl.sy), dim3(SCAT_THREADS), lds, s, b.depth_index,
-                           (const uint32_t*)b.rects, b.count, g, sl, (const uint32_t*)b.table, (const uint32_t*)b.bin_start, b.list,
-                           b.capacity, b.overflow);
+    if (n) {
+        if (eight)
+            hipLaunchKernelGGL(k_bin_scatter<8>, dim3(b.nblocks, sl.sx * sl.sy), dim3(SCAT_THREADS), lds, s, b.depth_index,
+                               (const uint32_t*)b.rects, b.count, g, sl, (const uint32_t*)b.table, (const uint32_t*)b.bin_start, b.list,
+                               b.capacity, b.overflow);
+        else
+            hipLaunchKernelGGL(k_bin_scatter<4>, dim3(b.nblocks, sl.sx * sl.sy), dim3(SCAT_THREADS), lds, s, b.depth_index,
+                               (const uint32_t*)b.rects, b.count, g, sl, (const uint32_t*)b.table, (const uint32_t*)b.bin_start, b.list,
+                               b.capacity, b.overflow);
+    }
 }
 
 }  // namespace gsr

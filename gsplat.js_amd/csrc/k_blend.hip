@@ -44,8 +44,14 @@ constexpr float LOG2E = 1.4426950408889634f;
 // [11] its entries, [12] its entry visits, [13] its bin.  Never compiled into the shipped library.
 __device__ unsigned int g_blend_stamps[4096 * 4 * 16];
 #define STAMP(v) const unsigned int v = (unsigned int)__builtin_readcyclecounter()
+#ifdef GSR_BLEND_COUNT_QUADS   // slow: counts visited quadrants, those without a covered pixel, and covered pixels
+#define GSR_COUNT_QUAD(q) { const unsigned long long cb_ = __ballot((q) <= 4.0f); a_quads++; a_empty += cb_ == 0ull; a_cov += __popcll(cb_); }
+#else
+#define GSR_COUNT_QUAD(q)
+#endif
 #else
 #define STAMP(v)
+#define GSR_COUNT_QUAD(q)
 #endif
 
 // 7 waves per SIMD: the kernel needs 74 VGPRs unconstrained (6 waves); capped at 72 it spills one register pair that is
@@ -79,6 +85,7 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
     // kernel start with ~2000 workgroups drawing from one counter serialises ~2000 same-address atomics.
 #ifdef GSR_BLEND_STAMPS
     unsigned int a_waitA = 0, a_stage = 0, a_waitB = 0, a_comp = 0, a_entries = 0;
+    unsigned int a_quads = 0, a_empty = 0, a_cov = 0;
     unsigned int a_items = 0, a_last_start = 0, a_max_dur = 0, a_max_len = 0, a_max_vis = 0, a_max_bin = 0, a_item_t0 = 0, a_item_vis0 = 0, a_item_len = 0, a_item_bin = 0;
     const unsigned int t_kernel0 = (unsigned int)__builtin_readcyclecounter();
     const unsigned int t_real0 = (unsigned int)__builtin_amdgcn_s_memrealtime();
@@ -192,6 +199,7 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
     if (qm & (BIT)) {                                                                              \
         const float vx_ = __builtin_fmaf(ux, (PX), (UR)), vy_ = __builtin_fmaf(wx, (PX), (WR));    \
         const float q_ = __builtin_fmaf(vy_, vy_, vx_ * vx_);                                      \
+        GSR_COUNT_QUAD(q_)                                                                         \
         if (q_ <= 4.0f) {                                                                          \
             const float w_ = (T) * __builtin_amdgcn_exp2f(__builtin_fmaf(q_, -LOG2E, la));         \
             (T) = (T) - w_;                                                                        \
@@ -284,6 +292,11 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
         o[0] = (unsigned int)__builtin_readcyclecounter() - t_kernel0; o[1] = a_waitA; o[2] = a_stage; o[3] = a_waitB; o[4] = a_comp;
         o[5] = t_real0; o[6] = (unsigned int)__builtin_amdgcn_s_memrealtime(); o[7] = a_entries;
         o[8] = a_items; o[9] = a_last_start; o[10] = a_max_dur; o[11] = a_max_len; o[12] = a_max_vis; o[13] = a_max_bin;
+#ifdef GSR_BLEND_COUNT_QUADS
+        o[1] = a_quads; o[2] = a_empty; o[3] = a_cov;
+#else
+        (void)a_quads; (void)a_empty; (void)a_cov;
+#endif
     }
 #endif
 }

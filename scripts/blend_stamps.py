@@ -32,6 +32,12 @@ v = v[v[:, 0] > 0]
 life = v[:, 0]
 print("%s %s: one frame, k_blend %.1f us (with stamps); %d waves; wave lifetime mean %.0f / max %.0f cycles"
       % (name, config, st["sum_ms_blend"] / max(1, st["frames"]) * 1e3, len(v), life.mean(), life.max()))
+if os.environ.get("COUNT_QUADS") == "1":
+    q, e, c = v[:, 1].sum(), v[:, 2].sum(), v[:, 3].sum()
+    print("quadrant visits %.4g, without a covered pixel %.4g (%.1f %%), covered pixels %.4g = %.1f %% of the lanes of visited quadrants, %.1f %% of the non-empty ones; entry visits %.4g (%.2f quadrants per visit)"
+          % (q, e, 100 * e / q, c, 100 * c / (64 * q), 100 * c / (64 * (q - e)), v[:, 7].sum(), q / v[:, 7].sum()))
+    r.dispose()
+    sys.exit(0)
 tot = life.sum()
 names = ["barrier A (chunk start)", "staging", "barrier B (staged)", "composite loop"]
 for k, nm in enumerate(names):
