@@ -597,8 +597,10 @@ int alloc_scene(gsr_ctx* c, uint32_t n, bool with_rows)
         return r;
     if (with_rows && ((r = dev_alloc(c, &c->rotv, n)) || (r = dev_alloc(c, &c->sclv, n)))) return r;
     // keys per radix workgroup: the scatter stores runs of keys_per_block / 2^bits keys, so larger scenes take larger
-    // blocks (whole cache lines per run) while small ones keep enough workgroups to fill the chip
-    c->sort_kpb = n <= (3u << 20) ? 2048 : n <= (12u << 20) ? 4096 : 8192;
+    // blocks (longer runs) while small ones keep enough workgroups to fill the chip.  Measured at 20 M splats, the two
+    // scatters: 135 + 126 us with 2048 keys, 99 + 98 us with 4096, 113 + 116 us with 8192 (96 KiB of LDS: one
+    // workgroup per CU, nothing overlaps its load and store phases).
+    c->sort_kpb = n <= (3u << 20) ? 2048 : 4096;
     if (const char* e = getenv("GSR_SORT_KPB")) {   // tuning knob: 2048, 4096 or 8192
         const long v = atol(e);
         if (v == 2048 || v == 4096 || v == 8192) c->sort_kpb = (uint32_t)v;
