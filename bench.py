@@ -426,12 +426,12 @@ def main():
                              "note": "event pairs around k_blend while other frames' kernels share the GPU: overlap-inflated"},
                          "note": "the compositor is bound by VALU issue and wave stalls (barriers, LDS reads), not by HBM "
                                  "(SURVEY 8(d) honest note); see valu and DESIGN.md section 8"},
-            # secondary ceiling: VALU issue.  peak = what tools/valu_peak.hip sustains on this chip for the compositor's
+            # secondary ceiling: VALU issue.  peak = what tools/valu_cost.hip sustains on this chip for the compositor's
             # own instruction mix (11 VALU of a covered quadrant incl. v_exp_f32 and v_pk_fma_f32, operands in VGPRs,
-            # 8 waves/SIMD): 0.667e12 wave-instr/s (profiles/r01_valu_peak_mi355x.txt); plain v_fma_f32 sustains 0.623e12
+            # 7 waves/SIMD like k_blend, wall clock): 0.651e12 wave-instr/s (profiles/r02_valu_cost4.txt)
             "valu": None if not (valu_solo if solo else valu) or not blend_ms else (lambda t_ms, v: {
                 "wave_instr_per_launch": v, "launch_ms": t_ms, "achieved_wave_instr_per_s": v / (t_ms * 1e-3),
-                "peak_wave_instr_per_s": 0.667e12, "frac": v / (t_ms * 1e-3) / 0.667e12})(blend_ms, valu_solo if solo else valu),
+                "peak_wave_instr_per_s": 0.651e12, "frac": v / (t_ms * 1e-3) / 0.651e12})(blend_ms, valu_solo if solo else valu),
             "overflow_frames": overflow_frames, "dropped_frames": dropped_frames,
             "build_id": gh.build_id(),
             "stage_roofline": {

@@ -20,8 +20,13 @@
  *                                 this container (no GL, no GPU) and its repo
  *                                 holds no test images.  These functions restate
  *                                 vertex.glsl.ts / frag.glsl.ts / the GL blend
- *                                 state line by line; known-answer tests in
- *                                 tests/test_oracle_render.py check closed forms.
+ *                                 state line by line.  What stands in for a pin:
+ *                                 tests/independent_math.py, a float64 statement
+ *                                 of the MATHEMATICS (numpy linear algebra, no
+ *                                 shared operation sequence with this file),
+ *                                 checked on off-axis, rotated, anisotropic
+ *                                 splats (tests/test_oracle_render.py), plus
+ *                                 closed-form known-answer tests.
  *
  * Build: gcc -O2 -ffp-contract=off -fPIC -shared (see oracle/Makefile).
  * -ffp-contract=off is REQUIRED: FMA contraction changes the sort result
