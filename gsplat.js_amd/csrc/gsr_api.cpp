@@ -80,12 +80,15 @@ struct gsr_ctx {
     uint32_t seg_target_items = 5000;
     uint32_t timing_every = 1, frame_no = 0;
     bool sort_culled = false;  // the last sort kept only the band's survivors (depth_index / keys are partial)
+    bool bucket_order_now = false;  // sort order of the frame being enqueued (part of the graph signature)
     // frame words
     FrameState* fstate = nullptr;       // device
     FrameState* fstate_host = nullptr;  // pinned
     uint64_t* accum = nullptr;          // device [8]: sums over frames (visible, bin entries, tile entries, frames), [4] entries of
                                         // the last frame, sticky [5] frames that did not fit, [6]/[7] most entries/items one needed
-    uint64_t* mailbox = nullptr;        // pinned host word the device stores accum[5] into (k_bin_finalize)
+    uint64_t* mailbox = nullptr;        // pinned host words the device stores into: [0] accum[5] (k_bin_finalize), [1] low half: keys in the
+                                        // largest high-digit bucket of the last sorted frame (k_local_sort / last LSD pass)
+    int sort_order = -1;                // -1: chosen per frame from the reported bucket size; 0: always LSD; 1: always bucket order
     uint64_t* mailbox_dev = nullptr;    // its device address
     uint64_t overflow_seen = 0;         // accum[5] as of the last regrowth
     uint64_t overflow_frames = 0;       // frames that did not fit, since the context was created
@@ -198,6 +201,22 @@ constexpr uint32_t BLEND_WG_PER_CU_EXACT = 7;
 constexpr uint32_t BLEND_WG_PER_CU_THROUGHPUT = 6;  // leaves room for the other contexts' kernels
 constexpr uint32_t SEG_LEN_WHOLE_BIN = 0x7fffff00u;
 
+// Sort order.  Up to BUCKET_ORDER_MAX_N splats the radix sort runs high digit first with one workgroup per bucket
+// (four launches, k_sort.hip) -- unless the last sorted frame reported a bucket above LOCAL_BUCKET_LIMIT keys: depth
+// outliers stretch the key range and can put most of a scene into one bucket, which would serialise in its workgroup.
+// Then, for the first frame of a scene, and above BUCKET_ORDER_MAX_N (the average bucket alone needs several chunks)
+// it runs the LSD order (six launches).  Same permutation either way.  GSR_SORT_ORDER=lsd|bucket pins it.
+constexpr uint32_t BUCKET_ORDER_MAX_N = 3u << 20;
+constexpr uint32_t LOCAL_BUCKET_LIMIT = 48u << 10;
+
+inline bool use_bucket_order(const gsr_ctx* c)
+{
+    if (c->sort_order >= 0) return c->sort_order == 1;
+    if (c->n > BUCKET_ORDER_MAX_N) return false;
+    const uint32_t largest = reinterpret_cast<volatile const uint32_t*>(c->mailbox)[2];   // low half of mailbox[1]
+    return largest <= LOCAL_BUCKET_LIMIT;   // 0xffffffff until a frame of this scene has reported
+}
+
 int alloc_bins(gsr_ctx* c)
 {
     if (!c->W) return GSR_OK;
@@ -281,7 +300,8 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
         // touches the band; the full depthIndex is produced on demand (gsr_read_depth_index)
         const bool cull = render && band_is_partial(c);
         SortBuffers sb{c->depth, c->slots, c->fstate->minmax, c->keys, c->keys_tmp, c->idx_tmp, c->depth_index,
-                       c->block_hist, c->fstate->digit_total, c->rect_idx, cull ? 1 : 0, &c->fstate->sorted_count, c->sort_kpb, c->sort_blocks};
+                       c->block_hist, c->fstate->digit_total, c->rect_idx, cull ? 1 : 0, &c->fstate->sorted_count, c->sort_kpb, c->sort_blocks,
+                       c->bucket_order_now ? 1 : 0, reinterpret_cast<uint32_t*>(c->mailbox_dev + 1)};
         c->sort_culled = cull;
         launch_sort(sb, c->n, s);
     }
@@ -327,7 +347,7 @@ static std::vector<uint64_t> chain_signature(const gsr_ctx* c)
     P(c->items); P(c->bin_list); P(c->partial); P(c->fb); P(c->accum); P(c->cam_dev);
     U(c->n); U((uint64_t)c->W); U((uint64_t)c->H); U((uint64_t)g.bx_lo); U((uint64_t)g.bx_hi); U(c->sort_kpb); U(c->sort_blocks);
     U(c->bin_capacity); U(c->max_items); U(c->seg_len); U(c->seg_target_items); U(c->blend_grid); U(c->bin_blocks);
-    U((uint64_t)c->opt.flags); U((uint64_t)(c->opt.early_out_eps * 1e9f));
+    U((uint64_t)c->opt.flags); U((uint64_t)(c->opt.early_out_eps * 1e9f)); U(c->bucket_order_now ? 1u : 0u);
     return v;
 }
 
@@ -362,6 +382,7 @@ int enqueue_frame(gsr_ctx* c, bool render)
         c->cam.band_px0 = bg.bx_lo * BIN_PX;
         c->cam.band_px1 = bg.bx_hi * BIN_PX;
     }
+    c->bucket_order_now = use_bucket_order(c);
     c->cam.sh_on = c->sh_count ? 1 : 0;
     c->cam.band[0] = c->band[0]; c->cam.band[1] = c->band[1]; c->cam.band[2] = c->band[2];
     static_assert(offsetof(FrameState, minmax) == 0 && sizeof(FrameState) % 4 == 0, "k_begin_frame resets the frame words");
@@ -524,6 +545,8 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
     CREATE_TRY(hipMemset(c->accum, 0, 8 * sizeof(uint64_t)));
     CREATE_TRY(hipHostMalloc((void**)&c->mailbox, 64, hipHostMallocMapped));
     memset(c->mailbox, 0, 64);
+    reinterpret_cast<uint32_t*>(c->mailbox)[2] = 0xffffffffu;   // no frame has reported its largest bucket yet
+    if (const char* e = getenv("GSR_SORT_ORDER")) c->sort_order = !strcmp(e, "lsd") ? 0 : !strcmp(e, "bucket") ? 1 : -1;
     CREATE_TRY(hipHostGetDevicePointer((void**)&c->mailbox_dev, c->mailbox, 0));
     CREATE_TRY(hipHostMalloc((void**)&c->fstate_host, sizeof(FrameState), hipHostMallocDefault));
     memset(c->fstate_host, 0, sizeof(FrameState));
@@ -584,6 +607,7 @@ namespace {
 int alloc_scene(gsr_ctx* c, uint32_t n, bool with_rows)
 {
     c->n = 0; c->have_frame = false; c->have_sort = false; c->have_rows = false;
+    if (c->mailbox) reinterpret_cast<volatile uint32_t*>(c->mailbox)[2] = 0xffffffffu;   // a new scene: LSD order until a frame reports
     c->sh_count = 0; c->band[0] = c->band[1] = c->band[2] = -1;
     dev_free(&c->sh_r); dev_free(&c->sh_g); dev_free(&c->sh_b); dev_free(&c->shcol);
     dev_free(&c->rotv); dev_free(&c->sclv);

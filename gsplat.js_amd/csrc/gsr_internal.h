@@ -119,6 +119,8 @@ struct SortBuffers {
     uint32_t* count;           // out: keys the first pass kept (n, or the band's survivors) = entries of depth_index
     uint32_t keys_per_block;
     uint32_t nblocks;
+    int bucket_order;          // 1: high digit first + one workgroup per bucket (4 launches); 0: LSD (6 launches); see k_sort.hip
+    uint32_t* max_bucket;      // out: keys in the frame's largest high-digit bucket (host-mapped word)
 };
 void launch_sort(const SortBuffers& b, uint32_t n, hipStream_t s);
 // column scan (k_sort.hip), shared with the binning

@@ -63,11 +63,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_quantise_hist(const int32_t* _
                                                                 int32_t* __restrict__ minmax_out, uint32_t n,
                                                                 uint32_t keys_per_block, const uint32_t* __restrict__ rect, int cull,
                                                                 uint32_t* __restrict__ keys,
-                                                                uint32_t* __restrict__ block_hist)
+                                                                uint32_t* __restrict__ block_hist, int hist_shift, int hist_bins)
 {
-    __shared__ uint32_t h_lo[RADIX_LO_BINS];
+    // the histogram is over the digit of the FIRST scatter pass: the low 8 bits (LSD order) or the high 9 (bucket order)
+    __shared__ uint32_t h_lo[RADIX_HI_BINS];
     __shared__ int32_t s_mm[2][SORT_THREADS / WAVE];
-    for (int d = threadIdx.x; d < RADIX_LO_BINS; d += SORT_THREADS) h_lo[d] = 0;
+    for (int d = threadIdx.x; d < hist_bins; d += SORT_THREADS) h_lo[d] = 0;
     // wasm.cpp:14-31's running min / max over ALL splats: fold the projection's per-workgroup pairs
     int32_t mn = 0x7fffffff, mx = (int32_t)0x80000000;
     if (threadIdx.x < FRAME_SLOTS) {
@@ -99,10 +100,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_quantise_hist(const int32_t* _
         q = min(q, DEPTH_RANGE);
         if (cull && rect[i] == RECT_NONE) q = 0xffffffffu;  // nothing to draw in this band: absent from its frame
         keys[i] = q;
-        if (q != 0xffffffffu) atomicAdd(&h_lo[q & (RADIX_LO_BINS - 1)], 1u);
+        if (q != 0xffffffffu) atomicAdd(&h_lo[(q >> hist_shift) & (uint32_t)(hist_bins - 1)], 1u);
     }
     __syncthreads();
-    for (int d = threadIdx.x; d < RADIX_LO_BINS; d += SORT_THREADS) block_hist[(size_t)blockIdx.x * RADIX_LO_BINS + d] = h_lo[d];
+    for (int d = threadIdx.x; d < hist_bins; d += SORT_THREADS) block_hist[(size_t)blockIdx.x * hist_bins + d] = h_lo[d];
 }
 
 // Workgroup histogram of the pass-2 digit over the pass-1 output order.
@@ -215,7 +216,7 @@ constexpr int SCAT_MAX_STEPS = 8;  // keys_per_block <= SCAT_THREADS * SCAT_MAX_
 template <int BITS>
 constexpr size_t scatter_lds_bytes(uint32_t keys_per_block)
 {
-    return (size_t)(SCAT_WAVES * (1 << BITS) + 2 * (1 << BITS) + 2 * ((1 << BITS) / WAVE) + 2 * keys_per_block) * sizeof(uint32_t);
+    return (size_t)(SCAT_WAVES * (1 << BITS) + 2 * (1 << BITS) + 3 * ((1 << BITS) / WAVE) + 2 * keys_per_block) * sizeof(uint32_t);
 }
 
 template <int BITS, int SHIFT, bool FIRST>
@@ -224,7 +225,8 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter(const uint32_t* __rest
                                                           uint32_t* __restrict__ count,
                                                           uint32_t keys_per_block, const uint32_t* __restrict__ base,
                                                           const uint32_t* __restrict__ total,
-                                                          uint32_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out)
+                                                          uint32_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out,
+                                                          uint32_t* __restrict__ max_bucket)
 {
     constexpr int BINS = 1 << BITS;
     static_assert(BINS <= SCAT_THREADS, "one digit per thread");
@@ -235,8 +237,8 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter(const uint32_t* __rest
     uint32_t (*cnt)[BINS] = reinterpret_cast<uint32_t (*)[BINS]>(s_scat);   // [wave][digit]: counts, then local positions
     uint32_t* gdelta = s_scat + SCAT_WAVES * BINS;   // [digit]: global destination of local position p is gdelta[digit] + p
     uint32_t* lstart = gdelta + BINS;                // [digit]: first local position of the digit (phase 2 scratch)
-    uint32_t* wsum = lstart + BINS;                  // [2][BINS / WAVE]: per-wave sums of the two scans
-    uint32_t* lkey = wsum + 2 * (BINS / WAVE);       // [keys_per_block]
+    uint32_t* wsum = lstart + BINS;                  // [3][BINS / WAVE]: per-wave sums of the two scans, per-wave maxima of the totals
+    uint32_t* lkey = wsum + 3 * (BINS / WAVE);       // [keys_per_block]
     uint32_t* lidx = lkey + keys_per_block;          // [keys_per_block]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     KSTAMP(0);
@@ -288,8 +290,19 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter(const uint32_t* __rest
             if (lane >= off) { incl_t += u; incl_h += v; }
         }
         if (lane == WAVE - 1) { wsum[wave] = incl_t; wsum[BINS / WAVE + wave] = incl_h; }
+        if (max_bucket && blockIdx.x == 0) {   // the largest high-digit bucket of the frame, for the host's choice of sort order
+            uint32_t mx = tot;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
+            if (lane == 0) wsum[2 * (BINS / WAVE) + wave] = mx;
+        }
     }
     __syncthreads();
+    if (max_bucket && blockIdx.x == 0 && threadIdx.x == 0) {
+        uint32_t mx = 0;
+        for (int w = 0; w < BINS / WAVE; w++) mx = max(mx, wsum[2 * (BINS / WAVE) + w]);
+        *max_bucket = mx;   // plain store: the word is host-mapped (no atomics on it)
+    }
     KSTAMP(3);
     if (threadIdx.x < BINS) {
         const int d = threadIdx.x;
@@ -340,6 +353,151 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter(const uint32_t* __rest
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// Bucket order (small scenes): the first pass partitions by the HIGH 9 bits (k_scatter<9, 8, true>, histogram taken in
+// k_quantise_hist), which leaves 257 contiguous buckets in index order; k_local_sort then sorts every bucket stably by
+// the low 8 bits.  Same permutation as the LSD order (ascending key, ties by index), but four launches instead of
+// six: no second histogram, no second column scan.
+//
+// One workgroup per LOCAL_CHUNK keys of a bucket, and no communication between workgroups: a workgroup counts the
+// digits of its whole bucket itself (the bucket's digit starts) and of the chunks in front of its own (its offset
+// inside every digit) -- a redundant read of the bucket, which sits in L2 -- then ranks its chunk exactly like
+// k_scatter does and places it.  The redundant counting is quadratic in the bucket size, so a bucket holding most of
+// the scene (depth outliers stretch the key range) is slow this way: every frame reports its largest bucket to the
+// host, which falls back to the LSD order while that exceeds LOCAL_BUCKET_LIMIT (gsr_api.cpp).
+// ---------------------------------------------------------------------------
+constexpr int LOCAL_THREADS = 1024;
+constexpr int LOCAL_WAVES = LOCAL_THREADS / WAVE;
+constexpr int LOCAL_STEPS = 4;                                    // 64-key steps per wave
+constexpr uint32_t LOCAL_CHUNK = LOCAL_THREADS * LOCAL_STEPS;     // 4096 keys per workgroup
+inline uint32_t local_sort_grid(uint32_t n) { return (n + LOCAL_CHUNK - 1) / LOCAL_CHUNK + RADIX_HI_BINS / 2 + 1; }   // >= sum over buckets of ceil(size / chunk)
+// (a 2-D grid -- chunk x bucket, bucket starts handed over by the partition pass, no search -- was measured slower:
+//  3084 mostly empty 1024-thread workgroups cost more to dispatch than the search saves: 13.7 -> 21.0 us on C3)
+
+__global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ idx,
+                                                              const uint32_t* __restrict__ total_hi,
+                                                              uint32_t* __restrict__ depth_index, uint32_t* __restrict__ max_bucket)
+{
+    constexpr int BINS = RADIX_LO_BINS;
+    __shared__ uint32_t cnt[LOCAL_WAVES][BINS];   // per wave: counts of my chunk, then keys of the digit in earlier waves
+    __shared__ uint32_t tot[BINS];                // digit counts of the bucket behind my chunk, then the digit's first position
+    __shared__ uint32_t bef[BINS];                // digit counts of the chunks in front of mine
+    __shared__ uint32_t wsum[BINS / WAVE];
+    __shared__ uint32_t s_scan[2][LOCAL_WAVES];
+    __shared__ uint32_t s_max[LOCAL_WAVES];
+    __shared__ uint32_t s_pick[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // which (bucket, chunk) am I?  Buckets in order, ceil(size / LOCAL_CHUNK) workgroups each: an inclusive scan of the
+    // chunk counts over the 512 bucket slots (one per thread on the first 512 threads), then the slot that contains my id
+    const uint32_t t = threadIdx.x < RADIX_HI_BINS ? total_hi[threadIdx.x] : 0u;
+    const uint32_t nch = (t + LOCAL_CHUNK - 1) / LOCAL_CHUNK;
+    uint32_t inc_c = nch, inc_k = t, mx = t;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const uint32_t a = __shfl_up(inc_c, off), b2 = __shfl_up(inc_k, off);
+        if (lane >= off) { inc_c += a; inc_k += b2; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
+    if (lane == WAVE - 1) { s_scan[0][wave] = inc_c; s_scan[1][wave] = inc_k; }
+    if (lane == 0) s_max[wave] = mx;
+    for (int d = threadIdx.x; d < LOCAL_WAVES * BINS; d += LOCAL_THREADS) (&cnt[0][0])[d] = 0;
+    if (threadIdx.x < BINS) { tot[threadIdx.x] = 0; bef[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) s_pick[0] = 0xffffffffu;
+    __syncthreads();
+    uint32_t base_c = 0, base_k = 0;
+    for (int w = 0; w < wave; w++) { base_c += s_scan[0][w]; base_k += s_scan[1][w]; }
+    inc_c += base_c; inc_k += base_k;                      // inclusive over all earlier buckets
+    if (threadIdx.x < RADIX_HI_BINS && nch && blockIdx.x >= inc_c - nch && blockIdx.x < inc_c) {
+        s_pick[0] = threadIdx.x;                           // my bucket
+        s_pick[1] = blockIdx.x - (inc_c - nch);            // my chunk inside it
+        s_pick[2] = inc_k - t;                             // first key of the bucket
+        s_pick[3] = t;                                     // its size
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && max_bucket && threadIdx.x == 0) {   // the frame's largest bucket, for the host's choice of sort order
+        uint32_t m2 = 0;
+        for (int w = 0; w < RADIX_HI_BINS / WAVE; w++) m2 = max(m2, s_max[w]);
+        *max_bucket = m2;                                  // plain store: the word is host-mapped
+    }
+    if (s_pick[0] == 0xffffffffu) return;                  // more workgroups than chunks
+    const uint32_t chunk = s_pick[1], s0 = s_pick[2], sz = s_pick[3];
+    const uint32_t cbeg = chunk * LOCAL_CHUNK, cend = min(cbeg + LOCAL_CHUNK, sz);
+
+    // my keys (registers), counted per wave
+    const uint32_t wbegin = cbeg + wave * (LOCAL_STEPS * WAVE), wend = min(wbegin + LOCAL_STEPS * WAVE, cend);
+    uint32_t key[LOCAL_STEPS], src[LOCAL_STEPS];
+#pragma unroll
+    for (int k = 0; k < LOCAL_STEPS; k++) {
+        const uint32_t i = wbegin + k * WAVE + lane;
+        const bool in = i < wend;
+        key[k] = in ? (keys[s0 + i] & (BINS - 1)) : 0xffffffffu;
+        src[k] = in ? idx[s0 + i] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < LOCAL_STEPS; k++)
+        if (key[k] != 0xffffffffu) atomicAdd(&cnt[wave][key[k]], 1u);
+    // the rest of the bucket: digits of the chunks in front of mine (-> bef) and behind it (-> tot); loads in batches
+    // of eight so that their round trips overlap (a load -> LDS-add chain per key made this the slowest part)
+    constexpr int CB = 8;
+    for (uint32_t i0 = threadIdx.x; i0 < sz; i0 += CB * LOCAL_THREADS) {
+        uint32_t v[CB];
+#pragma unroll
+        for (int j = 0; j < CB; j++) {
+            const uint32_t i = i0 + j * LOCAL_THREADS;
+            v[j] = (i < sz && (i < cbeg || i >= cend)) ? keys[s0 + i] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int j = 0; j < CB; j++) {
+            const uint32_t i = i0 + j * LOCAL_THREADS;
+            if (v[j] != 0xffffffffu) atomicAdd(i < cbeg ? &bef[v[j] & (BINS - 1)] : &tot[v[j] & (BINS - 1)], 1u);
+        }
+    }
+    __syncthreads();
+    // one digit per thread: prefix over my waves; bucket-wide digit starts
+    uint32_t H = 0, incl = 0, td = 0;
+    if (threadIdx.x < BINS) {
+        const int d = threadIdx.x;
+#pragma unroll
+        for (int w = 0; w < LOCAL_WAVES; w++) {
+            const uint32_t cv = cnt[w][d];
+            cnt[w][d] = H;
+            H += cv;
+        }
+        td = tot[d] + bef[d] + H;     // the digit's keys in the whole bucket
+        incl = td;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const uint32_t u = __shfl_up(incl, off);
+            if (lane >= off) incl += u;
+        }
+        if (lane == WAVE - 1) wsum[wave] = incl;
+    }
+    __syncthreads();
+    if (threadIdx.x < BINS) {
+        uint32_t run = incl - td;
+        for (int w = 0; w < wave; w++) run += wsum[w];
+        tot[threadIdx.x] = run + bef[threadIdx.x];   // first position, inside the bucket, of my chunk's keys of this digit
+    }
+    __syncthreads();
+    // rank and place
+    uint32_t* wc = cnt[wave];
+#pragma unroll
+    for (int k = 0; k < LOCAL_STEPS; k++) {
+        const bool valid = key[k] != 0xffffffffu;
+        const uint32_t digit = valid ? key[k] : 0u;
+        const uint64_t m = match_digit<RADIX_LO_BITS>(digit, valid);
+        const uint32_t rank = lanes_below(m);
+        const uint32_t earlier = wc[digit];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == 0) wc[digit] = earlier + (uint32_t)__popcll(m);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        if (valid) depth_index[s0 + tot[digit] + earlier + rank] = src[k];
+    }
+}
+
 void launch_sort(const SortBuffers& b, uint32_t n, hipStream_t s)
 {
     if (!n) return;
@@ -357,22 +515,36 @@ void launch_sort(const SortBuffers& b, uint32_t n, hipStream_t s)
                                       (int)scatter_lds_bytes<RADIX_LO_BITS>(SCAT_THREADS * SCAT_MAX_STEPS));
             (void)hipFuncSetAttribute((const void*)k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)scatter_lds_bytes<RADIX_HI_BITS>(SCAT_THREADS * SCAT_MAX_STEPS));
+            (void)hipFuncSetAttribute((const void*)k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)scatter_lds_bytes<RADIX_HI_BITS>(SCAT_THREADS * SCAT_MAX_STEPS));
             (void)hipGetLastError();   // a failure shows up as the launch error
             done_mask |= 1u << dev;
         }
     }
+    if (b.bucket_order) {
+        // bucket order: partition by the high 9 bits, then one workgroup per bucket sorts by the low 8 (k_local_sort)
+        hipLaunchKernelGGL(k_quantise_hist, grid, block, 0, s, b.depth, b.slots, b.minmax, n, b.keys_per_block,
+                           b.rect, b.cull, b.keys, b.block_hist, RADIX_LO_BITS, RADIX_HI_BINS);
+        launch_column_scan(b.block_hist, total_hi, RADIX_HI_BINS, b.nblocks, s);
+        hipLaunchKernelGGL((k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, true>), grid, dim3(SCAT_THREADS), lds_hi, s, (const uint32_t*)b.keys,
+                           (const uint32_t*)nullptr, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
+                           (const uint32_t*)total_hi, b.keys_tmp, b.idx_tmp, (uint32_t*)nullptr);
+        hipLaunchKernelGGL(k_local_sort, dim3(local_sort_grid(n)), dim3(LOCAL_THREADS), 0, s, (const uint32_t*)b.keys_tmp,
+                           (const uint32_t*)b.idx_tmp, (const uint32_t*)total_hi, b.depth_index, b.max_bucket);
+        return;
+    }
     hipLaunchKernelGGL(k_quantise_hist, grid, block, 0, s, b.depth, b.slots, b.minmax, n, b.keys_per_block,
-                       b.rect, b.cull, b.keys, b.block_hist);
+                       b.rect, b.cull, b.keys, b.block_hist, 0, RADIX_LO_BINS);
     launch_column_scan(b.block_hist, total_lo, RADIX_LO_BINS, b.nblocks, s);
     hipLaunchKernelGGL((k_scatter<RADIX_LO_BITS, 0, true>), grid, dim3(SCAT_THREADS), lds_lo, s, (const uint32_t*)b.keys,
                        (const uint32_t*)nullptr, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
-                       (const uint32_t*)total_lo, b.keys_tmp, b.idx_tmp);
+                       (const uint32_t*)total_lo, b.keys_tmp, b.idx_tmp, (uint32_t*)nullptr);
     hipLaunchKernelGGL(k_hist_hi, grid, block, 0, s, (const uint32_t*)b.keys_tmp, (const uint32_t*)b.count, b.keys_per_block,
                        b.block_hist);
     launch_column_scan(b.block_hist, total_hi, RADIX_HI_BINS, b.nblocks, s);
     hipLaunchKernelGGL((k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, false>), grid, dim3(SCAT_THREADS), lds_hi, s, (const uint32_t*)b.keys_tmp,
                        (const uint32_t*)b.idx_tmp, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
-                       (const uint32_t*)total_hi, (uint32_t*)nullptr, b.depth_index);
+                       (const uint32_t*)total_hi, (uint32_t*)nullptr, b.depth_index, b.max_bucket);
 }
 
 }  // namespace gsr

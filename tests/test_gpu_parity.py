@@ -836,3 +836,39 @@ def test_rccl_allgather_inside_the_library_single_rank(gh, scenes):
     ref.render_async(); ref.sync()
     assert np.array_equal(r.readPixels(), ref.readPixels())
     r.dispose(); ref.dispose()
+
+
+@pytest.mark.parametrize("order", ["lsd", "bucket", "auto"])
+def test_sort_orders_give_the_same_permutation(gh, oracle, scenes, monkeypatch, order):
+    """Two radix orders produce the reference's permutation: LSD (low 8 bits, then high 9: six launches) and bucket order
+    (high 9 bits first, then one workgroup per bucket sorts by the low 8: four launches, used for small scenes).
+    'auto' = what ships: LSD for the first frame of a scene, bucket order once a frame has reported that no bucket is
+    too large, LSD again when one is.  Scenes: uniform, one with depth outliers that push nearly every splat into a
+    few buckets (the fallback case), one with a single multi-chunk bucket (> 8192 keys), tiny ones."""
+    if order != "auto":
+        monkeypatch.setenv("GSR_SORT_ORDER", order)
+    rng = np.random.default_rng(5)
+    cases = []
+    rows, data, pos = scenes(200000, 41)
+    cases.append(("gaussian", np.array(pos, copy=True)))
+    p2 = np.array(pos, copy=True).reshape(-1, 3)
+    p2[:7] *= 4000.0                               # outliers stretch the key range: the rest collapses into a few buckets
+    cases.append(("outliers", p2.reshape(-1)))
+    p3 = rng.normal(size=(60000, 3)).astype(np.float32) * 1e-3
+    p3[::7] += rng.normal(size=(p3[::7].shape)).astype(np.float32)
+    cases.append(("dense slab", p3.reshape(-1)))
+    cases.append(("tiny", np.array(pos[:3 * 77], copy=True)))
+    for name, pp in cases:
+        n = pp.size // 3
+        d = np.zeros((n, 8), dtype=np.uint32)
+        d[:, 0:3] = pp.reshape(-1, 3).view(np.uint32)
+        r = gh.HIPRenderer(640, 480)
+        r.set_raw_scene(d, pp)
+        for k in (0, 17, 63, 91):
+            cam = _camera(gh, k, SMALL)
+            r.sort(cam)
+            odi, okeys, omm = oracle.sort(cam.f32()[2], pp)
+            keys, mm = r.read_keys()
+            assert mm == omm and np.array_equal(keys, okeys), (name, k)
+            assert np.array_equal(r.lastDepthIndex(), odi), (name, k, order)
+        r.dispose()
