@@ -160,17 +160,35 @@ __device__ __forceinline__ int partial_class(uint32_t r, uint32_t seg_len, bool 
     return !by_size ? 3 : r >= seg_len / 2 ? 1 : r >= seg_len / 4 ? 2 : 3;
 }
 
-__global__ __launch_bounds__(FIN_THREADS) void k_bin_finalize(const uint32_t* __restrict__ bin_total, int nbins,
-                                                              uint32_t seg_len_min, uint32_t seg_target_items, int by_size,
-                                                              uint32_t* __restrict__ seg_len_out, uint32_t max_items, uint32_t capacity,
-                                                              const int32_t* __restrict__ slots, uint32_t have_counts,
-                                                              uint32_t* __restrict__ bin_start,
-                                                              uint32_t* __restrict__ seg_start, uint32_t* __restrict__ items,
-                                                              uint32_t* __restrict__ overflow, uint64_t* __restrict__ visible,
-                                                              uint64_t* __restrict__ tile_entries, uint64_t* __restrict__ accum,
-                                                              uint64_t* __restrict__ report, uint32_t* __restrict__ queue,
-                                                              uint32_t queue_start, uint64_t* __restrict__ mailbox)
+// Arguments of the finalize step (by value in the kernel arguments of whichever kernel runs it).
+struct FinalizeArgs {
+    const uint32_t* bin_total; int nbins;
+    uint32_t seg_len_min, seg_target_items; int by_size;
+    uint32_t* seg_len_out; uint32_t max_items, capacity;
+    const int32_t* slots; uint32_t have_counts;
+    uint32_t *bin_start, *seg_start, *items, *overflow;
+    uint64_t *visible, *tile_entries, *accum, *report;
+    uint32_t* queue; uint32_t queue_start;
+    uint64_t* mailbox;
+};
+
+// One workgroup of FIN_THREADS threads.  It runs as an EXTRA workgroup of k_bin_scatter (the scatter workgroups
+// compute the bin starts they need themselves), so its ~9 us no longer sit between the column scan and the scatter;
+// k_bin_finalize is the stand-alone form for frames without splats.
+__device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa)
 {
+    const uint32_t* __restrict__ bin_total = fa.bin_total;
+    const int nbins = fa.nbins;
+    const uint32_t seg_len_min = fa.seg_len_min, seg_target_items = fa.seg_target_items, max_items = fa.max_items, capacity = fa.capacity;
+    const int by_size = fa.by_size;
+    uint32_t* __restrict__ bin_start = fa.bin_start;
+    uint32_t* __restrict__ seg_start = fa.seg_start;
+    uint32_t* __restrict__ items = fa.items;
+    const int32_t* __restrict__ slots = fa.slots;
+    const uint32_t have_counts = fa.have_counts;
+    uint32_t* seg_len_out = fa.seg_len_out; uint32_t* overflow = fa.overflow; uint64_t* visible = fa.visible;
+    uint64_t* tile_entries = fa.tile_entries; uint64_t* accum = fa.accum; uint64_t* report = fa.report;
+    uint32_t* queue = fa.queue; const uint32_t queue_start = fa.queue_start; uint64_t* mailbox = fa.mailbox;
     __shared__ uint32_t s_w[5][FIN_WAVES];
     const int per = (nbins + FIN_THREADS - 1) / FIN_THREADS;
     const int b0 = threadIdx.x * per, b1 = min(b0 + per, nbins);
@@ -258,6 +276,8 @@ __global__ __launch_bounds__(FIN_THREADS) void k_bin_finalize(const uint32_t* __
     }
 }
 
+__global__ __launch_bounds__(FIN_THREADS) void k_bin_finalize(FinalizeArgs fa) { bin_finalize_body(fa); }
+
 // ---------------------------------------------------------------------------
 // scatter: list[...] = splat index, bins in raster order, depth order inside a bin.
 // Workgroup = 16 waves over 2048 consecutive ranks.  The ranks form 4 groups of 512 (8 steps of 64);
@@ -303,15 +323,26 @@ inline BinSlices make_slices(int nbxb, int nby)
         }
 }
 
-template <int GROUPS>
-__global__ __launch_bounds__(SCAT_THREADS) void k_bin_scatter(const uint32_t* __restrict__ depth_index,
+// (8 waves per SIMD = 64 VGPRs: two of these 16-wave workgroups per CU.  The scatter path needs 46; the finalize step,
+// built for one workgroup, wants 104 and spills a little in its one workgroup instead of halving everybody's occupancy.)
+// FUSED (small bin grids): the finalize step runs as an extra workgroup of this kernel and every scatter workgroup scans
+// the bin totals itself -- C3: binning 61.3 -> 56.5 us.  Large grids (4K: 8160 bins) keep the stand-alone finalize
+// kernel and read its bin_start[]: there the 2442 redundant scans cost more than the launch they save (C4: +38 us).
+template <int GROUPS, bool FUSED>
+__global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bin_scatter(const uint32_t* __restrict__ depth_index,
                                                               const uint32_t* __restrict__ rects,
                                                               const uint32_t* __restrict__ count, BinGrid g, BinSlices sl,
                                                               const uint32_t* __restrict__ table,
-                                                              const uint32_t* __restrict__ bin_start,
+                                                              const uint32_t* __restrict__ bin_total /* FUSED */,
+                                                              const uint32_t* __restrict__ bin_start /* !FUSED */,
                                                               uint32_t* __restrict__ list, uint32_t capacity,
-                                                              uint32_t* __restrict__ overflow)
+                                                              uint32_t* __restrict__ overflow, FinalizeArgs fa)
 {
+    static_assert(FIN_THREADS == SCAT_THREADS, "the finalize step runs as a workgroup of this kernel");
+    if (FUSED && blockIdx.x == gridDim.x - 1) {   // the extra workgroup: bin starts, work items and frame counters for the compositor
+        if (blockIdx.y == 0) bin_finalize_body(fa);
+        return;
+    }
     constexpr int WAVES_PER_GROUP = SCAT_WAVES / GROUPS;            // 4 or 2
     constexpr int GROUP_STEPS = SCAT_STEPS / GROUPS;                // 8 or 4
     constexpr int PAIR_WORDS = GROUPS / 2;                          // two 16-bit per-group counts / offsets per word
@@ -362,11 +393,37 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_bin_scatter(const uint32_t* __
         }
         br[k] = b;
     }
-    // the workgroup's first slot in every bin (base[] is not touched by phase 1, so no barrier is needed before it)
-    for (int b = threadIdx.x; b < nb_s; b += SCAT_THREADS) {
-        const int ly = b / sw, lx = b - ly * sw;
-        const int gb = (sy0 + ly) * nbxb + sx0 + lx;  // the bin's index in the band
-        base[b] = bin_start[gb] + table[(size_t)blockIdx.x * nbins + gb];
+    // the workgroup's first slot in every bin = the bin's start (an exclusive scan of the bin totals, done here by
+    // every workgroup: the finalize step that publishes bin_start[] runs beside this kernel, not before it) + the
+    // entries earlier workgroups put into the bin (the scanned table).  base[] is not touched by phase 1.
+    if (!FUSED) {
+        for (int b = threadIdx.x; b < nb_s; b += SCAT_THREADS) {
+            const int ly = b / sw, lx = b - ly * sw;
+            const int gb = (sy0 + ly) * nbxb + sx0 + lx;  // the bin's index in the band
+            base[b] = bin_start[gb] + table[(size_t)blockIdx.x * nbins + gb];
+        }
+    } else {
+        __shared__ uint32_t s_ws[SCAT_WAVES];
+        const int per = (nbins + SCAT_THREADS - 1) / SCAT_THREADS;
+        const int gb0 = threadIdx.x * per, gb1 = min(gb0 + per, nbins);
+        uint32_t mine = 0;
+        for (int gb = gb0; gb < gb1; gb++) mine += bin_total[gb];
+        uint32_t inc = mine;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const uint32_t u = __shfl_up(inc, off);
+            if (lane >= off) inc += u;
+        }
+        if (lane == WAVE - 1) s_ws[wave] = inc;
+        __syncthreads();
+        uint32_t run = inc - mine;
+        for (int w = 0; w < wave; w++) run += s_ws[w];
+        for (int gb = gb0; gb < gb1; gb++) {
+            const int gy = gb / nbxb, gx = gb - gy * nbxb;
+            const uint32_t c = bin_total[gb];
+            if (gx >= sx0 && gx < sx1 && gy >= sy0 && gy < sy1) base[(gy - sy0) * sw + (gx - sx0)] = run + table[(size_t)blockIdx.x * nbins + gb];
+            run += c;
+        }
     }
     KSTAMP(2);
     // phase 1: per-group counts, and every lane ORs its bit into the column/row lane sets of its box
@@ -446,7 +503,9 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
     // for the common sizes (1080p needs 64 KiB).
     if (lds > 60 * 1024) {
         const int want = (int)std::min<size_t>(lds + 1024, 160 * 1024 - 256);
-        const void* fn = eight ? (const void*)k_bin_scatter<8> : (const void*)k_bin_scatter<4>;
+        const bool fz = n && nbins <= 4096;
+        const void* fn = eight ? (fz ? (const void*)k_bin_scatter<8, true> : (const void*)k_bin_scatter<8, false>)
+                               : (fz ? (const void*)k_bin_scatter<4, true> : (const void*)k_bin_scatter<4, false>);
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess)
             (void)hipGetLastError();  // the launch below then reports the real failure
     }
@@ -458,19 +517,22 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
                            (size_t)cnt_rows * nbxb * sizeof(uint32_t), s, b.depth_index, b.rect_idx, b.count, g, cnt_rows, b.table, b.rects);
         launch_column_scan(b.table, b.bin_total, nbins, b.nblocks, s);
     }
-    hipLaunchKernelGGL(k_bin_finalize, dim3(1), dim3(FIN_THREADS), 0, s, (const uint32_t*)b.bin_total, nbins, b.seg_len,
-                       b.seg_target_items, b.items_by_size, b.seg_len_dev, b.max_items, b.capacity, b.slots, n ? 1u : 0u,
-                       b.bin_start, b.seg_start, b.items, b.overflow, b.visible, b.tile_entries, b.accum, b.report, b.queue, b.queue_start,
-                       b.mailbox);
+    const FinalizeArgs fa{b.bin_total, nbins, b.seg_len, b.seg_target_items, b.items_by_size, b.seg_len_dev, b.max_items, b.capacity,
+                          b.slots, n ? 1u : 0u, b.bin_start, b.seg_start, b.items, b.overflow, b.visible, b.tile_entries, b.accum,
+                          b.report, b.queue, b.queue_start, b.mailbox};
+    const bool fused = n && nbins <= 4096;   // see k_bin_scatter
+    if (!fused) hipLaunchKernelGGL(k_bin_finalize, dim3(1), dim3(FIN_THREADS), 0, s, fa);
     if (n) {
-        if (eight)
-            hipLaunchKernelGGL(k_bin_scatter<8>, dim3(b.nblocks, sl.sx * sl.sy), dim3(SCAT_THREADS), lds, s, b.depth_index,
-                               (const uint32_t*)b.rects, b.count, g, sl, (const uint32_t*)b.table, (const uint32_t*)b.bin_start, b.list,
-                               b.capacity, b.overflow);
-        else
-            hipLaunchKernelGGL(k_bin_scatter<4>, dim3(b.nblocks, sl.sx * sl.sy), dim3(SCAT_THREADS), lds, s, b.depth_index,
-                               (const uint32_t*)b.rects, b.count, g, sl, (const uint32_t*)b.table, (const uint32_t*)b.bin_start, b.list,
-                               b.capacity, b.overflow);
+        const dim3 grid(b.nblocks + (fused ? 1 : 0), sl.sx * sl.sy), block(SCAT_THREADS);
+#define GSR_LAUNCH_SCATTER(G, F)                                                                                                    \
+    hipLaunchKernelGGL((k_bin_scatter<G, F>), grid, block, lds, s, b.depth_index, (const uint32_t*)b.rects, b.count, g, sl,         \
+                       (const uint32_t*)b.table, (const uint32_t*)b.bin_total, (const uint32_t*)b.bin_start, b.list, b.capacity,    \
+                       b.overflow, fa)
+        if (eight && fused) GSR_LAUNCH_SCATTER(8, true);
+        else if (eight) GSR_LAUNCH_SCATTER(8, false);
+        else if (fused) GSR_LAUNCH_SCATTER(4, true);
+        else GSR_LAUNCH_SCATTER(4, false);
+#undef GSR_LAUNCH_SCATTER
     }
 }
 
