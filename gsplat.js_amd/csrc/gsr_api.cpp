@@ -73,6 +73,8 @@ struct gsr_ctx {
     // binning
     uint32_t *bin_table = nullptr, *bin_total = nullptr, *bin_start = nullptr, *bin_list = nullptr;
     uint32_t *seg_start = nullptr, *items = nullptr;
+    uint32_t* bin_done = nullptr;     // per-bin arrival counters of the compositor (null: separate k_combine launch)
+    bool fuse_combine = true;
     uint32_t* bin_rects = nullptr;
     float4* partial = nullptr;
     uint32_t bin_blocks = 0, bin_capacity = 0, bin_table_elems = 0, bin_nbins_alloc = 0;
@@ -233,6 +235,7 @@ int alloc_bins(gsr_ctx* c)
         if (int r = dev_alloc(c, &c->bin_total, nbins)) return r;
         if (int r = dev_alloc(c, &c->bin_start, nbins + 1)) return r;
         if (int r = dev_alloc(c, &c->seg_start, nbins + 1)) return r;
+        if (c->fuse_combine) { if (int r = dev_alloc(c, &c->bin_done, nbins)) return r; }
         c->bin_nbins_alloc = nbins;
         items_dirty = true;
     }
@@ -312,13 +315,13 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
         if (!c->n) HIP_TRY(c, hipMemsetAsync(c->bin_total, 0, sizeof(uint32_t) * nbins, s));
         BinBuffers bb{c->depth_index, &c->fstate->sorted_count, c->bin_table, c->slots, c->rect_idx, c->bin_rects, c->bin_total, c->bin_start, c->seg_start,
                       c->items, c->bin_list, &c->fstate->overflow, &c->fstate->visible, &c->fstate->tile_entries,
-                      c->accum, c->mailbox_dev, c->fstate->report, c->bin_capacity, c->max_items, c->seg_len, &c->fstate->seg_len, (c->opt.flags & GSR_FLAG_THROUGHPUT) ? 0 : 1, &c->fstate->queue, std::min<uint32_t>(c->max_items, c->blend_grid), c->seg_target_items, c->bin_blocks};
+                      c->accum, c->mailbox_dev, c->fstate->report, c->bin_capacity, c->max_items, c->seg_len, &c->fstate->seg_len, (c->opt.flags & GSR_FLAG_THROUGHPUT) ? 0 : 1, &c->fstate->queue, std::min<uint32_t>(c->max_items, c->blend_grid), c->seg_target_items, c->bin_blocks, c->bin_done};
         launch_bin(bb, g, c->n, s);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BIN], s));
         BlendBuffers bl{c->items, c->seg_start, c->bin_start, c->bin_list, c->rec, c->bbox, c->shcol, c->fb, c->partial,
                         &c->fstate->queue, c->seg_len, &c->fstate->seg_len, std::min<uint32_t>(c->max_items, c->blend_grid), c->bin_capacity,
-                        std::max(c->n, 1u)};
-        launch_blend(bl, g, c->opt.early_out_eps, s, timing ? c->ev[EV_BLEND] : nullptr);
+                        std::max(c->n, 1u), c->bin_done};
+        launch_blend(bl, g, c->opt.early_out_eps, s, (timing && !c->bin_done) ? c->ev[EV_BLEND] : nullptr);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_COMBINE], s));
     }
     HIP_TRY(c, hipGetLastError());
@@ -343,7 +346,7 @@ static std::vector<uint64_t> chain_signature(const gsr_ctx* c)
     auto U = [&v](uint64_t x) { v.push_back(x); };
     P(c->px); P(c->py); P(c->pz); P(c->cov0); P(c->cov1); P(c->cov2); P(c->rgba); P(c->sh_r); P(c->sh_g); P(c->sh_b); P(c->shcol);
     P(c->depth); P(c->keys); P(c->keys_tmp); P(c->idx_tmp); P(c->depth_index); P(c->block_hist); P(c->fstate);
-    P(c->rec); P(c->bbox); P(c->slots); P(c->rect_idx); P(c->bin_table); P(c->bin_rects); P(c->bin_total); P(c->bin_start); P(c->seg_start);
+    P(c->rec); P(c->bbox); P(c->slots); P(c->rect_idx); P(c->bin_table); P(c->bin_rects); P(c->bin_total); P(c->bin_start); P(c->seg_start); P(c->bin_done);
     P(c->items); P(c->bin_list); P(c->partial); P(c->fb); P(c->accum); P(c->cam_dev);
     U(c->n); U((uint64_t)c->W); U((uint64_t)c->H); U((uint64_t)g.bx_lo); U((uint64_t)g.bx_hi); U(c->sort_kpb); U(c->sort_blocks);
     U(c->bin_capacity); U(c->max_items); U(c->seg_len); U(c->seg_target_items); U(c->blend_grid); U(c->bin_blocks);
@@ -435,8 +438,12 @@ int finish_frame(gsr_ctx* c)
         t = a + b;
         if (render) {
             HIP_TRY(c, hipEventElapsedTime(&d, ev[EV_SORT], ev[EV_BIN]));
-            HIP_TRY(c, hipEventElapsedTime(&e, ev[EV_BIN], ev[EV_BLEND]));
-            HIP_TRY(c, hipEventElapsedTime(&f, ev[EV_BLEND], ev[EV_COMBINE]));
+            if (c->bin_done) {   // the fold of multi-segment bins runs inside k_blend: one stage, no event in between
+                HIP_TRY(c, hipEventElapsedTime(&e, ev[EV_BIN], ev[EV_COMBINE]));
+            } else {
+                HIP_TRY(c, hipEventElapsedTime(&e, ev[EV_BIN], ev[EV_BLEND]));
+                HIP_TRY(c, hipEventElapsedTime(&f, ev[EV_BLEND], ev[EV_COMBINE]));
+            }
             HIP_TRY(c, hipEventElapsedTime(&t, ev[EV_BEGIN], ev[EV_COMBINE]));
         }
         c->tm.ms_project_key = a; c->tm.ms_sort = b; c->tm.ms_bin = d; c->tm.ms_blend = e; c->tm.ms_combine = f; c->tm.ms_total = t;
@@ -541,6 +548,7 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
     CREATE_TRY(hipMalloc((void**)&c->slots, sizeof(int32_t) * FRAME_SLOTS * FRAME_SLOT_WORDS));
     CREATE_TRY(hipMemset(c->slots, 0, sizeof(int32_t) * FRAME_SLOTS * FRAME_SLOT_WORDS));
     if (const char* e = getenv("GSR_NO_GRAPH")) c->graphs_enabled = atoi(e) == 0;
+    if (const char* e = getenv("GSR_FUSE_COMBINE")) c->fuse_combine = atoi(e) != 0;   // A/B knob: 0 = separate k_combine launch
     CREATE_TRY(hipMalloc((void**)&c->accum, 8 * sizeof(uint64_t)));
     CREATE_TRY(hipMemset(c->accum, 0, 8 * sizeof(uint64_t)));
     CREATE_TRY(hipHostMalloc((void**)&c->mailbox, 64, hipHostMallocMapped));
@@ -585,7 +593,7 @@ int gsr_destroy(gsr_ctx* c)
     dev_free(&c->depth); dev_free(&c->keys); dev_free(&c->keys_tmp); dev_free(&c->idx_tmp); dev_free(&c->depth_index);
     dev_free(&c->block_hist); dev_free(&c->rec); dev_free(&c->bbox); dev_free(&c->slots); dev_free(&c->rect_idx);
     dev_free(&c->bin_table); dev_free(&c->bin_total); dev_free(&c->bin_start); dev_free(&c->bin_list);
-    dev_free(&c->seg_start); dev_free(&c->items); dev_free(&c->partial); dev_free(&c->bin_rects);
+    dev_free(&c->seg_start); dev_free(&c->bin_done); dev_free(&c->items); dev_free(&c->partial); dev_free(&c->bin_rects);
     drop_graph(c);
     dev_free(&c->cam_dev);
     dev_free(&c->fstate); dev_free(&c->accum); dev_free(&c->fb); dev_free(&c->fb8);

@@ -160,6 +160,7 @@ struct BinBuffers {
     uint32_t queue_start;
     uint32_t seg_target_items;   // full segments the frame should be cut into at least (long lists -> longer segments)
     uint32_t nblocks;
+    uint32_t* bin_done;          // nbins: the compositor's per-bin arrival counters, zeroed by the finalize step (may be null)
 };
 void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s);
 
@@ -179,6 +180,8 @@ struct BlendBuffers {
     uint32_t grid;              // persistent workgroups launched
     uint32_t capacity;          // entries the list can hold
     uint32_t nsplats;
+    uint32_t* bin_done;         // nbins arrival counters, zeroed by the finalize step: the workgroup delivering a bin's last
+                                // segment folds the bin inside k_blend; null = the separate k_combine launch does it
 };
 // `between` (may be null) is recorded after k_blend and before k_combine
 void launch_blend(const BlendBuffers& b, const BinGrid& g, float early_out_eps, hipStream_t s, hipEvent_t between);

@@ -170,6 +170,7 @@ struct FinalizeArgs {
     uint64_t *visible, *tile_entries, *accum, *report;
     uint32_t* queue; uint32_t queue_start;
     uint64_t* mailbox;
+    uint32_t* bin_done;
 };
 
 // One workgroup of FIN_THREADS threads.  It runs as an EXTRA workgroup of k_bin_scatter (the scatter workgroups
@@ -231,6 +232,7 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa)
         const bool part = r || !nf;
         bin_start[b] = fits ? ex : 0u;
         seg_start[b] = fits ? sx : 0u;
+        if (fa.bin_done) fa.bin_done[b] = 0u;
         if (fits) {
             for (uint32_t k = 0; k < nf; k++) items[fx + k] = (uint32_t)b | (k << 16);
             if (part) {
@@ -519,7 +521,7 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
     }
     const FinalizeArgs fa{b.bin_total, nbins, b.seg_len, b.seg_target_items, b.items_by_size, b.seg_len_dev, b.max_items, b.capacity,
                           b.slots, n ? 1u : 0u, b.bin_start, b.seg_start, b.items, b.overflow, b.visible, b.tile_entries, b.accum,
-                          b.report, b.queue, b.queue_start, b.mailbox};
+                          b.report, b.queue, b.queue_start, b.mailbox, b.bin_done};
     const bool fused = n && nbins <= 4096;   // see k_bin_scatter
     if (!fused) hipLaunchKernelGGL(k_bin_finalize, dim3(1), dim3(FIN_THREADS), 0, s, fa);
     if (n) {

@@ -18,9 +18,11 @@
 //
 // Long lists (screen centre) are cut into segments that are composited
 // concurrently by different workgroups, each from (colour 0, transmittance 1);
-// "under" compositing is associative, so k_combine folds the partial
-// (colour, transmittance) pairs of a bin front to back:
+// "under" compositing is associative, so the partial (colour, transmittance)
+// pairs of a bin are folded front to back:
 //     C = C0 + T0*C1 + T0*T1*C2 + ...,  T = T0*T1*T2*...
+// by the workgroup that delivers the bin's last segment (see the end of k_blend;
+// k_combine is the same fold as a separate launch, GSR_FUSE_COMBINE=0).
 // This removes the serial critical path of the heaviest tiles.  With early
 // termination enabled a bin is one item (segments could not see each other's
 // saturation), processed front to back until every pixel is opaque.
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
                                                          const float4* __restrict__ shcol, float4* __restrict__ fb,
                                                          float4* __restrict__ partial, uint32_t* __restrict__ queue,
                                                          BinGrid g, float eps, const uint32_t* __restrict__ seg_len_dev, uint32_t capacity,
-                                                         uint32_t nsplats)
+                                                         uint32_t nsplats, uint32_t* __restrict__ bin_done)
 {
     const uint32_t seg_len = *seg_len_dev;  // this frame's list entries per work item (k_bin_finalize)
     // [0]: ux, uy, -dot(u, c - bin origin), wx   [1]: wy, -dot(w, c - bin origin), log2(opacity), blue   [2]: red, green
@@ -73,6 +75,7 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
     __shared__ uint32_t s_mask[CHUNK];
     __shared__ uint32_t s_done;
     __shared__ uint32_t s_item;
+    __shared__ uint32_t s_last;
 
     const int nbxb = g.bx_hi - g.bx_lo, nbins = nbxb * g.nby;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -279,11 +282,56 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
             }
         } else {
             // ---- partial (colour, transmittance) of this segment, slot-major: fully coalesced ----
-            float4* p = partial + (size_t)(seg_start[bin] + seg) * BIN_PIXELS + wave * (TILE * TILE) + lane;
-            p[0] = make_float4(r00, g00, b00, T00);
-            p[64] = make_float4(r10, g10, b10, T10);
-            p[128] = make_float4(r01, g01, b01, T01);
-            p[192] = make_float4(r11, g11, b11, T11);
+            float4* p0 = partial + (size_t)seg_start[bin] * BIN_PIXELS + wave * (TILE * TILE) + lane;
+            float4* p = p0 + (size_t)seg * BIN_PIXELS;
+            if (!bin_done) {   // k_combine folds the bin after this kernel
+                p[0] = make_float4(r00, g00, b00, T00);
+                p[64] = make_float4(r10, g10, b10, T10);
+                p[128] = make_float4(r01, g01, b01, T01);
+                p[192] = make_float4(r11, g11, b11, T11);
+            } else {
+                // The workgroup that delivers a bin's LAST segment folds the bin itself (front to back, k_combine's fixed
+                // order: which workgroup does it changes nothing in the result), so the fold runs beside the other
+                // workgroups' arithmetic and the k_combine launch goes away.
+                // Visibility between workgroups on different XCDs (one L2 each) WITHOUT a release fence: an agent-scope
+                // release is buffer_wbl2, a write-back of the XCD's whole L2, and one per work item made the kernel 3.5x
+                // slower.  Instead the partials are the only data exchanged and they move with agent-scope accesses on
+                // both sides (sc1: stores write through to memory, loads do not hit another XCD's stale line -- what
+                // relaxed agent-scope atomics compile to); the stores are complete (vmcnt 0, every thread, then the
+                // barrier) before thread 0 counts the arrival with an agent-scope atomic.
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const v4f o0 = {r00, g00, b00, T00}, o1 = {r10, g10, b10, T10}, o2 = {r01, g01, b01, T01}, o3 = {r11, g11, b11, T11};
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:1024 sc1\n\t"
+                             "global_store_dwordx4 %0, %3, off offset:2048 sc1\n\tglobal_store_dwordx4 %0, %4, off offset:3072 sc1\n\t"
+                             "s_waitcnt vmcnt(0)"
+                             :: "v"(p), "v"(o0), "v"(o1), "v"(o2), "v"(o3) : "memory");
+                __syncthreads();
+                if (threadIdx.x == 0)
+                    s_last = (__hip_atomic_fetch_add(&bin_done[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nseg - 1u) ? 1u : 0u;
+                __syncthreads();
+                if (s_last) {
+                    float cr[4] = {0.f, 0.f, 0.f, 0.f}, cg[4] = {0.f, 0.f, 0.f, 0.f}, cb[4] = {0.f, 0.f, 0.f, 0.f}, cT[4] = {1.f, 1.f, 1.f, 1.f};
+                    for (uint32_t k = 0; k < nseg; k++) {
+                        v4f v[4];
+                        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
+                                     "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:3072 sc1\n\t"
+                                     "s_waitcnt vmcnt(0)"
+                                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(p0 + (size_t)k * BIN_PIXELS) : "memory");
+#pragma unroll
+                        for (int slot = 0; slot < 4; slot++) {
+                            cr[slot] = __builtin_fmaf(cT[slot], v[slot].x, cr[slot]);
+                            cg[slot] = __builtin_fmaf(cT[slot], v[slot].y, cg[slot]);
+                            cb[slot] = __builtin_fmaf(cT[slot], v[slot].z, cb[slot]);
+                            cT[slot] = cT[slot] * v[slot].w;
+                        }
+                    }
+#pragma unroll
+                    for (int slot = 0; slot < 4; slot++) {
+                        const int x = X0 + lx + 8 * (slot & 1), y = Y0 + ly + 8 * (slot >> 1);
+                        if (x < g.W && y < g.H) fb[(size_t)y * g.W + x] = make_float4(cr[slot], cg[slot], cb[slot], 1.0f - cT[slot]);
+                    }
+                }
+            }
         }
     }
 #ifdef GSR_BLEND_STAMPS
@@ -308,7 +356,8 @@ extern "C" int gsr_debug_blend_stamps(unsigned int* out /* 4096*4*16 */)
 }
 #endif
 
-// Fold the per-segment partials of every multi-segment bin, front to back.  A thread folds its four
+// Fold the per-segment partials of every multi-segment bin, front to back -- the stand-alone form (BlendBuffers::bin_done
+// null); by default the fold runs inside k_blend and this kernel is not launched.  A thread folds its four
 // pixels as four independent chains and the segment loop is unrolled, so 16 loads are in flight per
 // thread: the kernel is a latency-bound read of the partials (85 MB on C3 with 512-entry segments).
 __global__ __launch_bounds__(BLEND_THREADS) void k_combine(const uint32_t* __restrict__ seg_start,
@@ -350,9 +399,9 @@ void launch_blend(const BlendBuffers& b, const BinGrid& g, float early_out_eps, 
     const int nbins = (g.bx_hi - g.bx_lo) * g.nby;
     if (nbins <= 0) return;
     hipLaunchKernelGGL(k_blend, dim3(b.grid), dim3(BLEND_THREADS), 0, s, b.items, b.seg_start, b.bin_start, b.list, b.rec,
-                       b.shcol, b.fb, b.partial, b.queue, g, early_out_eps, b.seg_len_dev, b.capacity, b.nsplats);
+                       b.shcol, b.fb, b.partial, b.queue, g, early_out_eps, b.seg_len_dev, b.capacity, b.nsplats, b.bin_done);
     if (between) (void)hipEventRecord(between, s);
-    if (b.seg_len < 0x40000000u)
+    if (b.seg_len < 0x40000000u && !b.bin_done)
         hipLaunchKernelGGL(k_combine, dim3(nbins), dim3(BLEND_THREADS), 0, s, b.seg_start, (const float4*)b.partial, b.fb, g);
 }
 

@@ -74,8 +74,8 @@ typedef struct gsr_timings {
     float ms_project_key; /* projection + depth key + min/max            */
     float ms_sort;        /* quantise + 2 radix passes -> depthIndex      */
     float ms_bin;         /* coarse bin count/scan/scatter                */
-    float ms_blend;       /* k_blend alone: tile composite, the dominant kernel */
-    float ms_combine;     /* k_combine: fold of the per-segment partials  */
+    float ms_blend;       /* k_blend: tile composite (and the fold of multi-segment bins), the dominant kernel */
+    float ms_combine;     /* k_combine: fold of the per-segment partials; 0 when the fold runs inside k_blend (default) */
     float ms_total;       /* first event -> last event                    */
     uint64_t visible;     /* V: splats with a non-empty screen bbox (within the band) */
     uint64_t bin_entries; /* entries in the coarse (32x32 px) bin lists   */

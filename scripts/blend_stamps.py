@@ -16,7 +16,7 @@ cfg = gh.synth.CONFIGS[config]
 W, H = cfg["width"], cfg["height"]
 scene = gh.Scene()
 scene.setData(gh.synth.config_rows(config))
-r = gh.HIPRenderer(W, H, timing=True, lib_path=lib)
+r = gh.HIPRenderer(W, H, timing=True, lib_path=lib, early_out_eps=float(os.environ.get("EPS", "0")))
 r.render(scene, gh.orbit_camera(0, 120, W, H, cfg["fx"]))
 L = r._L
 import numpy as np

@@ -24,6 +24,7 @@ L = r._L
 
 
 def show(title, a, names):
+    a0 = a
     a = a[a[:, 5] != 0].astype(np.int64)
     t0 = a[:, 0].min()
     print("%s: %d workgroups, kernel span %.1f us (first start -> last end)" % (title, len(a), 0.01 * (a[:, 5].max() - t0)))
@@ -33,6 +34,10 @@ def show(title, a, names):
         print("   %-34s mean %5.2f  p90 %5.2f  max %5.2f us" % (nm, d.mean(), np.percentile(d, 90), d.max()))
     life = (a[:, 5] - a[:, 0]) * 0.01
     print("   workgroup lifetime                 mean %5.2f  p90 %5.2f  max %5.2f us" % (life.mean(), np.percentile(life, 90), life.max()))
+    ids = np.nonzero(a0[:, 5] != 0)[0]
+    order = np.argsort(-life)[:8]
+    print("   slowest workgroups (blockIdx: lifetime us): " + ", ".join("%d: %.1f" % (ids[k], life[k]) for k in order))
+    print("   lifetime by position: first 4 " + " ".join("%.1f" % x for x in life[:4]) + " | p99 %.1f | last 4 " % np.percentile(life, 99) + " ".join("%.1f" % x for x in life[-4:]))
 
 
 buf = np.zeros(2 * 4096 * 8, dtype=np.uint32)

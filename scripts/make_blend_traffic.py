@@ -60,7 +60,7 @@ doc = {
     "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for 16-B-per-lane reads -> doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact; rocprofv3 reports both in KB (x1024); for this kernel's 32-byte record gathers the doubling is an upper bound: true traffic lies between fetch_raw + write and 2 x fetch_raw + write",
     "frames_in_flight": leg(grids[0], "GSR_FLAG_THROUGHPUT: %d workgroups (the timed region of the default bench)" % grids[0]),
     "one_frame": leg(grids[-1], "default context: %d workgroups (bench.py's one_frame_in_flight leg)" % grids[-1]),
-    "note": "counts L2<->fabric traffic incl. Infinity Cache hits; the 32 MB record array is cache resident. Above the algorithmic 32D+16P because each 32-B record gather pulls a whole line and the segment partials are written, then re-read by k_combine.",
+    "note": "counts L2<->fabric traffic incl. Infinity Cache hits; the 32 MB record array is cache resident. Above the algorithmic 32D+16P because each 32-B record gather pulls a whole line and the segment partials are written, then re-read by the fold at the end of k_blend.",
 }
 json.dump(doc, open(os.path.join(ROOT, "profiles", "blend_traffic.json"), "w"), indent=1)
 print(json.dumps(doc, indent=1))

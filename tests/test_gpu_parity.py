@@ -872,3 +872,42 @@ def test_sort_orders_give_the_same_permutation(gh, oracle, scenes, monkeypatch, 
             assert mm == omm and np.array_equal(keys, okeys), (name, k)
             assert np.array_equal(r.lastDepthIndex(), odi), (name, k, order)
         r.dispose()
+
+
+@pytest.mark.gpu
+def test_fold_inside_the_compositor_matches_the_separate_kernel(gh, monkeypatch):
+    """Bins cut into several segments are folded by the workgroup that delivers the bin's last segment (inside k_blend;
+    the partials cross XCDs with agent-scope stores and loads).  The fold order is fixed, so the image must equal the
+    separate k_combine launch (GSR_FUSE_COMBINE=0) bit for bit -- on every pose, with several frames queued back to
+    back (a stale partial from the previous frame would show), and for a second context on the same device."""
+    cfg = gh.synth.CONFIGS["C3"]
+    W, H = cfg["width"], cfg["height"]
+    scene = gh.Scene()
+    scene.setData(gh.synth.config_rows("C3"))
+    monkeypatch.setenv("GSR_FUSE_COMBINE", "0")
+    ref = gh.HIPRenderer(W, H)
+    monkeypatch.delenv("GSR_FUSE_COMBINE")
+    a, b = gh.HIPRenderer(W, H), gh.HIPRenderer(W, H)
+    poses = list(range(0, 120, 5))
+    ref.render(scene, gh.orbit_camera(0, 120, W, H, cfg["fx"]))
+    a.render(scene, gh.orbit_camera(0, 120, W, H, cfg["fx"]))
+    b.render(scene, gh.orbit_camera(0, 120, W, H, cfg["fx"]))
+    multi = 0
+    for k in poses:
+        cam = gh.orbit_camera(k, 120, W, H, cfg["fx"])
+        ref.render(scene, cam)
+        want = ref.readPixelsFloat()
+        for r in (a, b):      # three frames queued without a sync in between, the last one is read
+            r.set_camera(gh.orbit_camera((k + 60) % 120, 120, W, H, cfg["fx"]))
+            r.render_async()
+            r.set_camera(gh.orbit_camera((k + 30) % 120, 120, W, H, cfg["fx"]))
+            r.render_async()
+            r.set_camera(cam)
+            r.render_async()
+        for r in (a, b):
+            r.sync()
+            assert np.array_equal(r.readPixelsFloat(), want), k
+        multi += 1
+    assert multi == len(poses)
+    for r in (ref, a, b):
+        r.dispose()
