@@ -59,6 +59,10 @@ __device__ unsigned int g_blend_stamps[4096 * 4 * 16];
 // 7 waves per SIMD: the kernel needs 74 VGPRs unconstrained (6 waves); capped at 72 it spills one register pair that is
 // stored once per workgroup and reloaded once per work item, and the seventh wave hides more of the LDS/barrier
 // waits (measured: k_blend -5.7 % alone; 8 waves = 64 VGPRs spills inside the loops and is no better).
+// (Fetching the next entry's record before the current entry's arithmetic -- two register sets, loop unrolled by two --
+//  was measured 24 % SLOWER at 7 and at 6 waves: the compiler's s_waitcnt placement in the rotated loop waits for the
+//  new reads as well, and the extra scalar control costs more than the hidden LDS latency; the other waves of the
+//  SIMD already cover that latency.)
 __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_blend(const uint32_t* __restrict__ items,
                                                          const uint32_t* __restrict__ seg_start,
                                                          const uint32_t* __restrict__ bin_start,

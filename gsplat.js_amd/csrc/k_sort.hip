@@ -140,6 +140,11 @@ constexpr int CS_COLS = 16;
 constexpr int CS_SLOTS = CS_THREADS / CS_COLS;  // 32
 constexpr int CS_BATCH = 8;
 
+// KEEP: a slot holds at most CS_KEEP rows (tables of up to CS_SLOTS * CS_KEEP = 512 rows: every scene up to 1 M splats),
+// which stay in registers between the two sweeps -- one global round trip less in a kernel that is nothing but round trips.
+constexpr int CS_KEEP = 16;
+
+template <bool KEEP>
 __global__ __launch_bounds__(CS_THREADS) void k_column_scan(uint32_t* __restrict__ table, uint32_t* __restrict__ total,
                                                             int ncols, uint32_t nrows)
 {
@@ -153,7 +158,13 @@ __global__ __launch_bounds__(CS_THREADS) void k_column_scan(uint32_t* __restrict
     uint32_t* p = table + (size_t)r0 * ncols + (ok ? col : 0);
 
     uint32_t sum = 0;
-    if (ok) {
+    uint32_t kept[KEEP ? CS_KEEP : 1];
+    if (KEEP) {
+#pragma unroll
+        for (int k = 0; k < CS_KEEP; k++) kept[k] = (ok && r0 + k < r1) ? p[(size_t)k * ncols] : 0u;
+#pragma unroll
+        for (int k = 0; k < CS_KEEP; k++) sum += kept[k];
+    } else if (ok) {
         for (uint32_t r = r0; r < r1; r += CS_BATCH) {
             uint32_t v[CS_BATCH];
 #pragma unroll
@@ -173,14 +184,22 @@ __global__ __launch_bounds__(CS_THREADS) void k_column_scan(uint32_t* __restrict
     }
     if (ok) {
         uint32_t run = base;
-        for (uint32_t r = r0; r < r1; r += CS_BATCH) {
-            uint32_t v[CS_BATCH];
+        if (KEEP) {
 #pragma unroll
-            for (int k = 0; k < CS_BATCH; k++) v[k] = (r + k < r1) ? p[(size_t)(r - r0 + k) * ncols] : 0u;
+            for (int k = 0; k < CS_KEEP; k++) {
+                if (r0 + k < r1) p[(size_t)k * ncols] = run;
+                run += kept[k];
+            }
+        } else {
+            for (uint32_t r = r0; r < r1; r += CS_BATCH) {
+                uint32_t v[CS_BATCH];
 #pragma unroll
-            for (int k = 0; k < CS_BATCH; k++) {
-                if (r + k < r1) p[(size_t)(r - r0 + k) * ncols] = run;
-                run += v[k];
+                for (int k = 0; k < CS_BATCH; k++) v[k] = (r + k < r1) ? p[(size_t)(r - r0 + k) * ncols] : 0u;
+#pragma unroll
+                for (int k = 0; k < CS_BATCH; k++) {
+                    if (r + k < r1) p[(size_t)(r - r0 + k) * ncols] = run;
+                    run += v[k];
+                }
             }
         }
         if (slot == 0) total[col] = tot;
@@ -189,7 +208,9 @@ __global__ __launch_bounds__(CS_THREADS) void k_column_scan(uint32_t* __restrict
 
 void launch_column_scan(uint32_t* table, uint32_t* total, int ncols, uint32_t nrows, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_column_scan, dim3((ncols + CS_COLS - 1) / CS_COLS), dim3(CS_THREADS), 0, s, table, total, ncols, nrows);
+    const dim3 grid((ncols + CS_COLS - 1) / CS_COLS), block(CS_THREADS);
+    if (nrows <= (uint32_t)CS_SLOTS * CS_KEEP) hipLaunchKernelGGL(k_column_scan<true>, grid, block, 0, s, table, total, ncols, nrows);
+    else hipLaunchKernelGGL(k_column_scan<false>, grid, block, 0, s, table, total, ncols, nrows);
 }
 
 // ---------------------------------------------------------------------------
