@@ -200,7 +200,10 @@ constexpr uint32_t SEG_TARGET_THROUGHPUT = 1300; // GSR_FLAG_THROUGHPUT: concurr
 // resident workgroup exits.  With 8 per CU, one item in eight began at 222 us of a 270 us kernel (in-kernel stamps,
 // scripts/blend_stamps.py): k_blend 271 -> 252 us on C3 at 7 per CU.
 constexpr uint32_t BLEND_WG_PER_CU_EXACT = 7;
-constexpr uint32_t BLEND_WG_PER_CU_THROUGHPUT = 6;  // leaves room for the other contexts' kernels
+// Contexts that overlap with others' kernels (GSR_FLAG_THROUGHPUT): 6 per CU left a wave slot per SIMD to the other
+// contexts and was best while the fold of the partials was a kernel of its own; with the fold inside k_blend 7 is
+// (bench.py, three frames in flight, C3: 3324 -> 3400 frames/s, reproducible; C2 -0.8 %, C4 and early-out unchanged).
+constexpr uint32_t BLEND_WG_PER_CU_THROUGHPUT = 7;
 constexpr uint32_t SEG_LEN_WHOLE_BIN = 0x7fffff00u;
 
 // Sort order.  Up to BUCKET_ORDER_MAX_N splats the radix sort runs high digit first with one workgroup per bucket
