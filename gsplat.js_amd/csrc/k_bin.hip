@@ -345,6 +345,7 @@ __global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(8,
         if (blockIdx.y == 0) bin_finalize_body(fa);
         return;
     }
+    const uint32_t blk = xcd_group_remap(blockIdx.x, gridDim.x - (FUSED ? 1u : 0u));   // neighbouring rank blocks on one XCD (gsr_internal.h)
     constexpr int WAVES_PER_GROUP = SCAT_WAVES / GROUPS;            // 4 or 2
     constexpr int GROUP_STEPS = SCAT_STEPS / GROUPS;                // 8 or 4
     constexpr int PAIR_WORDS = GROUPS / 2;                          // two 16-bit per-group counts / offsets per word
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(8,
     KSTAMP(1);
 
     // this wave's 2 steps of 64 consecutive ranks; rectangles clipped to the sub-grid, in sub-grid coordinates
-    const uint32_t gbegin = blockIdx.x * BIN_RANKS_PER_BLOCK + group * (GROUP_STEPS * WAVE);
+    const uint32_t gbegin = blk * BIN_RANKS_PER_BLOCK + group * (GROUP_STEPS * WAVE);
     uint32_t idx[SCAT_STEPS_PER_WAVE];
     BinRect br[SCAT_STEPS_PER_WAVE];
 #pragma unroll
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(8,
         for (int b = threadIdx.x; b < nb_s; b += SCAT_THREADS) {
             const int ly = b / sw, lx = b - ly * sw;
             const int gb = (sy0 + ly) * nbxb + sx0 + lx;  // the bin's index in the band
-            base[b] = bin_start[gb] + table[(size_t)blockIdx.x * nbins + gb];
+            base[b] = bin_start[gb] + table[(size_t)blk * nbins + gb];
         }
     } else {
         __shared__ uint32_t s_ws[SCAT_WAVES];
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(8,
         for (int gb = gb0; gb < gb1; gb++) {
             const int gy = gb / nbxb, gx = gb - gy * nbxb;
             const uint32_t c = bin_total[gb];
-            if (gx >= sx0 && gx < sx1 && gy >= sy0 && gy < sy1) base[(gy - sy0) * sw + (gx - sx0)] = run + table[(size_t)blockIdx.x * nbins + gb];
+            if (gx >= sx0 && gx < sx1 && gy >= sy0 && gy < sy1) base[(gy - sy0) * sw + (gx - sx0)] = run + table[(size_t)blk * nbins + gb];
             run += c;
         }
     }

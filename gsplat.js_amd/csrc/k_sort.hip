@@ -262,12 +262,13 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter(const uint32_t* __rest
     uint32_t* lkey = wsum + 3 * (BINS / WAVE);       // [keys_per_block]
     uint32_t* lidx = lkey + keys_per_block;          // [keys_per_block]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t blk = xcd_group_remap(blockIdx.x, gridDim.x);   // neighbouring key blocks on one XCD (gsr_internal.h)
     KSTAMP(0);
     // the two table reads of this workgroup do not depend on its keys: issued first
     uint32_t tot = 0, wg_base = 0;
     if (threadIdx.x < BINS) {
         tot = total[threadIdx.x];
-        wg_base = base[(size_t)blockIdx.x * BINS + threadIdx.x];
+        wg_base = base[(size_t)blk * BINS + threadIdx.x];
     }
     for (int d = threadIdx.x; d < SCAT_WAVES * BINS; d += SCAT_THREADS) (&cnt[0][0])[d] = 0;
     __syncthreads();
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter(const uint32_t* __rest
 
     const uint32_t per_wave = keys_per_block / SCAT_WAVES;  // multiple of 64
     const uint32_t steps = per_wave / WAVE;                 // <= SCAT_MAX_STEPS
-    const uint32_t wbegin = blockIdx.x * keys_per_block + wave * per_wave;
+    const uint32_t wbegin = blk * keys_per_block + wave * per_wave;
     const uint32_t wend = min(wbegin + per_wave, n);
 
     // phase 1: load this wave's keys (and, in the last pass, their indices) into registers; count digits per wave
