@@ -2,7 +2,9 @@
 """profiles/blend_traffic.json from the rocprofv3 --pmc passes of scripts/gpu_pmc.sh (gpurun_out/pmc/*).
 
 k_blend's HBM traffic and VALU instruction count per launch, for the two configurations bench.py runs: the timed region
-(several frames in flight: 6 workgroups per CU) and the one-frame leg (7 per CU), told apart by the dispatch's grid size.
+(several frames in flight, 2048-entry work items) and the one-frame leg (512-entry items).  Both launch 7 workgroups per
+CU, so they are told apart by dispatch order: under scripts/gpu_pmc.sh (--steps 12 --warmup 4, three contexts) the first
+3 + 4 + 12 = 19 k_blend dispatches of a pass belong to the timed region, the rest to the one-frame leg.
 The file is stamped with the build id of the library the counters were collected on (bench.py refuses other builds).
 gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide read -> doubled (MI355X_MICROARCH.md, HBM); both counters
 are in KB."""
@@ -17,24 +19,28 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "pmc")
 build_id = sys.argv[2] if len(sys.argv) > 2 else open(os.path.join(src, "build_id.txt")).read().strip()
 
-vals = {}   # (grid, counter) -> [values]
+THR_DISPATCHES = int(os.environ.get("THR_DISPATCHES", "19"))
+vals = {}   # (leg, counter) -> [values]
 dur = {}
+grid_of = {}
 for f in glob.glob(os.path.join(src, "*", "*", "*counter_collection.csv")):
-    for r in csv.DictReader(open(f)):
-        if "k_blend" not in r["Kernel_Name"]:
-            continue
-        grid = int(r["Grid_Size"]) // 256
-        vals.setdefault((grid, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
-        dur.setdefault(grid, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-grids = sorted({g for g, _ in vals})
-if len(grids) < 2:
-    raise SystemExit("expected k_blend dispatches of two grid sizes (one-frame leg and frames-in-flight leg), found %s" % grids)
+    rows = [r for r in csv.DictReader(open(f)) if "k_blend" in r["Kernel_Name"]]
+    ids = sorted({int(r["Dispatch_Id"]) for r in rows})
+    thr = set(ids[:THR_DISPATCHES])
+    for r in rows:
+        which = 0 if int(r["Dispatch_Id"]) in thr else 1
+        vals.setdefault((which, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+        dur.setdefault(which, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        grid_of[which] = int(r["Grid_Size"]) // 256
+grids = [0, 1]
+if not all((g, "FETCH_SIZE") in vals for g in grids):
+    raise SystemExit("expected k_blend dispatches of both legs in %s" % src)
 
 
 def leg(grid, what):
     med = lambda c: statistics.median(vals[(grid, c)]) if (grid, c) in vals else None
     fetch, write = med("FETCH_SIZE"), med("WRITE_SIZE")
-    out = {"config": what, "workgroups": grid, "dispatches": len(vals.get((grid, "FETCH_SIZE"), [])),
+    out = {"config": what, "workgroups": grid_of[grid], "dispatches": len(vals.get((grid, "FETCH_SIZE"), [])),
            "fetch_size_kb_raw": fetch, "write_size_kb_raw": write,
            "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
            "valu_wave_instructions_per_launch": med("SQ_INSTS_VALU"),
@@ -58,8 +64,8 @@ doc = {
     "workload": "C3 exact mode, bench.py --steps 12 --warmup 4 under rocprofv3 --pmc (kernels serialised by the profiler); medians per configuration",
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ counters, separate passes (scripts/gpu_pmc.sh); summary of all kernels in profiles/r02_pmc_c3_exact.txt",
     "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for 16-B-per-lane reads -> doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact; rocprofv3 reports both in KB (x1024); for this kernel's 32-byte record gathers the doubling is an upper bound: true traffic lies between fetch_raw + write and 2 x fetch_raw + write",
-    "frames_in_flight": leg(grids[0], "GSR_FLAG_THROUGHPUT: %d workgroups (the timed region of the default bench)" % grids[0]),
-    "one_frame": leg(grids[-1], "default context: %d workgroups (bench.py's one_frame_in_flight leg)" % grids[-1]),
+    "frames_in_flight": leg(0, "GSR_FLAG_THROUGHPUT contexts (the timed region of the default bench): the first %d dispatches" % THR_DISPATCHES),
+    "one_frame": leg(1, "default context (bench.py's one_frame_in_flight leg): the remaining dispatches"),
     "note": "counts L2<->fabric traffic incl. Infinity Cache hits; the 32 MB record array is cache resident. Above the algorithmic 32D+16P because each 32-B record gather pulls a whole line and the segment partials are written, then re-read by the fold at the end of k_blend.",
 }
 json.dump(doc, open(os.path.join(ROOT, "profiles", "blend_traffic.json"), "w"), indent=1)
