@@ -1180,7 +1180,8 @@ int gsr_device_info(gsr_ctx* c, char* name, int32_t name_len, int32_t* cus, int3
     if (!c) return GSR_ERR_ARG;
     hipDeviceProp_t p;
     HIP_TRY(c, hipGetDeviceProperties(&p, c->device));
-    if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s (%s)", p.name, p.gcnArchName);
+    // (the marketing name comes from libdrm's amdgpu.ids and is empty where that file is missing)
+    if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s (%s)", p.name[0] ? p.name : "AMD GPU", p.gcnArchName);
     if (cus) *cus = p.multiProcessorCount;
     if (clock_khz) *clock_khz = p.clockRate;
     return GSR_OK;

@@ -131,8 +131,9 @@ export class HIPRenderer {
     renderDeviceScene(camera: Camera): void;
     dispose(): void;
     /** RGBA8, row 0 = top, round(clamp(x,0,1)*255), premultiplied alpha */
-    readPixels(): Uint8Array;
-    readPixelsFloat(): Float32Array;
+    /** RGBA8, row 0 = top; pass an array of width*height*4 elements to have it filled and returned (no allocation per frame). */
+    readPixels(out?: Uint8Array): Uint8Array;
+    readPixelsFloat(out?: Float32Array): Float32Array;
     lastDepthIndex(): Uint32Array;
     stats(): FrameStats;
     deviceInfo(): { name: string; computeUnits: number; clockKhz: number };

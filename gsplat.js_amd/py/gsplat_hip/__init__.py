@@ -440,13 +440,21 @@ class HIPRenderer:
         self._check(self._L.gsr_read_depth_index(self._ctx, out.ctypes.data))
         return out
 
-    def readPixelsFloat(self):
-        out = np.empty((self.height, self.width, 4), dtype=np.float32)
+    def readPixelsFloat(self, out=None):
+        """premultiplied RGBA float32 [H, W, 4], row 0 = top; `out` (C-contiguous, that shape and dtype) is filled and returned"""
+        if out is None:
+            out = np.empty((self.height, self.width, 4), dtype=np.float32)
+        elif out.dtype != np.float32 or out.size != self.height * self.width * 4 or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be a C-contiguous float32 array of height*width*4 elements")
         self._check(self._L.gsr_read_pixels_rgba32f(self._ctx, out.ctypes.data))
         return out
 
-    def readPixels(self):
-        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+    def readPixels(self, out=None):
+        """RGBA8 [H, W, 4], row 0 = top; `out` (C-contiguous uint8, height*width*4 elements) is filled and returned"""
+        if out is None:
+            out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        elif out.dtype != np.uint8 or out.size != self.height * self.width * 4 or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be a C-contiguous uint8 array of height*width*4 elements")
         self._check(self._L.gsr_read_pixels_rgba8(self._ctx, out.ctypes.data))
         return out
 

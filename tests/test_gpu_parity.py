@@ -911,3 +911,24 @@ def test_fold_inside_the_compositor_matches_the_separate_kernel(gh, monkeypatch)
     assert multi == len(poses)
     for r in (ref, a, b):
         r.dispose()
+
+
+@pytest.mark.gpu
+def test_read_pixels_into_a_caller_buffer(gh):
+    """readPixels(out) / readPixelsFloat(out) fill and return the caller's array (no allocation per frame) and refuse
+    arrays of the wrong type or size."""
+    cfg = gh.synth.CONFIGS["C1"]
+    W, H = cfg["width"], cfg["height"]
+    scene = gh.Scene()
+    scene.setData(gh.synth.config_rows("C1"))
+    r = gh.HIPRenderer(W, H)
+    r.render(scene, gh.orbit_camera(5, 120, W, H, cfg["fx"]))
+    a8 = np.zeros((H, W, 4), dtype=np.uint8)
+    af = np.zeros(H * W * 4, dtype=np.float32)
+    assert r.readPixels(a8) is a8 and np.array_equal(a8, r.readPixels())
+    assert r.readPixelsFloat(af) is af and np.array_equal(af.reshape(H, W, 4), r.readPixelsFloat())
+    with pytest.raises(ValueError):
+        r.readPixels(np.zeros((H, W, 3), dtype=np.uint8))
+    with pytest.raises(ValueError):
+        r.readPixelsFloat(a8)
+    r.dispose()
