@@ -300,9 +300,10 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
                 // Visibility between workgroups on different XCDs (one L2 each) WITHOUT a release fence: an agent-scope
                 // release is buffer_wbl2, a write-back of the XCD's whole L2, and one per work item made the kernel 3.5x
                 // slower.  Instead the partials are the only data exchanged and they move with agent-scope accesses on
-                // both sides (sc1: stores write through to memory, loads do not hit another XCD's stale line -- what
-                // relaxed agent-scope atomics compile to); the stores are complete (vmcnt 0, every thread, then the
-                // barrier) before thread 0 counts the arrival with an agent-scope atomic.
+                // both sides (sc1: the stores write through, the loads bypass the CU's L1): every storing wave drains its
+                // stores (vmcnt 0), the workgroup's barrier, then ONE lane counts the arrival with an agent-scope atomic
+                // add; the workgroup whose add came last takes one agent-scope acquire and loads behind a barrier
+                // (MI355X_MICROARCH.md, Workgroup dispatch ... inter-workgroup visibility, Valid forms).
                 typedef float v4f __attribute__((ext_vector_type(4)));
                 const v4f o0 = {r00, g00, b00, T00}, o1 = {r10, g10, b10, T10}, o2 = {r01, g01, b01, T01}, o3 = {r11, g11, b11, T11};
                 asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:1024 sc1\n\t"
@@ -310,8 +311,18 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
                              "s_waitcnt vmcnt(0)"
                              :: "v"(p), "v"(o0), "v"(o1), "v"(o2), "v"(o3) : "memory");
                 __syncthreads();
-                if (threadIdx.x == 0)
-                    s_last = (__hip_atomic_fetch_add(&bin_done[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nseg - 1u) ? 1u : 0u;
+                if (threadIdx.x == 0) {
+                    const bool last = __hip_atomic_fetch_add(&bin_done[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nseg - 1u;
+                    if (last) {
+                        // one agent-scope acquire on the folding CU (buffer_inv sc1: drops this CU's L1, about 1.7 us, once
+                        // per multi-segment bin) in front of the barrier the other waves load behind.  The loads below are
+                        // sc1 and bypass the L1 by themselves; the acquire makes the hand-off the documented form
+                        // (MI355X_MICROARCH.md, Valid forms) rather than one that rests on that alone.
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    s_last = last ? 1u : 0u;
+                }
                 __syncthreads();
                 if (s_last) {
                     float cr[4] = {0.f, 0.f, 0.f, 0.f}, cg[4] = {0.f, 0.f, 0.f, 0.f}, cb[4] = {0.f, 0.f, 0.f, 0.f}, cT[4] = {1.f, 1.f, 1.f, 1.f};
