@@ -932,3 +932,30 @@ def test_read_pixels_into_a_caller_buffer(gh):
     with pytest.raises(ValueError):
         r.readPixelsFloat(a8)
     r.dispose()
+
+
+@pytest.mark.gpu
+def test_band_contexts_with_multi_segment_bins_equal_the_full_frame(gh):
+    """The multi-GPU partition at the size where bins are cut into segments (C3: up to ~50 segments per bin), so that band
+    contexts run the fold of the partials too: four band contexts, each compositing its columns of the same frame,
+    reproduce the full-frame context's image bit for bit, on several poses."""
+    cfg = gh.synth.CONFIGS["C3"]
+    W, H = cfg["width"], cfg["height"]
+    scene = gh.Scene()
+    scene.setData(gh.synth.config_rows("C3"))
+    edges = [0, 448, 960, 1472, W]
+    full = gh.HIPRenderer(W, H)
+    parts = [gh.HIPRenderer(W, H, band=(x0, x1)) for x0, x1 in zip(edges[:-1], edges[1:])]
+    for k in (7, 52, 99):
+        cam = gh.orbit_camera(k, 120, W, H, cfg["fx"])
+        full.render(scene, cam)
+        want = full.readPixelsFloat()
+        got = np.zeros_like(want)
+        for r, x0, x1 in zip(parts, edges[:-1], edges[1:]):
+            r.render(scene, cam)
+            img = r.readPixelsFloat()
+            assert not img[:, :x0].any() and not img[:, x1:].any()
+            got[:, x0:x1] = img[:, x0:x1]
+        assert np.array_equal(got, want), k
+    for r in [full] + parts:
+        r.dispose()
