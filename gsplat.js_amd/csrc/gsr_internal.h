@@ -115,7 +115,8 @@ __device__ __forceinline__ uint32_t xcd_group_remap(uint32_t bid, uint32_t nwg)
 #endif
 constexpr uint32_t PROJ_THREADS = 256;
 constexpr int FRAME_SLOTS = 64;
-constexpr int FRAME_SLOT_WORDS = 32;   // words per slot (one 128-byte line): [0] min depth, [1] max depth, [2] visible, [3] tiles
+constexpr int FRAME_SLOT_WORDS = 32;   // words per slot (one 128-byte line): [0] min depth, [1] max depth, [2] visible, [3] tiles,
+                                       // [4] sum of opacity byte x tiles / 16 (the frame's optical depth, k_bin_finalize)
 void launch_project_key(const SceneSoA& sc, uint32_t n, const CamParams* cam_dev, int do_project, int32_t* depth,
                         int32_t* slots /* FRAME_SLOTS * FRAME_SLOT_WORDS, reset by k_begin_frame */, Record* rec, uint2* bbox,
                         uint32_t* rect /* n: packed bin rectangle per splat */, hipStream_t s);
@@ -178,6 +179,9 @@ struct BinBuffers {
     uint32_t seg_target_items;   // full segments the frame should be cut into at least (long lists -> longer segments)
     uint32_t nblocks;
     uint32_t* bin_done;          // nbins: the compositor's per-bin arrival counters, zeroed by the finalize step (may be null)
+    int32_t long_policy;         // work items of at least seg_len_long entries: 1 always, 0 never, -1 where the frame's optical depth >= long_tau
+    uint32_t seg_len_long, long_tau;
+    uint32_t npix;               // pixels of this context's band (the optical depth is per pixel)
 };
 void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s);
 
@@ -199,6 +203,7 @@ struct BlendBuffers {
     uint32_t nsplats;
     uint32_t* bin_done;         // nbins arrival counters, zeroed by the finalize step: the workgroup delivering a bin's last
                                 // segment folds the bin inside k_blend; null = the separate k_combine launch does it
+    uint32_t saturate;          // 1: quadrants whose pixels can no longer change are skipped (bit-identical; k_blend); 0: A/B knob
 };
 // `between` (may be null) is recorded after k_blend and before k_combine
 void launch_blend(const BlendBuffers& b, const BinGrid& g, float early_out_eps, hipStream_t s, hipEvent_t between);

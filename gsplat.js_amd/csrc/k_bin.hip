@@ -171,6 +171,7 @@ struct FinalizeArgs {
     uint32_t* queue; uint32_t queue_start;
     uint64_t* mailbox;
     uint32_t* bin_done;
+    int long_policy; uint32_t seg_len_long, long_tau, npix;   // see BinBuffers
 };
 
 // One workgroup of FIN_THREADS threads.  It runs as an EXTRA workgroup of k_bin_scatter (the scatter workgroups
@@ -196,10 +197,18 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa)
     UN<1> ent = {{0}}, ent_tot;
     for (int b = b0; b < b1; b++) ent.v[0] += bin_total[b];
     block_exclusive_scan<1>(ent, s_w, &ent_tot);
+    // Long work items where the frame saturates (gsr_api.cpp, "Work-item length"): the frame's optical depth
+    // tau = sum(opacity x tiles) x 256 / pixels from the projection's slots ([4] holds opacity byte x tiles / 16)
+    UN<1> ot = {{0}}, ot_tot;
+    if (have_counts && threadIdx.x < FRAME_SLOTS) ot.v[0] = (uint32_t)slots[(size_t)threadIdx.x * FRAME_SLOT_WORDS + 4];
+    block_exclusive_scan<1>(ot, s_w, &ot_tot);
+    const bool dense = (uint64_t)ot_tot.v[0] * (16u * 256u) >= (uint64_t)fa.long_tau * 255u * (uint64_t)fa.npix;
+    uint32_t seg_min = seg_len_min;
+    if (seg_len_min < 0x40000000u && (fa.long_policy > 0 || (fa.long_policy < 0 && dense))) seg_min = max(seg_len_min, fa.seg_len_long);
     // segment length of this frame (a multiple of 256; the whole-bin sentinel of early termination passes through)
-    uint32_t seg_len = seg_len_min;
-    if (seg_len_min < 0x40000000u)
-        seg_len = min(max(ent_tot.v[0] / seg_target_items / 256u * 256u, seg_len_min), max(SEG_LEN_MAX, seg_len_min));
+    uint32_t seg_len = seg_min;
+    if (seg_min < 0x40000000u)
+        seg_len = min(max(ent_tot.v[0] / seg_target_items / 256u * 256u, seg_min), max(SEG_LEN_MAX, seg_min));
     // Items are emitted heaviest first -- every full segment, then the bins' last segments by size class --
     // so the compositor's queue hands out the long items while the chip is still full and only short
     // ones are left for the tail.  Streams: entries, segments, full segments, class-1 and class-2 partials.
@@ -522,7 +531,7 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
     }
     const FinalizeArgs fa{b.bin_total, nbins, b.seg_len, b.seg_target_items, b.items_by_size, b.seg_len_dev, b.max_items, b.capacity,
                           b.slots, n ? 1u : 0u, b.bin_start, b.seg_start, b.items, b.overflow, b.visible, b.tile_entries, b.accum,
-                          b.report, b.queue, b.queue_start, b.mailbox, b.bin_done};
+                          b.report, b.queue, b.queue_start, b.mailbox, b.bin_done, b.long_policy, b.seg_len_long, b.long_tau, b.npix};
     const bool fused = n && nbins <= 4096;   // see k_bin_scatter
     if (!fused) hipLaunchKernelGGL(k_bin_finalize, dim3(1), dim3(FIN_THREADS), 0, s, fa);
     if (n) {

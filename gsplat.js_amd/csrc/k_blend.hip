@@ -71,7 +71,7 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
                                                          const float4* __restrict__ shcol, float4* __restrict__ fb,
                                                          float4* __restrict__ partial, uint32_t* __restrict__ queue,
                                                          BinGrid g, float eps, const uint32_t* __restrict__ seg_len_dev, uint32_t capacity,
-                                                         uint32_t nsplats, uint32_t* __restrict__ bin_done)
+                                                         uint32_t nsplats, uint32_t* __restrict__ bin_done, uint32_t saturate)
 {
     const uint32_t seg_len = *seg_len_dev;  // this frame's list entries per work item (k_bin_finalize)
     // [0]: ux, uy, -dot(u, c - bin origin), wx   [1]: wy, -dot(w, c - bin origin), log2(opacity), blue   [2]: red, green
@@ -132,6 +132,7 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
         const uint32_t begin = min(bin_start[bin] + seg * seg_len, bin_end);
         const uint32_t end = min(begin + seg_len, bin_end);
         bool done = false;
+        uint32_t alive = 15u;   // quadrants of my tile that can still change (wave-uniform); see the saturation test below
 #ifdef GSR_BLEND_STAMPS
         a_item_len = end - begin;
 #endif
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
             if (!done) {
                 const uint32_t cnt = min((uint32_t)CHUNK, end - base);
                 for (uint32_t c0 = 0; c0 < cnt; c0 += WAVE) {
-                    const uint32_t mine = (s_mask[c0 + lane] >> (wave * 4)) & 15u;  // entry (c0+lane) vs my tile
+                    const uint32_t mine = (s_mask[c0 + lane] >> (wave * 4)) & alive;  // entry (c0+lane) vs the live quadrants of my tile
                     uint64_t bal = __ballot(mine != 0u);
 #ifdef GSR_BLEND_STAMPS
                     a_entries += __popcll(bal);
@@ -257,6 +258,28 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
                             break;
                         }
                     }
+                }
+                // ---- saturation that changes no bit (once per chunk) ----
+                // A pixel whose transmittance is below 2^-27 of its smallest colour channel is finished: every later
+                // weight is w <= T (opacity <= 1, exp <= 1), colours are <= 1, so w*c is under half an ulp of each channel
+                // and fma(w, c, C) returns C; its alpha is 1 - T = 1.0f for any T that small.  The segment's own T
+                // would still shrink, but only ever multiplies later segments' colours (the fold), whose terms are then
+                // under half an ulp of the folded colour as well: the image is bit-identical to compositing every entry
+                // (test_saturated_quadrants_are_skipped_without_changing_a_bit).  A quadrant whose 64 pixels are all
+                // finished drops out of `alive`; a tile with no live quadrant is done, a bin with no live tile ends its
+                // work item (s_done).  Pixels with a zero channel finish only at T == 0.
+                if (!done) {
+                    constexpr float K = 0x1p-27f;
+                    const bool f00 = T00 < K * fminf(r00, fminf(g00, b00)) || T00 == 0.0f;
+                    const bool f10 = T10 < K * fminf(r10, fminf(g10, b10)) || T10 == 0.0f;
+                    const bool f01 = T01 < K * fminf(r01, fminf(g01, b01)) || T01 == 0.0f;
+                    const bool f11 = T11 < K * fminf(r11, fminf(g11, b11)) || T11 == 0.0f;
+                    alive = (__ballot(!f00) ? 1u : 0u) | (__ballot(!f10) ? 2u : 0u) | (__ballot(!f01) ? 4u : 0u) | (__ballot(!f11) ? 8u : 0u);
+                    if (saturate && alive == 0u) {
+                        done = true;
+                        if (lane == 0) atomicAdd(&s_done, 1u);
+                    }
+                    if (!saturate) alive = 15u;
                 }
             }
 #ifdef GSR_BLEND_STAMPS
@@ -414,7 +437,7 @@ void launch_blend(const BlendBuffers& b, const BinGrid& g, float early_out_eps, 
     const int nbins = (g.bx_hi - g.bx_lo) * g.nby;
     if (nbins <= 0) return;
     hipLaunchKernelGGL(k_blend, dim3(b.grid), dim3(BLEND_THREADS), 0, s, b.items, b.seg_start, b.bin_start, b.list, b.rec,
-                       b.shcol, b.fb, b.partial, b.queue, g, early_out_eps, b.seg_len_dev, b.capacity, b.nsplats, b.bin_done);
+                       b.shcol, b.fb, b.partial, b.queue, g, early_out_eps, b.seg_len_dev, b.capacity, b.nsplats, b.bin_done, b.saturate);
     if (between) (void)hipEventRecord(between, s);
     if (b.seg_len < 0x40000000u && !b.bin_done)
         hipLaunchKernelGGL(k_combine, dim3(nbins), dim3(BLEND_THREADS), 0, s, b.seg_start, (const float4*)b.partial, b.fb, g);

@@ -145,9 +145,10 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_project_key(SceneSoA sc, uint3
 {
     const CamParams& cam = *camp;  // uniform address: scalar loads
     __shared__ int32_t s_min[4], s_max[4];
-    __shared__ uint32_t s_vis[4], s_til[4];
+    __shared__ uint32_t s_vis[4], s_til[4], s_oti[4];
     int32_t dmin = 0x7fffffff, dmax = (int32_t)0x80000000;
     uint32_t vis = 0, tiles = 0;   // this thread's visible splats and the 16x16 tiles their boxes overlap (V and D of the byte model)
+    uint32_t otiles = 0;           // sum of opacity byte x tiles / 16 over them
     const int bx_lo = cam.band_px0 / BIN_PX, bx_hi = (cam.band_px1 + BIN_PX - 1) / BIN_PX;   // this context's band of bin columns
 
     const uint32_t i = blockIdx.x * PROJ_THREADS + threadIdx.x;
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_project_key(SceneSoA sc, uint3
 
         if (do_project) {
             uint2 bb = make_uint2(BBOX_INVISIBLE_X, BBOX_INVISIBLE_Y);
+            uint32_t op8 = 0;   // the splat's opacity byte (for the frame's optical-depth figure below)
             do {
                 // :133-136  cam = view * vec4(p,1); pos2d = projection * cam
                 float camv[4], pos2d[4];
@@ -244,6 +246,7 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_project_key(SceneSoA sc, uint3
                 if (!finite4(majx, majy, minx, miny)) break;  // normalize(0,0) -> NaN: splat dropped
                 // :177-178: opacity; colour stays packed (:207 divides by 255 at composite time)
                 const float opacity = (float)((cw >> 24) & 0xffu) / 255.0f;
+                op8 = (cw >> 24) & 0xffu;
                 // :226-229 + viewport transform, image rows top-down
                 const float vcx = pos2d[0] / pos2d[3], vcy = pos2d[1] / pos2d[3];
                 const float cx = ((vcx + 1.0f) * 0.5f) * (float)cam.W;
@@ -299,7 +302,11 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_project_key(SceneSoA sc, uint3
             if ((bb.x & 0xffffu) <= (bb.x >> 16)) {
                 vis++;
                 const int tx0 = max((int)(bb.x & 0xffffu) / TILE, bx_lo * BIN_TILES), tx1 = min((int)(bb.x >> 16) / TILE, bx_hi * BIN_TILES - 1);
-                tiles += (uint32_t)((tx1 - tx0 + 1) * ((int)(bb.y >> 16) / TILE - (int)(bb.y & 0xffffu) / TILE + 1));
+                const uint32_t nt = (uint32_t)((tx1 - tx0 + 1) * ((int)(bb.y >> 16) / TILE - (int)(bb.y & 0xffffu) / TILE + 1));
+                tiles += nt;
+                // opacity x tiles, /16 so that a slot's sum stays inside 32 bits (<= 255 * 4096 / 16 per splat): the frame's
+                // optical depth in the unit k_bin_finalize compares (FinalizeArgs::long_tau)
+                otiles += (op8 * min(nt, 4096u)) >> 4;
             }
         }
     }
@@ -311,9 +318,10 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_project_key(SceneSoA sc, uint3
         dmax = max(dmax, __shfl_xor(dmax, off));
         vis += __shfl_xor(vis, off);
         tiles += __shfl_xor(tiles, off);
+        otiles += __shfl_xor(otiles, off);
     }
     const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { s_min[wave] = dmin; s_max[wave] = dmax; s_vis[wave] = vis; s_til[wave] = tiles; }
+    if ((threadIdx.x & 63) == 0) { s_min[wave] = dmin; s_max[wave] = dmax; s_vis[wave] = vis; s_til[wave] = tiles; s_oti[wave] = otiles; }
     __syncthreads();
     if (threadIdx.x == 0) {
         int32_t* slot = slots + (size_t)(blockIdx.x & (FRAME_SLOTS - 1)) * FRAME_SLOT_WORDS;
@@ -322,6 +330,7 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_project_key(SceneSoA sc, uint3
         if (do_project) {
             atomicAdd(reinterpret_cast<uint32_t*>(&slot[2]), s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3]);
             atomicAdd(reinterpret_cast<uint32_t*>(&slot[3]), s_til[0] + s_til[1] + s_til[2] + s_til[3]);
+            atomicAdd(reinterpret_cast<uint32_t*>(&slot[4]), s_oti[0] + s_oti[1] + s_oti[2] + s_oti[3]);
         }
     }
 }
@@ -341,9 +350,9 @@ __global__ void k_begin_frame(CamParams cam, CamParams* __restrict__ dst, uint32
                               int32_t* __restrict__ slots)
 {
     // the frame slots: min <- INT_MAX, max <- INT_MIN (the values wasm/wasm.cpp:14-15 starts from), the counters <- 0
-    for (uint32_t t = threadIdx.x; t < (uint32_t)FRAME_SLOTS * 4; t += blockDim.x) {
-        const uint32_t k = t & 3u;
-        slots[(size_t)(t >> 2) * FRAME_SLOT_WORDS + k] = k == 0 ? 0x7fffffff : k == 1 ? (int32_t)0x80000000 : 0;
+    for (uint32_t t = threadIdx.x; t < (uint32_t)FRAME_SLOTS * 8; t += blockDim.x) {
+        const uint32_t k = t & 7u;
+        slots[(size_t)(t >> 3) * FRAME_SLOT_WORDS + k] = k == 0 ? 0x7fffffff : k == 1 ? (int32_t)0x80000000 : 0;
     }
     constexpr uint32_t WORDS = sizeof(CamParams) / 4;
     const uint32_t* src = reinterpret_cast<const uint32_t*>(&cam);

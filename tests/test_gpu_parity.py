@@ -935,27 +935,93 @@ def test_read_pixels_into_a_caller_buffer(gh):
 
 
 @pytest.mark.gpu
-def test_band_contexts_with_multi_segment_bins_equal_the_full_frame(gh):
-    """The multi-GPU partition at the size where bins are cut into segments (C3: up to ~50 segments per bin), so that band
-    contexts run the fold of the partials too: four band contexts, each compositing its columns of the same frame,
-    reproduce the full-frame context's image bit for bit, on several poses."""
+def test_band_contexts_with_multi_segment_bins_equal_the_full_frame(gh, monkeypatch):
+    """The multi-GPU partition at the size where bins are cut into segments (C3: up to ~50 segments per bin with short
+    work items), so that band contexts run the fold of the partials too: four band contexts, each compositing its columns
+    of the same frame, reproduce the full-frame context's image bit for bit, on several poses, when the work-item length
+    is pinned.  Left to itself every context picks the length from the optical depth of its OWN pixels (dense centre
+    bands: long items, sparse edge bands: short segments), and the bands then agree with the full frame to f32
+    association order (2e-6; RGBA8 within one step)."""
     cfg = gh.synth.CONFIGS["C3"]
     W, H = cfg["width"], cfg["height"]
     scene = gh.Scene()
     scene.setData(gh.synth.config_rows("C3"))
     edges = [0, 448, 960, 1472, W]
+    for pinned in ("0", None):
+        if pinned is None:
+            monkeypatch.delenv("GSR_LONG_ITEMS", raising=False)
+        else:
+            monkeypatch.setenv("GSR_LONG_ITEMS", pinned)
+        full = gh.HIPRenderer(W, H)
+        parts = [gh.HIPRenderer(W, H, band=(x0, x1)) for x0, x1 in zip(edges[:-1], edges[1:])]
+        for k in (7, 52, 99):
+            cam = gh.orbit_camera(k, 120, W, H, cfg["fx"])
+            full.render(scene, cam)
+            want = full.readPixelsFloat()
+            got = np.zeros_like(want)
+            for r, x0, x1 in zip(parts, edges[:-1], edges[1:]):
+                r.render(scene, cam)
+                img = r.readPixelsFloat()
+                assert not img[:, :x0].any() and not img[:, x1:].any()
+                got[:, x0:x1] = img[:, x0:x1]
+            if pinned is None:
+                assert np.abs(got - want).max() <= 2e-6, k
+            else:
+                assert np.array_equal(got, want), k
+        for r in [full] + parts:
+            r.dispose()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("long_items", ["0", "1"])
+def test_saturated_quadrants_are_skipped_without_changing_a_bit(gh, monkeypatch, long_items):
+    """k_blend drops a quadrant once every one of its pixels has a transmittance below 2^-27 of its smallest colour
+    channel: no later splat can change a bit of such a pixel (w <= T, c <= 1: w*c is under half an ulp of the channel; alpha
+    is 1 - T = 1.0f), and what the segment's own T would still become only multiplies later segments in the fold, whose
+    terms are then under half an ulp as well.  So the image must equal, BIT FOR BIT, the one composited without the skip
+    (GSR_SATURATE=0) -- with short segments (512 entries: the fold of partials is in play) and with long work items
+    (whole bins, where most of the skipping happens: 53 % of C3's list entries)."""
+    cfg = gh.synth.CONFIGS["C3"]
+    W, H = cfg["width"], cfg["height"]
+    scene = gh.Scene()
+    scene.setData(gh.synth.config_rows("C3"))
+    monkeypatch.setenv("GSR_LONG_ITEMS", long_items)
+    monkeypatch.setenv("GSR_SATURATE", "0")
     full = gh.HIPRenderer(W, H)
-    parts = [gh.HIPRenderer(W, H, band=(x0, x1)) for x0, x1 in zip(edges[:-1], edges[1:])]
-    for k in (7, 52, 99):
+    monkeypatch.delenv("GSR_SATURATE")
+    skip = gh.HIPRenderer(W, H)
+    for k in (2, 31, 64, 97):
         cam = gh.orbit_camera(k, 120, W, H, cfg["fx"])
         full.render(scene, cam)
-        want = full.readPixelsFloat()
-        got = np.zeros_like(want)
-        for r, x0, x1 in zip(parts, edges[:-1], edges[1:]):
+        skip.render(scene, cam)
+        assert np.array_equal(skip.readPixelsFloat(), full.readPixelsFloat()), k
+        assert np.array_equal(skip.readPixels(), full.readPixels()), k
+    full.dispose(); skip.dispose()
+
+
+@pytest.mark.gpu
+def test_long_and_short_work_items_agree(gh, monkeypatch):
+    """The work-item length is chosen per frame from the frame's optical depth (k_bin_finalize): long items where the
+    scene saturates.  The two cuts of a bin's list differ in f32 association order only: images within 2e-6, RGBA8
+    within one step, and the policy picks long items on C3 (tau 362) and short ones on C2 (tau 74) -- seen through the
+    number of work items, which the segment count of the statistics does not expose, so through the images: the
+    automatic choice equals the pinned one bit for bit."""
+    for name, expect in (("C3", "1"), ("C2", "0")):
+        cfg = gh.synth.CONFIGS[name]
+        W, H = cfg["width"], cfg["height"]
+        scene = gh.Scene()
+        scene.setData(gh.synth.config_rows(name))
+        cam = gh.orbit_camera(17, 120, W, H, cfg["fx"])
+        imgs = {}
+        for mode in ("0", "1", "auto"):
+            if mode == "auto":
+                monkeypatch.delenv("GSR_LONG_ITEMS", raising=False)
+            else:
+                monkeypatch.setenv("GSR_LONG_ITEMS", mode)
+            r = gh.HIPRenderer(W, H)
             r.render(scene, cam)
-            img = r.readPixelsFloat()
-            assert not img[:, :x0].any() and not img[:, x1:].any()
-            got[:, x0:x1] = img[:, x0:x1]
-        assert np.array_equal(got, want), k
-    for r in [full] + parts:
-        r.dispose()
+            imgs[mode] = (r.readPixelsFloat(), r.readPixels())
+            r.dispose()
+        assert np.abs(imgs["0"][0] - imgs["1"][0]).max() <= 2e-6
+        assert np.abs(imgs["0"][1].astype(np.int32) - imgs["1"][1].astype(np.int32)).max() <= 1
+        assert np.array_equal(imgs["auto"][0], imgs[expect][0]), name
