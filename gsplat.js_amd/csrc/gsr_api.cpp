@@ -224,10 +224,14 @@ constexpr uint32_t LOCAL_BUCKET_LIMIT = 48u << 10;
 // on C3 and 85 % on C4; or any thin, low-opacity scene) long items only cost balance (C2: 6670 -> 2780 frames/s).
 // k_bin_finalize decides per frame, from a figure the projection already has: the frame's optical depth
 //     tau = sum over visible splats of opacity x (16x16 tiles its box overlaps) x 256 / pixels
-// (C1 14, C2 74, C3 362, C4 1090): items are at least SEG_LEN_LONG entries (in practice whole bins) from LONG_TAU on.
+// (C1 14, C2 74, C3 362, C4 1090): items are at least SEG_LEN_LONG entries (in practice whole bins) from LONG_TAU_* on.
 // A function of the frame alone: no feedback from earlier frames, the same frame always takes the same path.
+// Where long items start to pay (scripts/tau_crossover.py: the C3 and C2 generators at 0.25 .. 1.6 M splats): with other
+// frames' kernels filling the gaps, from tau ~ 145 (1080p: 7170 -> 7480 frames/s at tau 145, 4730 -> 6060 at 250); one
+// frame at a time the few long items are the frame's tail and the gain starts near tau 340 (C3: +7 %; at tau 250
+// long items lose 10 %).
 constexpr uint32_t SEG_LEN_LONG = 16384;
-constexpr uint32_t LONG_TAU = 180;
+constexpr uint32_t LONG_TAU_EXACT = 340, LONG_TAU_THROUGHPUT = 150;
 
 inline bool use_bucket_order(const gsr_ctx* c)
 {
@@ -334,7 +338,8 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
         BinBuffers bb{c->depth_index, &c->fstate->sorted_count, c->bin_table, c->slots, c->rect_idx, c->bin_rects, c->bin_total, c->bin_start, c->seg_start,
                       c->items, c->bin_list, &c->fstate->overflow, &c->fstate->visible, &c->fstate->tile_entries,
                       c->accum, c->mailbox_dev, c->fstate->report, c->bin_capacity, c->max_items, c->seg_len, &c->fstate->seg_len, (c->opt.flags & GSR_FLAG_THROUGHPUT) ? 0 : 1, &c->fstate->queue, std::min<uint32_t>(c->max_items, c->blend_grid), c->seg_target_items, c->bin_blocks, c->bin_done,
-                      c->seg_len == SEG_LEN_WHOLE_BIN ? 0 : c->long_items >= 0 ? c->long_items : c->saturate ? -1 : 0, SEG_LEN_LONG, LONG_TAU,
+                      c->seg_len == SEG_LEN_WHOLE_BIN ? 0 : c->long_items >= 0 ? c->long_items : c->saturate ? -1 : 0, SEG_LEN_LONG,
+                      (c->opt.flags & GSR_FLAG_THROUGHPUT) ? LONG_TAU_THROUGHPUT : LONG_TAU_EXACT,
                       (uint32_t)((g.bx_hi - g.bx_lo) * BIN_PX) * (uint32_t)c->H};
         launch_bin(bb, g, c->n, s);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BIN], s));

@@ -194,15 +194,15 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa)
     __shared__ uint32_t s_w[5][FIN_WAVES];
     const int per = (nbins + FIN_THREADS - 1) / FIN_THREADS;
     const int b0 = threadIdx.x * per, b1 = min(b0 + per, nbins);
-    UN<1> ent = {{0}}, ent_tot;
+    // two sums in one pass: the frame's list entries, and the projection's optical-depth figure (slots [4]: opacity byte x
+    // tiles / 16), which decides below whether this frame's work items are long
+    UN<2> ent = {{0, 0}}, ent_tot;
     for (int b = b0; b < b1; b++) ent.v[0] += bin_total[b];
-    block_exclusive_scan<1>(ent, s_w, &ent_tot);
+    if (have_counts && threadIdx.x < FRAME_SLOTS) ent.v[1] = (uint32_t)slots[(size_t)threadIdx.x * FRAME_SLOT_WORDS + 4];
+    block_exclusive_scan<2>(ent, s_w, &ent_tot);
     // Long work items where the frame saturates (gsr_api.cpp, "Work-item length"): the frame's optical depth
     // tau = sum(opacity x tiles) x 256 / pixels from the projection's slots ([4] holds opacity byte x tiles / 16)
-    UN<1> ot = {{0}}, ot_tot;
-    if (have_counts && threadIdx.x < FRAME_SLOTS) ot.v[0] = (uint32_t)slots[(size_t)threadIdx.x * FRAME_SLOT_WORDS + 4];
-    block_exclusive_scan<1>(ot, s_w, &ot_tot);
-    const bool dense = (uint64_t)ot_tot.v[0] * (16u * 256u) >= (uint64_t)fa.long_tau * 255u * (uint64_t)fa.npix;
+    const bool dense = (uint64_t)ent_tot.v[1] * (16u * 256u) >= (uint64_t)fa.long_tau * 255u * (uint64_t)fa.npix;
     uint32_t seg_min = seg_len_min;
     if (seg_len_min < 0x40000000u && (fa.long_policy > 0 || (fa.long_policy < 0 && dense))) seg_min = max(seg_len_min, fa.seg_len_long);
     // segment length of this frame (a multiple of 256; the whole-bin sentinel of early termination passes through)

@@ -37,6 +37,7 @@ constexpr int BLEND_THREADS = 256;
 constexpr int CHUNK = BLEND_THREADS;
 constexpr int BIN_PIXELS = BIN_PX * BIN_PX;
 constexpr float LOG2E = 1.4426950408889634f;
+constexpr uint32_t SAT_FROM = CHUNK;   // entries of a work item in front of the chunk after which it is first tested for saturation
 
 #ifdef GSR_BLEND_STAMPS
 // Diagnostic build only (scripts/build_exp.sh stamps "-DGSR_BLEND_STAMPS", read by scripts/blend_stamps.py): where a
@@ -268,18 +269,24 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
                 // (test_saturated_quadrants_are_skipped_without_changing_a_bit).  A quadrant whose 64 pixels are all
                 // finished drops out of `alive`; a tile with no live quadrant is done, a bin with no live tile ends its
                 // work item (s_done).  Pixels with a zero channel finish only at T == 0.
-                if (!done) {
-                    constexpr float K = 0x1p-27f;
-                    const bool f00 = T00 < K * fminf(r00, fminf(g00, b00)) || T00 == 0.0f;
-                    const bool f10 = T10 < K * fminf(r10, fminf(g10, b10)) || T10 == 0.0f;
-                    const bool f01 = T01 < K * fminf(r01, fminf(g01, b01)) || T01 == 0.0f;
-                    const bool f11 = T11 < K * fminf(r11, fminf(g11, b11)) || T11 == 0.0f;
-                    alive = (__ballot(!f00) ? 1u : 0u) | (__ballot(!f10) ? 2u : 0u) | (__ballot(!f01) ? 4u : 0u) | (__ballot(!f11) ? 8u : 0u);
-                    if (saturate && alive == 0u) {
+                // (not after an item's first chunk, where nothing has saturated yet, and not after its last, where nothing
+                //  is left to skip: 512-entry segments -- all a frame that does not saturate has -- never pay for the test,
+                //  which cost 3 % on C2; at 4K a bin saturates within ~500 entries, so no later than that)
+                if (!done && saturate && base - begin >= SAT_FROM && base + CHUNK < end) {
+                    constexpr float K = 0x1p-27f, NEAR = 1e-6f;   // nothing above NEAR can pass the test: a cheap filter first
+#define GSR_FINISHED(BIT, T, R, G, B_)                                                                          \
+    if ((alive & (BIT)) && __ballot((T) >= NEAR) == 0ull &&                                                      \
+        __ballot(!((T) < K * fminf((R), fminf((G), (B_))) || (T) == 0.0f)) == 0ull)                              \
+        alive &= ~(BIT);
+                    GSR_FINISHED(1u, T00, r00, g00, b00)
+                    GSR_FINISHED(2u, T10, r10, g10, b10)
+                    GSR_FINISHED(4u, T01, r01, g01, b01)
+                    GSR_FINISHED(8u, T11, r11, g11, b11)
+#undef GSR_FINISHED
+                    if (alive == 0u) {
                         done = true;
                         if (lane == 0) atomicAdd(&s_done, 1u);
                     }
-                    if (!saturate) alive = 15u;
                 }
             }
 #ifdef GSR_BLEND_STAMPS
