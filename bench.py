@@ -127,7 +127,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="C3")
     ap.add_argument("--early-out-eps", type=float, default=0.0,
-                    help="0 = composite every splat like the reference (default)")
+                    help="0 = no approximate termination (default): every fragment that can change a bit of the image is composited")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timed-only", action="store_true",
                     help="skip the untimed secondary legs (one frame in flight, latency, readback, sort alone) and the CPU baseline: "
@@ -363,6 +363,33 @@ def main():
             sr.render_async()
             sr.readPixels()
         solo["frames_per_sec_with_rgba8_readback"] = 30 / (time.perf_counter() - t3)
+        # For the record, the same frames with the compositor's saturation skip switched off (GSR_SATURATE=0: every list
+        # entry is visited; the image is the same bit for bit, tests/test_gpu_parity.py): F contexts in flight and one.
+        if args.early_out_eps == 0.0:
+            os.environ["GSR_SATURATE"] = "0"
+            try:
+                noskip = {}
+                for nctx, key in ((F, "frames_per_sec"), (1, "frames_per_sec_one_frame_in_flight")):
+                    xs = [gh.HIPRenderer(W, H, device=local_rank, throughput=nctx > 1) for _ in range(nctx)]
+                    for x in xs:
+                        for j in range(3):
+                            x.render(scene, gh.orbit_camera(j, ORBIT_FRAMES, W, H, cfg["fx"]))
+                    t4 = time.perf_counter()
+                    nfr = 90
+                    for k in range(nfr):
+                        v, p, vp = poses[k % ORBIT_FRAMES]
+                        x = xs[k % nctx]
+                        x.set_camera_arrays(v, p, vp, cfg["fx"], cfg["fx"])
+                        x.render_async()
+                    for x in xs:
+                        x.sync()
+                    noskip[key] = nfr / (time.perf_counter() - t4)
+                    for x in xs:
+                        x.dispose()
+                noskip["note"] = "GSR_SATURATE=0: quadrants whose pixels can no longer change are still visited; identical image"
+                solo["without_saturation_skip"] = noskip
+            finally:
+                del os.environ["GSR_SATURATE"]
         # the sort path alone, as the reference's worker runs it (wasm.cpp sort(): key + min/max + quantise + order):
         # gsr_sort = key kernel without projection + the two radix passes
         sr.reset_stats()
@@ -425,7 +452,9 @@ def main():
                                    "= depth key + 17-bit sort + projection + binning + composite"
                                    % (args.config, N, cfg["seed"], W, H),
                        "early_out_eps": args.early_out_eps, "frames_in_flight": F, "stage_events_every": max(1, args.timing_interval), "emulated_rank": args.emulate_rank, "backend": (args.backend if world > 1 else None), "world_size": world, "parallelism": "tile-column bands x%d%s" % (world, "" if world == 1 else (", %s all-gather %s, %s edges" % (args.exchange, "inside the library (RCCL)" if in_library else "in the harness (gloo rehearsal, host staged)", "equal" if args.equal_bands else "cost-balanced"))),
-                       "output": "RGBA f32 premultiplied, left in HBM"},
+                       "output": "RGBA f32 premultiplied, left in HBM",
+                       "saturation_skip": "on (default): a quadrant is no longer visited once no later splat can change a bit of its "
+                                          "pixels; image bit-identical to GSR_SATURATE=0, whose rate is in one_frame_in_flight.without_saturation_skip"},
             "sorted_splats_per_sec": N / ((sm["project_key"] + sm["sort"]) * 1e-3) if (sm["project_key"] + sm["sort"]) > 0 else None,
             "stage_ms": ms,
             "counts": {"N": N, "V": V, "D_tiles16": D, "bin_entries32": E, "P": band_px},
