@@ -151,13 +151,17 @@ __device__ __forceinline__ UN<N> block_exclusive_scan(UN<N> x, uint32_t (*s_w)[F
 // per 512 entries; every extra segment costs a 16 KiB partial written by k_blend and read by k_combine.
 constexpr uint32_t SEG_LEN_MAX = 8192;
 
-// size class of a bin's last (partial) segment of r entries: 1: >= 1/2 segment, 2: >= 1/4, 3: the rest (and empty bins)
-// (with several frames in flight the tail of one frame's compositor is filled by the other frames' kernels, and
-// a tail made only of the lightest items was measured 2.5 % slower: then `by_size` is off and the bins' last
-// segments stay in raster order)
-__device__ __forceinline__ int partial_class(uint32_t r, uint32_t seg_len, bool by_size)
+// Size class of a bin's last (partial) segment of r entries -- with long work items: of the whole bin -- for the order of
+// the work items: 4 classes per power of two (r < 65536 -> 0 .. 63), larger = heavier.  The compositor draws the items of
+// the heaviest class first.  (With several frames in flight the tail of one frame's compositor is filled by the other
+// frames' kernels, and a tail made only of the lightest items was measured 2.5 % slower: then `by_size` is off and the
+// bins' last segments stay in raster order.)
+constexpr int FIN_CLASSES = 64;
+__device__ __forceinline__ int partial_class(uint32_t r)
 {
-    return !by_size ? 3 : r >= seg_len / 2 ? 1 : r >= seg_len / 4 ? 2 : 3;
+    if (r < 4u) return (int)r;
+    const int e = 31 - __clz((int)r);                       // 2 .. 31
+    return min(FIN_CLASSES - 1, (e - 1) * 4 + (int)((r >> (e - 2)) & 3u));
 }
 
 // Arguments of the finalize step (by value in the kernel arguments of whichever kernel runs it).
@@ -209,28 +213,39 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa)
     uint32_t seg_len = seg_min;
     if (seg_min < 0x40000000u)
         seg_len = min(max(ent_tot.v[0] / seg_target_items / 256u * 256u, seg_min), max(SEG_LEN_MAX, seg_min));
-    // Items are emitted heaviest first -- every full segment, then the bins' last segments by size class --
-    // so the compositor's queue hands out the long items while the chip is still full and only short
-    // ones are left for the tail.  Streams: entries, segments, full segments, class-1 and class-2 partials.
-    UN<5> mine = {{0, 0, 0, 0, 0}};
+    // Items are emitted heaviest first -- every full segment, then the bins' last segments (with long work items: the
+    // whole bins) by size class, a counting sort over FIN_CLASSES classes in LDS -- so the compositor's queue hands out
+    // the long items while the chip is still full and only short ones are left for the tail.  The order inside a class
+    // is whatever the atomics give: the item list is a work list, its order changes no pixel.
+    // Streams of the scan: entries, segments, full segments.
+    __shared__ uint32_t s_cls[FIN_CLASSES];
+    if (threadIdx.x < FIN_CLASSES) s_cls[threadIdx.x] = 0;
+    __syncthreads();
+    UN<3> mine = {{0, 0, 0}};
     for (int b = b0; b < b1; b++) {
         const uint32_t c = bin_total[b];
         const uint32_t nf = c / seg_len, r = c - nf * seg_len;
         mine.v[0] += c;
         mine.v[1] += nf + ((r || !nf) ? 1u : 0u);
         mine.v[2] += nf;
-        if (r || !nf) {
-            const int cl = partial_class(r, seg_len, by_size != 0);
-            mine.v[3] += cl == 1;
-            mine.v[4] += cl == 2;
-        }
+        if (by_size && (r || !nf)) atomicAdd(&s_cls[partial_class(r)], 1u);
     }
-    UN<5> tot;
-    const UN<5> ex5 = block_exclusive_scan<5>(mine, s_w, &tot);
-    uint32_t ex = ex5.v[0], sx = ex5.v[1], fx = ex5.v[2];
-    uint32_t p1 = tot.v[2] + ex5.v[3];                                        // class 1 follows all full items
-    uint32_t p2 = tot.v[2] + tot.v[3] + ex5.v[4];                             // then class 2
-    uint32_t p3 = tot.v[2] + tot.v[3] + tot.v[4] + (sx - fx - ex5.v[3] - ex5.v[4]);  // then the rest
+    UN<3> tot;
+    const UN<3> ex3 = block_exclusive_scan<3>(mine, s_w, &tot);   // (its barriers also order the class counts)
+    uint32_t ex = ex3.v[0], sx = ex3.v[1], fx = ex3.v[2];
+    if (by_size && threadIdx.x < WAVE) {   // class counts -> first item index of each class, heaviest class first
+        static_assert(FIN_CLASSES == WAVE, "one class per lane");
+        const uint32_t cnt = s_cls[FIN_CLASSES - 1 - threadIdx.x];
+        uint32_t inc = cnt;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const uint32_t u = __shfl_up(inc, off);
+            if ((int)threadIdx.x >= off) inc += u;
+        }
+        s_cls[FIN_CLASSES - 1 - threadIdx.x] = tot.v[2] + inc - cnt;
+    }
+    __syncthreads();
+    uint32_t p3 = tot.v[2] + (sx - fx);   // raster order of the last segments (by_size off)
     // A frame whose lists do not fit (entries > capacity or items > max_items) must not be composited:
     // it publishes no work items at all (every index the compositor derives stays in range), raises the
     // overflow word, and the host regrows the buffers and renders the frame again (gsr_sync).
@@ -245,9 +260,8 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa)
         if (fits) {
             for (uint32_t k = 0; k < nf; k++) items[fx + k] = (uint32_t)b | (k << 16);
             if (part) {
-                const int cl = partial_class(r, seg_len, by_size != 0);
-                uint32_t& pos = cl == 1 ? p1 : cl == 2 ? p2 : p3;
-                items[pos++] = (uint32_t)b | (nf << 16);
+                const uint32_t pos = by_size ? atomicAdd(&s_cls[partial_class(r)], 1u) : p3++;
+                items[pos] = (uint32_t)b | (nf << 16);
             }
         }
         ex += c;
