@@ -74,6 +74,7 @@ struct gsr_ctx {
     uint32_t *bin_table = nullptr, *bin_total = nullptr, *bin_start = nullptr, *bin_list = nullptr;
     uint32_t *seg_start = nullptr, *items = nullptr;
     uint32_t* bin_done = nullptr;     // per-bin arrival counters of the compositor (null: separate k_combine launch)
+    int items_by_size = 1;            // work items heaviest first (k_bin_finalize); GSR_ITEMS_BY_SIZE
     bool fuse_combine = true;
     bool saturate = true;             // skip quadrants that can no longer change (GSR_SATURATE=0: composite every entry)
     int long_items = -1;              // -1: long work items where the frame's optical depth says so (LONG_TAU), 0 / 1: pinned (GSR_LONG_ITEMS)
@@ -337,7 +338,7 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
         if (!c->n) HIP_TRY(c, hipMemsetAsync(c->bin_total, 0, sizeof(uint32_t) * nbins, s));
         BinBuffers bb{c->depth_index, &c->fstate->sorted_count, c->bin_table, c->slots, c->rect_idx, c->bin_rects, c->bin_total, c->bin_start, c->seg_start,
                       c->items, c->bin_list, &c->fstate->overflow, &c->fstate->visible, &c->fstate->tile_entries,
-                      c->accum, c->mailbox_dev, c->fstate->report, c->bin_capacity, c->max_items, c->seg_len, &c->fstate->seg_len, (c->opt.flags & GSR_FLAG_THROUGHPUT) ? 0 : 1, &c->fstate->queue, std::min<uint32_t>(c->max_items, c->blend_grid), c->seg_target_items, c->bin_blocks, c->bin_done,
+                      c->accum, c->mailbox_dev, c->fstate->report, c->bin_capacity, c->max_items, c->seg_len, &c->fstate->seg_len, c->items_by_size, &c->fstate->queue, std::min<uint32_t>(c->max_items, c->blend_grid), c->seg_target_items, c->bin_blocks, c->bin_done,
                       c->seg_len == SEG_LEN_WHOLE_BIN ? 0 : c->long_items >= 0 ? c->long_items : c->saturate ? -1 : 0, SEG_LEN_LONG,
                       (c->opt.flags & GSR_FLAG_THROUGHPUT) ? LONG_TAU_THROUGHPUT : LONG_TAU_EXACT,
                       (uint32_t)((g.bx_hi - g.bx_lo) * BIN_PX) * (uint32_t)c->H};
@@ -375,7 +376,7 @@ static std::vector<uint64_t> chain_signature(const gsr_ctx* c)
     P(c->items); P(c->bin_list); P(c->partial); P(c->fb); P(c->accum); P(c->cam_dev);
     U(c->n); U((uint64_t)c->W); U((uint64_t)c->H); U((uint64_t)g.bx_lo); U((uint64_t)g.bx_hi); U(c->sort_kpb); U(c->sort_blocks);
     U(c->bin_capacity); U(c->max_items); U(c->seg_len); U(c->seg_target_items); U(c->blend_grid); U(c->bin_blocks);
-    U((uint64_t)c->opt.flags); U((uint64_t)(c->opt.early_out_eps * 1e9f)); U(c->bucket_order_now ? 1u : 0u); U(c->saturate ? 1u : 0u); U((uint64_t)(int64_t)c->long_items);
+    U((uint64_t)c->opt.flags); U((uint64_t)(c->opt.early_out_eps * 1e9f)); U(c->bucket_order_now ? 1u : 0u); U(c->saturate ? 1u : 0u); U((uint64_t)c->items_by_size); U((uint64_t)(int64_t)c->long_items);
     return v;
 }
 
@@ -575,6 +576,8 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
     if (const char* e = getenv("GSR_NO_GRAPH")) c->graphs_enabled = atoi(e) == 0;
     if (const char* e = getenv("GSR_FUSE_COMBINE")) c->fuse_combine = atoi(e) != 0;   // A/B knob: 0 = separate k_combine launch
     if (const char* e = getenv("GSR_SATURATE")) c->saturate = atoi(e) != 0;           // A/B knob: 0 = no saturation skip
+    c->items_by_size = (o.flags & GSR_FLAG_THROUGHPUT) ? 0 : 1;
+    if (const char* e = getenv("GSR_ITEMS_BY_SIZE")) c->items_by_size = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("GSR_LONG_ITEMS")) c->long_items = atoi(e) != 0 ? 1 : 0; // pins the work-item length policy
     CREATE_TRY(hipMalloc((void**)&c->accum, 8 * sizeof(uint64_t)));
     CREATE_TRY(hipMemset(c->accum, 0, 8 * sizeof(uint64_t)));

@@ -186,7 +186,6 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa)
     const uint32_t* __restrict__ bin_total = fa.bin_total;
     const int nbins = fa.nbins;
     const uint32_t seg_len_min = fa.seg_len_min, seg_target_items = fa.seg_target_items, max_items = fa.max_items, capacity = fa.capacity;
-    const int by_size = fa.by_size;
     uint32_t* __restrict__ bin_start = fa.bin_start;
     uint32_t* __restrict__ seg_start = fa.seg_start;
     uint32_t* __restrict__ items = fa.items;
@@ -210,6 +209,9 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa)
     uint32_t seg_min = seg_len_min;
     if (seg_len_min < 0x40000000u && (fa.long_policy > 0 || (fa.long_policy < 0 && dense))) seg_min = max(seg_len_min, fa.seg_len_long);
     // segment length of this frame (a multiple of 256; the whole-bin sentinel of early termination passes through)
+    // long items are ordered heaviest first in every mode: the few that run long must not start late (three frames in
+    // flight, C3: 4970 -> 5310 frames/s); short segments in throughput contexts stay in raster order (C2: 11 550 vs 11 250)
+    const bool by_size = fa.by_size != 0 || seg_min > seg_len_min;
     uint32_t seg_len = seg_min;
     if (seg_min < 0x40000000u)
         seg_len = min(max(ent_tot.v[0] / seg_target_items / 256u * 256u, seg_min), max(SEG_LEN_MAX, seg_min));
