@@ -37,7 +37,7 @@ constexpr int BLEND_THREADS = 256;
 constexpr int CHUNK = BLEND_THREADS;
 constexpr int BIN_PIXELS = BIN_PX * BIN_PX;
 constexpr float LOG2E = 1.4426950408889634f;
-constexpr uint32_t SAT_FROM = CHUNK;   // entries of a work item in front of the chunk after which it is first tested for saturation
+constexpr uint32_t SAT_FROM = CHUNK;   // entries of a long work item before its first saturation test
 
 #ifdef GSR_BLEND_STAMPS
 // Diagnostic build only (scripts/build_exp.sh stamps "-DGSR_BLEND_STAMPS", read by scripts/blend_stamps.py): where a
@@ -132,6 +132,7 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
         const uint32_t bin_end = min(bin_start[bin + 1], capacity);
         const uint32_t begin = min(bin_start[bin] + seg * seg_len, bin_end);
         const uint32_t end = min(begin + seg_len, bin_end);
+        const bool sat_item = saturate != 0u && end - begin > 2u * CHUNK;   // only long items test for saturation
         bool done = false;
         uint32_t alive = 15u;   // quadrants of my tile that can still change (wave-uniform); see the saturation test below
 #ifdef GSR_BLEND_STAMPS
@@ -259,33 +260,33 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
                             break;
                         }
                     }
-                }
-                // ---- saturation that changes no bit (once per chunk) ----
-                // A pixel whose transmittance is below 2^-27 of its smallest colour channel is finished: every later
-                // weight is w <= T (opacity <= 1, exp <= 1), colours are <= 1, so w*c is under half an ulp of each channel
-                // and fma(w, c, C) returns C; its alpha is 1 - T = 1.0f for any T that small.  The segment's own T
-                // would still shrink, but only ever multiplies later segments' colours (the fold), whose terms are then
-                // under half an ulp of the folded colour as well: the image is bit-identical to compositing every entry
-                // (test_saturated_quadrants_are_skipped_without_changing_a_bit).  A quadrant whose 64 pixels are all
-                // finished drops out of `alive`; a tile with no live quadrant is done, a bin with no live tile ends its
-                // work item (s_done).  Pixels with a zero channel finish only at T == 0.
-                // (not after an item's first chunk, where nothing has saturated yet, and not after its last, where nothing
-                //  is left to skip: 512-entry segments -- all a frame that does not saturate has -- never pay for the test,
-                //  which cost 3 % on C2; at 4K a bin saturates within ~500 entries, so no later than that)
-                if (!done && saturate && base - begin >= SAT_FROM && base + CHUNK < end) {
-                    constexpr float K = 0x1p-27f, NEAR = 1e-6f;   // nothing above NEAR can pass the test: a cheap filter first
+                    // ---- saturation that changes no bit (after every 64 entries of a long item) ----
+                    // A pixel whose transmittance is below 2^-27 of its smallest colour channel is finished: every later
+                    // weight is w <= T (opacity <= 1, exp <= 1), colours are <= 1, so w*c is under half an ulp of each channel
+                    // and fma(w, c, C) returns C; its alpha is 1 - T = 1.0f for any T that small.  The segment's own T
+                    // would still shrink, but only ever multiplies later segments' colours (the fold), whose terms are then
+                    // under half an ulp of the folded colour as well: the image is bit-identical to compositing every entry
+                    // (test_saturated_quadrants_are_skipped_without_changing_a_bit).  A quadrant whose 64 pixels are all
+                    // finished drops out of `alive`; a tile with no live quadrant is done, a bin with no live tile ends its
+                    // work item (s_done).  Pixels with a zero channel finish only at T == 0.
+                    // (Items of up to two chunks -- all a frame that does not saturate has -- never run the test, which
+                    //  cost 3 % on C2, and nothing saturates within an item's first SAT_FROM entries.)
+                    if (sat_item && base - begin + c0 >= SAT_FROM) {
+                        constexpr float K = 0x1p-27f, NEAR = 1e-6f;   // nothing above NEAR can pass the test: a cheap filter first
 #define GSR_FINISHED(BIT, T, R, G, B_)                                                                          \
     if ((alive & (BIT)) && __ballot((T) >= NEAR) == 0ull &&                                                      \
         __ballot(!((T) < K * fminf((R), fminf((G), (B_))) || (T) == 0.0f)) == 0ull)                              \
         alive &= ~(BIT);
-                    GSR_FINISHED(1u, T00, r00, g00, b00)
-                    GSR_FINISHED(2u, T10, r10, g10, b10)
-                    GSR_FINISHED(4u, T01, r01, g01, b01)
-                    GSR_FINISHED(8u, T11, r11, g11, b11)
+                        GSR_FINISHED(1u, T00, r00, g00, b00)
+                        GSR_FINISHED(2u, T10, r10, g10, b10)
+                        GSR_FINISHED(4u, T01, r01, g01, b01)
+                        GSR_FINISHED(8u, T11, r11, g11, b11)
 #undef GSR_FINISHED
-                    if (alive == 0u) {
-                        done = true;
-                        if (lane == 0) atomicAdd(&s_done, 1u);
+                        if (alive == 0u) {
+                            done = true;
+                            if (lane == 0) atomicAdd(&s_done, 1u);
+                            break;
+                        }
                     }
                 }
             }
