@@ -36,6 +36,7 @@ struct FrameState {  // small per-frame device words, reset by k_begin_frame (mi
     uint32_t digit_total[RADIX_LO_BINS + RADIX_HI_BINS];
     uint32_t sorted_count;  // entries of depth_index: n, or the band's survivors (SortBuffers::count)
     uint32_t seg_len;       // the frame's compositor segment length (k_bin_finalize -> k_blend)
+    uint32_t n_items;       // and its number of work items (directly behind seg_len: k_blend reads both through one pointer)
 };
 
 }  // namespace
@@ -75,6 +76,8 @@ struct gsr_ctx {
     uint32_t *seg_start = nullptr, *items = nullptr;
     uint32_t* bin_done = nullptr;     // per-bin arrival counters of the compositor (null: separate k_combine launch)
     int items_by_size = 1;            // work items heaviest first (k_bin_finalize); GSR_ITEMS_BY_SIZE
+    uint32_t quad_from = 0;           // whole-bin items from this many entries go to four workgroups, one per tile (GSR_QUAD_FROM); 0 = off,
+                                      // the default: measured slower (C3 k_blend 184 -> 203 / 215 / 238 us from 4096 / 3072 / 2048 entries)
     bool fuse_combine = true;
     bool saturate = true;             // skip quadrants that can no longer change (GSR_SATURATE=0: composite every entry)
     int long_items = -1;              // -1: long work items where the frame's optical depth says so (LONG_TAU), 0 / 1: pinned (GSR_LONG_ITEMS)
@@ -283,12 +286,15 @@ int alloc_bins(gsr_ctx* c)
         const long v = atol(e);
         if (v >= 256 && c->seg_len != SEG_LEN_WHOLE_BIN) c->seg_len = (uint32_t)(v / 256 * 256);
     }
-    const uint32_t want_items = nbins + c->bin_capacity / c->seg_len + 16;
+    // segments (each may need a partial slot): one per bin plus one per seg_len entries; work items: a heavy single-segment
+    // bin is handed out as four (ITEM_TILE0), so up to three more per bin
+    const uint32_t want_segs = nbins + c->bin_capacity / c->seg_len + 16;
+    const uint32_t want_items = want_segs + 3u * nbins;
     if (items_dirty || want_items > c->max_items) {
         c->max_items = want_items;
         if (int r = dev_alloc(c, &c->items, c->max_items)) return r;
         if (c->seg_len != SEG_LEN_WHOLE_BIN) {
-            if (int r = dev_alloc(c, &c->partial, (size_t)c->max_items * BIN_PX * BIN_PX)) return r;
+            if (int r = dev_alloc(c, &c->partial, (size_t)want_segs * BIN_PX * BIN_PX)) return r;
         }
     }
     return GSR_OK;
@@ -341,7 +347,7 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
                       c->accum, c->mailbox_dev, c->fstate->report, c->bin_capacity, c->max_items, c->seg_len, &c->fstate->seg_len, c->items_by_size, &c->fstate->queue, std::min<uint32_t>(c->max_items, c->blend_grid), c->seg_target_items, c->bin_blocks, c->bin_done,
                       c->seg_len == SEG_LEN_WHOLE_BIN ? 0 : c->long_items >= 0 ? c->long_items : c->saturate ? -1 : 0, SEG_LEN_LONG,
                       (c->opt.flags & GSR_FLAG_THROUGHPUT) ? LONG_TAU_THROUGHPUT : LONG_TAU_EXACT,
-                      (uint32_t)((g.bx_hi - g.bx_lo) * BIN_PX) * (uint32_t)c->H};
+                      (uint32_t)((g.bx_hi - g.bx_lo) * BIN_PX) * (uint32_t)c->H, c->quad_from};
         launch_bin(bb, g, c->n, s);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BIN], s));
         BlendBuffers bl{c->items, c->seg_start, c->bin_start, c->bin_list, c->rec, c->bbox, c->shcol, c->fb, c->partial,
@@ -376,7 +382,7 @@ static std::vector<uint64_t> chain_signature(const gsr_ctx* c)
     P(c->items); P(c->bin_list); P(c->partial); P(c->fb); P(c->accum); P(c->cam_dev);
     U(c->n); U((uint64_t)c->W); U((uint64_t)c->H); U((uint64_t)g.bx_lo); U((uint64_t)g.bx_hi); U(c->sort_kpb); U(c->sort_blocks);
     U(c->bin_capacity); U(c->max_items); U(c->seg_len); U(c->seg_target_items); U(c->blend_grid); U(c->bin_blocks);
-    U((uint64_t)c->opt.flags); U((uint64_t)(c->opt.early_out_eps * 1e9f)); U(c->bucket_order_now ? 1u : 0u); U(c->saturate ? 1u : 0u); U((uint64_t)c->items_by_size); U((uint64_t)(int64_t)c->long_items);
+    U((uint64_t)c->opt.flags); U((uint64_t)(c->opt.early_out_eps * 1e9f)); U(c->bucket_order_now ? 1u : 0u); U(c->saturate ? 1u : 0u); U((uint64_t)c->items_by_size); U(c->quad_from); U((uint64_t)(int64_t)c->long_items);
     return v;
 }
 
@@ -578,6 +584,7 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
     if (const char* e = getenv("GSR_SATURATE")) c->saturate = atoi(e) != 0;           // A/B knob: 0 = no saturation skip
     c->items_by_size = (o.flags & GSR_FLAG_THROUGHPUT) ? 0 : 1;
     if (const char* e = getenv("GSR_ITEMS_BY_SIZE")) c->items_by_size = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("GSR_QUAD_FROM")) c->quad_from = (uint32_t)std::max(0L, atol(e));
     if (const char* e = getenv("GSR_LONG_ITEMS")) c->long_items = atoi(e) != 0 ? 1 : 0; // pins the work-item length policy
     CREATE_TRY(hipMalloc((void**)&c->accum, 8 * sizeof(uint64_t)));
     CREATE_TRY(hipMemset(c->accum, 0, 8 * sizeof(uint64_t)));

@@ -113,6 +113,9 @@ __device__ __forceinline__ uint32_t xcd_group_remap(uint32_t bid, uint32_t nwg)
     return (bid - in) + (in % 8u) * RUN + in / 8u;
 }
 #endif
+// Compositor work items: bin | segment << 16.  Segment codes from ITEM_TILE0 on mean "the whole (single-segment) bin, but
+// only its 16x16 tile code - ITEM_TILE0": a heavy bin handed to four workgroups, one 8x8 quadrant per wave (k_blend).
+constexpr uint32_t ITEM_TILE0 = 0xfff0u;
 constexpr uint32_t PROJ_THREADS = 256;
 constexpr int FRAME_SLOTS = 64;
 constexpr int FRAME_SLOT_WORDS = 32;   // words per slot (one 128-byte line): [0] min depth, [1] max depth, [2] visible, [3] tiles,
@@ -172,7 +175,7 @@ struct BinBuffers {
     uint32_t max_items;
     uint32_t seg_len;            // minimum list entries per compositor work item (multiple of 256); k_bin_finalize
                                  // raises it for long lists and publishes the frame's value in *seg_len_dev
-    uint32_t* seg_len_dev;
+    uint32_t* seg_len_dev;       // [0] the frame's segment length, [1] its number of work items
     int32_t items_by_size;       // order the bins' last segments by size class (one frame at a time) or leave them in raster order
     uint32_t* queue;             // the compositor's work-item counter, set to queue_start (= its grid size) by k_bin_finalize
     uint32_t queue_start;
@@ -182,6 +185,7 @@ struct BinBuffers {
     int32_t long_policy;         // work items of at least seg_len_long entries: 1 always, 0 never, -1 where the frame's optical depth >= long_tau
     uint32_t seg_len_long, long_tau;
     uint32_t npix;               // pixels of this context's band (the optical depth is per pixel)
+    uint32_t quad_from;          // single-item bins with at least this many entries become four work items, one per 16x16 tile (0: never)
 };
 void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s);
 
@@ -197,7 +201,7 @@ struct BlendBuffers {
     float4* partial;            // max_items * 1024 float4: per-segment (colour, transmittance), slot = seg_start[bin] + segment
     uint32_t* queue;            // device-wide work-item counter, zero at frame start
     uint32_t seg_len;           // host's minimum; >= 0x40000000: one item per bin (early termination mode)
-    const uint32_t* seg_len_dev; // the frame's segment length (k_bin_finalize)
+    const uint32_t* seg_len_dev; // [0] the frame's segment length, [1] its number of work items (k_bin_finalize)
     uint32_t grid;              // persistent workgroups launched
     uint32_t capacity;          // entries the list can hold
     uint32_t nsplats;

@@ -176,6 +176,7 @@ struct FinalizeArgs {
     uint64_t* mailbox;
     uint32_t* bin_done;
     int long_policy; uint32_t seg_len_long, long_tau, npix;   // see BinBuffers
+    uint32_t quad_from;
 };
 
 // One workgroup of FIN_THREADS threads.  It runs as an EXTRA workgroup of k_bin_scatter (the scatter workgroups
@@ -223,17 +224,27 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa)
     __shared__ uint32_t s_cls[FIN_CLASSES];
     if (threadIdx.x < FIN_CLASSES) s_cls[threadIdx.x] = 0;
     __syncthreads();
-    UN<3> mine = {{0, 0, 0}};
+    // Heavy single-item bins as FOUR work items, one per 16x16 tile, each wave of the workgroup that draws one taking one
+    // 8x8 quadrant (k_blend, ITEM_TILE0): meant to shorten the one-frame kernel's tail (its last workgroups hold the
+    // heaviest bins), bit-identical, but measured slower at every threshold -- the bin is staged four times and a wave
+    // that owns one quadrant pays the per-entry costs for a quarter of the pixels.  Off unless GSR_QUAD_FROM is set.
+    const uint32_t quad_from = (fa.by_size != 0 && fa.quad_from) ? fa.quad_from : 0xffffffffu;
+    UN<3> mine = {{0, 0, 0}};   // entries, segments, full segments
+    UN<1> extra = {{0}};        // extra work items (3 per heavy bin)
     for (int b = b0; b < b1; b++) {
         const uint32_t c = bin_total[b];
         const uint32_t nf = c / seg_len, r = c - nf * seg_len;
         mine.v[0] += c;
         mine.v[1] += nf + ((r || !nf) ? 1u : 0u);
         mine.v[2] += nf;
-        if (by_size && (r || !nf)) atomicAdd(&s_cls[partial_class(r)], 1u);
+        const bool quad = !nf && c >= quad_from;
+        extra.v[0] += quad ? 3u : 0u;
+        if (by_size && (r || !nf)) atomicAdd(&s_cls[partial_class(r)], quad ? 4u : 1u);
     }
     UN<3> tot;
     const UN<3> ex3 = block_exclusive_scan<3>(mine, s_w, &tot);   // (its barriers also order the class counts)
+    UN<1> extra_tot = {{0}};
+    if (quad_from != 0xffffffffu) block_exclusive_scan<1>(extra, s_w, &extra_tot);   // (uniform)
     uint32_t ex = ex3.v[0], sx = ex3.v[1], fx = ex3.v[2];
     if (by_size && threadIdx.x < WAVE) {   // class counts -> first item index of each class, heaviest class first
         static_assert(FIN_CLASSES == WAVE, "one class per lane");
@@ -251,7 +262,8 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa)
     // A frame whose lists do not fit (entries > capacity or items > max_items) must not be composited:
     // it publishes no work items at all (every index the compositor derives stays in range), raises the
     // overflow word, and the host regrows the buffers and renders the frame again (gsr_sync).
-    const bool fits = tot.v[0] <= capacity && tot.v[1] <= max_items;
+    const uint32_t n_items = tot.v[1] + extra_tot.v[0];
+    const bool fits = tot.v[0] <= capacity && n_items <= max_items;
     for (int b = b0; b < b1; b++) {
         const uint32_t c = bin_total[b];
         const uint32_t nf = c / seg_len, r = c - nf * seg_len;
@@ -262,15 +274,22 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa)
         if (fits) {
             for (uint32_t k = 0; k < nf; k++) items[fx + k] = (uint32_t)b | (k << 16);
             if (part) {
-                const uint32_t pos = by_size ? atomicAdd(&s_cls[partial_class(r)], 1u) : p3++;
-                items[pos] = (uint32_t)b | (nf << 16);
+                if (!nf && c >= quad_from) {   // (by_size holds)
+                    const uint32_t pos = atomicAdd(&s_cls[partial_class(r)], 4u);
+#pragma unroll
+                    for (uint32_t t = 0; t < 4; t++) items[pos + t] = (uint32_t)b | ((ITEM_TILE0 + t) << 16);
+                } else {
+                    const uint32_t pos = by_size ? atomicAdd(&s_cls[partial_class(r)], 1u) : p3++;
+                    items[pos] = (uint32_t)b | (nf << 16);
+                }
             }
         }
         ex += c;
         sx += nf + (part ? 1u : 0u);
         fx += nf;
     }
-    // frame counters
+    // frame counters (scans of two or three streams keep this workgroup inside the 64 registers of k_bin_scatter, which it
+    // is an extra workgroup of; four-stream scans made it spill 60 registers and the bin stage 5 us longer on C2)
     UN<2> cnt = {{0, 0}};
     if (have_counts && threadIdx.x < FRAME_SLOTS) {   // the projection's visible-splat and tile-overlap sums
         cnt.v[0] = (uint32_t)slots[(size_t)threadIdx.x * FRAME_SLOT_WORDS + 2];
@@ -280,7 +299,8 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa)
     block_exclusive_scan<2>(cnt, s_w, &ctot);
     if (threadIdx.x == 0) {
         *queue = queue_start;  // the compositor's workgroups take items 0..grid-1 by index, later ones from here
-        *seg_len_out = seg_len;
+        seg_len_out[0] = seg_len;
+        seg_len_out[1] = fits ? n_items : 0u;   // the compositor's queue length
         bin_start[nbins] = fits ? tot.v[0] : 0u;
         seg_start[nbins] = fits ? tot.v[1] : 0u;
         accum[4] = tot.v[0];  // entries this frame needs (the host sizes the regrowth from it)
@@ -291,7 +311,7 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa)
             // the middle of an asynchronous run without a copy or a sync (gsr_render_async polls it)
             accum[5] += 1;
             accum[6] = max(accum[6], (uint64_t)tot.v[0]);
-            accum[7] = max(accum[7], (uint64_t)tot.v[1]);
+            accum[7] = max(accum[7], (uint64_t)n_items);
             __hip_atomic_store(mailbox, accum[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         *visible = ctot.v[0];
@@ -547,7 +567,7 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
     }
     const FinalizeArgs fa{b.bin_total, nbins, b.seg_len, b.seg_target_items, b.items_by_size, b.seg_len_dev, b.max_items, b.capacity,
                           b.slots, n ? 1u : 0u, b.bin_start, b.seg_start, b.items, b.overflow, b.visible, b.tile_entries, b.accum,
-                          b.report, b.queue, b.queue_start, b.mailbox, b.bin_done, b.long_policy, b.seg_len_long, b.long_tau, b.npix};
+                          b.report, b.queue, b.queue_start, b.mailbox, b.bin_done, b.long_policy, b.seg_len_long, b.long_tau, b.npix, b.quad_from};
     const bool fused = n && nbins <= 4096;   // see k_bin_scatter
     if (!fused) hipLaunchKernelGGL(k_bin_finalize, dim3(1), dim3(FIN_THREADS), 0, s, fa);
     if (n) {

@@ -82,10 +82,10 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
     __shared__ uint32_t s_item;
     __shared__ uint32_t s_last;
 
-    const int nbxb = g.bx_hi - g.bx_lo, nbins = nbxb * g.nby;
+    const int nbxb = g.bx_hi - g.bx_lo;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lx = lane & 7, ly = lane >> 3;
-    const uint32_t total_items = seg_start[nbins];
+    const uint32_t total_items = seg_len_dev[1];   // the frame's work items (k_bin_finalize; heavy bins count four)
 
     // Work items come from one device-wide queue (items are ordered heaviest first), so a workgroup
     // that drew light items simply draws more: no static assignment, no long pole.
@@ -114,14 +114,23 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
 #ifdef GSR_BLEND_STAMPS
         a_items++; a_item_t0 = (unsigned int)__builtin_amdgcn_s_memrealtime(); a_last_start = a_item_t0; a_item_vis0 = a_entries; a_item_bin = (unsigned int)bin;
 #endif
-        const uint32_t seg = it >> 16;
+        // A tile item (ITEM_TILE0 + t: a heavy single-segment bin, handed out as four items): this workgroup composites
+        // tile t alone and every wave takes ONE of its 8x8 quadrants -- one pixel per lane, the (.)00 accumulators --
+        // instead of a whole tile: the same arithmetic per pixel, a third of the entries and quadrants per wave.
+        const bool tile_item = (it >> 16) >= ITEM_TILE0;
+        const uint32_t seg = tile_item ? 0u : it >> 16;
+        const int tile = tile_item ? (int)((it >> 16) - ITEM_TILE0) : wave;
         const uint32_t nseg = seg_start[bin + 1] - seg_start[bin];
         const int by = bin / nbxb, bxl = bin - by * nbxb;
         const int binX0 = (g.bx_lo + bxl) * BIN_PX, binY0 = by * BIN_PX;
-        const int X0 = binX0 + (wave & 1) * TILE, Y0 = binY0 + (wave >> 1) * TILE;
+        const int ox = (tile & 1) * TILE + (tile_item ? (wave & 1) * 8 : 0), oy = (tile >> 1) * TILE + (tile_item ? (wave >> 1) * 8 : 0);
+        const int X0 = binX0 + ox, Y0 = binY0 + oy;
+        // which bits of an entry's 16-bit quadrant mask are mine: my tile's nibble, or my one quadrant of it
+        const int mask_shift = tile_item ? tile * 4 + wave : wave * 4;
+        const uint32_t mask_sel = tile_item ? 1u : 15u;
         // pixel centres relative to the centre of the bin's first pixel: small exact integers
-        const float pxf0 = (float)((wave & 1) * TILE + lx), pxf1 = pxf0 + 8.0f;
-        const float pyf0 = (float)((wave >> 1) * TILE + ly), pyf1 = pyf0 + 8.0f;
+        const float pxf0 = (float)(ox + lx), pxf1 = pxf0 + 8.0f;
+        const float pyf0 = (float)(oy + ly), pyf1 = pyf0 + 8.0f;
         const float bx0c = (float)binX0 + 0.5f, by0c = (float)binY0 + 0.5f;
 
         float T00 = 1.f, T10 = 1.f, T01 = 1.f, T11 = 1.f;  // Tij: pixel (x+8i, y+8j); 1 - alpha
@@ -134,7 +143,7 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
         const uint32_t end = min(begin + seg_len, bin_end);
         const bool sat_item = saturate != 0u && end - begin > 2u * CHUNK;   // only long items test for saturation
         bool done = false;
-        uint32_t alive = 15u;   // quadrants of my tile that can still change (wave-uniform); see the saturation test below
+        uint32_t alive = mask_sel;   // quadrants of mine that can still change (wave-uniform); see the saturation test below
 #ifdef GSR_BLEND_STAMPS
         a_item_len = end - begin;
 #endif
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
             if (!done) {
                 const uint32_t cnt = min((uint32_t)CHUNK, end - base);
                 for (uint32_t c0 = 0; c0 < cnt; c0 += WAVE) {
-                    const uint32_t mine = (s_mask[c0 + lane] >> (wave * 4)) & alive;  // entry (c0+lane) vs the live quadrants of my tile
+                    const uint32_t mine = (s_mask[c0 + lane] >> mask_shift) & alive;  // entry (c0+lane) vs my live quadrants
                     uint64_t bal = __ballot(mine != 0u);
 #ifdef GSR_BLEND_STAMPS
                     a_entries += __popcll(bal);
@@ -309,9 +318,9 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
             const int x0 = X0 + lx, x1 = x0 + 8, y0 = Y0 + ly, y1 = y0 + 8;
             if (y0 < g.H) {
                 if (x0 < g.W) fb[(size_t)y0 * g.W + x0] = make_float4(r00, g00, b00, 1.0f - T00);
-                if (x1 < g.W) fb[(size_t)y0 * g.W + x1] = make_float4(r10, g10, b10, 1.0f - T10);
+                if (x1 < g.W && !tile_item) fb[(size_t)y0 * g.W + x1] = make_float4(r10, g10, b10, 1.0f - T10);
             }
-            if (y1 < g.H) {
+            if (y1 < g.H && !tile_item) {
                 if (x0 < g.W) fb[(size_t)y1 * g.W + x0] = make_float4(r01, g01, b01, 1.0f - T01);
                 if (x1 < g.W) fb[(size_t)y1 * g.W + x1] = make_float4(r11, g11, b11, 1.0f - T11);
             }

@@ -1025,3 +1025,36 @@ def test_long_and_short_work_items_agree(gh, monkeypatch):
         assert np.abs(imgs["0"][0] - imgs["1"][0]).max() <= 2e-6
         assert np.abs(imgs["0"][1].astype(np.int32) - imgs["1"][1].astype(np.int32)).max() <= 1
         assert np.array_equal(imgs["auto"][0], imgs[expect][0]), name
+
+
+@pytest.mark.gpu
+def test_heavy_bins_split_into_tile_items_change_no_bit(gh, monkeypatch):
+    """(An option, off by default: measured slower.)  A heavy whole-bin work item can be handed out as four items, one per
+    16x16 tile; the workgroup that draws one gives every wave a single 8x8 quadrant (k_blend, ITEM_TILE0, GSR_QUAD_FROM).  Per pixel the arithmetic and the order of
+    the splats are the same, so the image equals the unsplit one (GSR_QUAD_FROM=0) bit for bit -- also when nearly every
+    bin is split (GSR_QUAD_FROM=64).  With early termination (approximate by definition: a wave stops when ITS pixels are
+    below the threshold, and a wave's pixels are then a quadrant instead of a tile) the images agree to the threshold."""
+    cfg = gh.synth.CONFIGS["C3"]
+    W, H = cfg["width"], cfg["height"]
+    scene = gh.Scene()
+    scene.setData(gh.synth.config_rows("C3"))
+    for eps in (0.0, 1e-4):
+        monkeypatch.setenv("GSR_QUAD_FROM", "0")
+        whole = gh.HIPRenderer(W, H, early_out_eps=eps)
+        monkeypatch.setenv("GSR_QUAD_FROM", "3072")
+        split = gh.HIPRenderer(W, H, early_out_eps=eps)
+        monkeypatch.setenv("GSR_QUAD_FROM", "64")
+        split_all = gh.HIPRenderer(W, H, early_out_eps=eps)
+        monkeypatch.delenv("GSR_QUAD_FROM")
+        for k in (11, 58, 103):
+            cam = gh.orbit_camera(k, 120, W, H, cfg["fx"])
+            whole.render(scene, cam)
+            want = whole.readPixelsFloat()
+            for r in (split, split_all):
+                r.render(scene, cam)
+                if eps == 0.0:
+                    assert np.array_equal(r.readPixelsFloat(), want), k
+                else:
+                    assert np.abs(r.readPixelsFloat() - want).max() <= 2 * eps, k
+        for r in (whole, split, split_all):
+            r.dispose()
