@@ -230,12 +230,13 @@ constexpr uint32_t LOCAL_BUCKET_LIMIT = 48u << 10;
 //     tau = sum over visible splats of opacity x (16x16 tiles its box overlaps) x 256 / pixels
 // (C1 14, C2 74, C3 362, C4 1090): items are at least SEG_LEN_LONG entries (in practice whole bins) from LONG_TAU_* on.
 // A function of the frame alone: no feedback from earlier frames, the same frame always takes the same path.
-// Where long items start to pay (scripts/tau_crossover.py: the C3 and C2 generators at 0.25 .. 1.6 M splats): with other
-// frames' kernels filling the gaps, from tau ~ 145 (1080p: 7170 -> 7480 frames/s at tau 145, 4730 -> 6060 at 250); one
-// frame at a time the few long items are the frame's tail and the gain starts near tau 340 (C3: +7 %; at tau 250
-// long items lose 10 %).
+// Where long items start to pay (scripts/tau_crossover.py: the C3 and C2 generators at 0.25 .. 1.6 M splats, 1080p): with
+// other frames' kernels filling the gaps, between tau 90 and 145 for both generators (tau 90: 10 390 -> 10 080 frames/s,
+// tau 145: 7350 -> 8640, tau 250: 4730 -> 6800); one frame at a time the few long items are the frame's tail and the
+// crossover depends on the scene (C3 generator: tau ~ 255, C3 itself +23 %; the C2 generator's small splats still lose
+// 8 % at tau 390), so the threshold there stays high.
 constexpr uint32_t SEG_LEN_LONG = 16384;
-constexpr uint32_t LONG_TAU_EXACT = 340, LONG_TAU_THROUGHPUT = 150;
+constexpr uint32_t LONG_TAU_EXACT = 340, LONG_TAU_THROUGHPUT = 120;
 
 inline bool use_bucket_order(const gsr_ctx* c)
 {
