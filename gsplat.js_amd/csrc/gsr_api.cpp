@@ -237,6 +237,7 @@ constexpr uint32_t LOCAL_BUCKET_LIMIT = 48u << 10;
 // 8 % at tau 390), so the threshold there stays high.
 constexpr uint32_t SEG_LEN_LONG = 16384;
 constexpr uint32_t LONG_TAU_EXACT = 340, LONG_TAU_THROUGHPUT = 120;
+constexpr uint32_t LONG_TILES_X2_EXACT = 9;   // one frame at a time: and at least 4.5 tiles per visible splat (k_bin_finalize)
 
 inline bool use_bucket_order(const gsr_ctx* c)
 {
@@ -348,7 +349,8 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
                       c->accum, c->mailbox_dev, c->fstate->report, c->bin_capacity, c->max_items, c->seg_len, &c->fstate->seg_len, c->items_by_size, &c->fstate->queue, std::min<uint32_t>(c->max_items, c->blend_grid), c->seg_target_items, c->bin_blocks, c->bin_done,
                       c->seg_len == SEG_LEN_WHOLE_BIN ? 0 : c->long_items >= 0 ? c->long_items : c->saturate ? -1 : 0, SEG_LEN_LONG,
                       (c->opt.flags & GSR_FLAG_THROUGHPUT) ? LONG_TAU_THROUGHPUT : LONG_TAU_EXACT,
-                      (uint32_t)((g.bx_hi - g.bx_lo) * BIN_PX) * (uint32_t)c->H, c->quad_from};
+                      (uint32_t)((g.bx_hi - g.bx_lo) * BIN_PX) * (uint32_t)c->H, c->quad_from,
+                      (c->opt.flags & GSR_FLAG_THROUGHPUT) ? 0u : LONG_TILES_X2_EXACT};
         launch_bin(bb, g, c->n, s);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BIN], s));
         BlendBuffers bl{c->items, c->seg_start, c->bin_start, c->bin_list, c->rec, c->bbox, c->shcol, c->fb, c->partial,

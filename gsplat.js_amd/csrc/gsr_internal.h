@@ -186,6 +186,7 @@ struct BinBuffers {
     uint32_t seg_len_long, long_tau;
     uint32_t npix;               // pixels of this context's band (the optical depth is per pixel)
     uint32_t quad_from;          // single-item bins with at least this many entries become four work items, one per 16x16 tile (0: never)
+    uint32_t long_tiles_x2;      // long work items also need this many 16x16 tiles per visible splat, times two (0: no such condition)
 };
 void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s);
 

@@ -176,7 +176,7 @@ struct FinalizeArgs {
     uint64_t* mailbox;
     uint32_t* bin_done;
     int long_policy; uint32_t seg_len_long, long_tau, npix;   // see BinBuffers
-    uint32_t quad_from;
+    uint32_t quad_from, long_tiles_x2;
 };
 
 // One workgroup of FIN_THREADS threads.  It runs as an EXTRA workgroup of k_bin_scatter (the scatter workgroups
@@ -206,7 +206,21 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa)
     block_exclusive_scan<2>(ent, s_w, &ent_tot);
     // Long work items where the frame saturates (gsr_api.cpp, "Work-item length"): the frame's optical depth
     // tau = sum(opacity x tiles) x 256 / pixels from the projection's slots ([4] holds opacity byte x tiles / 16)
-    const bool dense = (uint64_t)ent_tot.v[1] * (16u * 256u) >= (uint64_t)fa.long_tau * 255u * (uint64_t)fa.npix;
+    // frame counters: the projection's visible-splat and tile-overlap sums (scans of two or three streams keep this
+    // workgroup inside the 64 registers of k_bin_scatter, which it is an extra workgroup of; four-stream scans made it
+    // spill 60 registers and the bin stage 5 us longer on C2)
+    UN<2> cnt = {{0, 0}};
+    if (have_counts && threadIdx.x < FRAME_SLOTS) {
+        cnt.v[0] = (uint32_t)slots[(size_t)threadIdx.x * FRAME_SLOT_WORDS + 2];
+        cnt.v[1] = (uint32_t)slots[(size_t)threadIdx.x * FRAME_SLOT_WORDS + 3];
+    }
+    UN<2> ctot;
+    block_exclusive_scan<2>(cnt, s_w, &ctot);
+    // dense enough to saturate: optical depth, and (one frame at a time, where the long items are the frame's tail) splats
+    // that cover several tiles each -- small splats take many more entries to saturate a pixel (the C2 generator at
+    // 1.6 M splats: tau 394, 3.6 tiles per splat, long items 8 % slower; C3: 5.3 tiles per splat, 23 % faster)
+    const bool dense = (uint64_t)ent_tot.v[1] * (16u * 256u) >= (uint64_t)fa.long_tau * 255u * (uint64_t)fa.npix &&
+                       (uint64_t)ctot.v[1] * 2u >= (uint64_t)fa.long_tiles_x2 * ctot.v[0];
     uint32_t seg_min = seg_len_min;
     if (seg_len_min < 0x40000000u && (fa.long_policy > 0 || (fa.long_policy < 0 && dense))) seg_min = max(seg_len_min, fa.seg_len_long);
     // segment length of this frame (a multiple of 256; the whole-bin sentinel of early termination passes through)
@@ -288,15 +302,6 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa)
         sx += nf + (part ? 1u : 0u);
         fx += nf;
     }
-    // frame counters (scans of two or three streams keep this workgroup inside the 64 registers of k_bin_scatter, which it
-    // is an extra workgroup of; four-stream scans made it spill 60 registers and the bin stage 5 us longer on C2)
-    UN<2> cnt = {{0, 0}};
-    if (have_counts && threadIdx.x < FRAME_SLOTS) {   // the projection's visible-splat and tile-overlap sums
-        cnt.v[0] = (uint32_t)slots[(size_t)threadIdx.x * FRAME_SLOT_WORDS + 2];
-        cnt.v[1] = (uint32_t)slots[(size_t)threadIdx.x * FRAME_SLOT_WORDS + 3];
-    }
-    UN<2> ctot;
-    block_exclusive_scan<2>(cnt, s_w, &ctot);
     if (threadIdx.x == 0) {
         *queue = queue_start;  // the compositor's workgroups take items 0..grid-1 by index, later ones from here
         seg_len_out[0] = seg_len;
@@ -567,7 +572,7 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
     }
     const FinalizeArgs fa{b.bin_total, nbins, b.seg_len, b.seg_target_items, b.items_by_size, b.seg_len_dev, b.max_items, b.capacity,
                           b.slots, n ? 1u : 0u, b.bin_start, b.seg_start, b.items, b.overflow, b.visible, b.tile_entries, b.accum,
-                          b.report, b.queue, b.queue_start, b.mailbox, b.bin_done, b.long_policy, b.seg_len_long, b.long_tau, b.npix, b.quad_from};
+                          b.report, b.queue, b.queue_start, b.mailbox, b.bin_done, b.long_policy, b.seg_len_long, b.long_tau, b.npix, b.quad_from, b.long_tiles_x2};
     const bool fused = n && nbins <= 4096;   // see k_bin_scatter
     if (!fused) hipLaunchKernelGGL(k_bin_finalize, dim3(1), dim3(FIN_THREADS), 0, s, fa);
     if (n) {
