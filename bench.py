@@ -386,10 +386,24 @@ def main():
                     noskip[key] = nfr / (time.perf_counter() - t4)
                     for x in xs:
                         x.dispose()
+                # and the claim itself, checked in this run: same cut of the lists (long work items pinned), skip off vs on
+                os.environ["GSR_LONG_ITEMS"] = "1"
+                a = gh.HIPRenderer(W, H, device=local_rank)
+                del os.environ["GSR_SATURATE"]
+                b = gh.HIPRenderer(W, H, device=local_rank)
+                same = True
+                for k in (17, 71):
+                    cam_k = gh.orbit_camera(k, ORBIT_FRAMES, W, H, cfg["fx"])
+                    a.render(scene, cam_k)
+                    b.render(scene, cam_k)
+                    same = same and bool(np.array_equal(a.readPixelsFloat(), b.readPixelsFloat()))
+                a.dispose(); b.dispose()
+                noskip["image_bit_identical_to_skip_on"] = same
                 noskip["note"] = "GSR_SATURATE=0: quadrants whose pixels can no longer change are still visited; identical image"
                 solo["without_saturation_skip"] = noskip
             finally:
-                del os.environ["GSR_SATURATE"]
+                os.environ.pop("GSR_SATURATE", None)
+                os.environ.pop("GSR_LONG_ITEMS", None)
         # the sort path alone, as the reference's worker runs it (wasm.cpp sort(): key + min/max + quantise + order):
         # gsr_sort = key kernel without projection + the two radix passes
         sr.reset_stats()
