@@ -235,7 +235,7 @@ constexpr uint32_t LOCAL_BUCKET_LIMIT = 48u << 10;
 // tau 145: 7350 -> 8640, tau 250: 4730 -> 6800); one frame at a time the few long items are the frame's tail and the
 // crossover depends on the scene (C3 generator: tau ~ 255, C3 itself +23 %; the C2 generator's small splats still lose
 // 8 % at tau 390), so the threshold there stays high.
-constexpr uint32_t SEG_LEN_LONG = 16384;
+constexpr uint32_t SEG_LEN_LONG = 32768;   // (16384: C4 k_blend 437 instead of 405 us -- its heaviest bins hold 50-100 k entries; 65536 measures the same)
 constexpr uint32_t LONG_TAU_EXACT = 340, LONG_TAU_THROUGHPUT = 120;
 constexpr uint32_t LONG_TILES_X2_EXACT = 9;   // one frame at a time: and at least 4.5 tiles per visible splat (k_bin_finalize)
 
