@@ -148,7 +148,7 @@ __device__ __forceinline__ UN<N> block_exclusive_scan(UN<N> x, uint32_t (*s_w)[F
 }
 
 // Long lists raise the segment length: the compositor needs a few thousand work items to fill the chip, not one
-// per 512 entries; every extra segment costs a 16 KiB partial written by k_blend and read by k_combine.
+// per 512 entries; every extra segment costs a 16 KiB partial written and read again by k_blend (the fold).
 constexpr uint32_t SEG_LEN_MAX = 8192;
 
 // Size class of a bin's last (partial) segment of r entries -- with long work items: of the whole bin -- for the order of

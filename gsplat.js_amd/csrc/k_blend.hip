@@ -23,9 +23,14 @@
 //     C = C0 + T0*C1 + T0*T1*C2 + ...,  T = T0*T1*T2*...
 // by the workgroup that delivers the bin's last segment (see the end of k_blend;
 // k_combine is the same fold as a separate launch, GSR_FUSE_COMBINE=0).
-// This removes the serial critical path of the heaviest tiles.  With early
-// termination enabled a bin is one item (segments could not see each other's
-// saturation), processed front to back until every pixel is opaque.
+// This removes the serial critical path of the heaviest tiles where nothing else
+// does.  Where the frame saturates, something else does: a quadrant whose pixels
+// can no longer change a bit (transmittance under half an ulp of the colour) is
+// not visited any more, a bin then needs only the few thousand entries in front,
+// and k_bin_finalize makes the work items whole bins (a segment would start from
+// transmittance 1 and never saturate on its own).  With early termination
+// enabled a bin is one item too, processed until every pixel is below the
+// caller's threshold.
 //
 // Compiled with -ffp-contract=off; the fused multiply-adds below are explicit,
 // so the coverage test (|vPosition|^2 <= 4) is bit-identical to the oracle's.
