@@ -238,6 +238,8 @@ constexpr uint32_t LOCAL_BUCKET_LIMIT = 48u << 10;
 constexpr uint32_t SEG_LEN_LONG = 32768;   // (16384: C4 k_blend 437 instead of 405 us -- its heaviest bins hold 50-100 k entries; 65536 measures the same)
 constexpr uint32_t LONG_TAU_EXACT = 340, LONG_TAU_THROUGHPUT = 120;
 constexpr uint32_t LONG_TILES_X2_EXACT = 9;   // one frame at a time: and at least 4.5 tiles per visible splat (k_bin_finalize)
+constexpr uint32_t LONG_TILES_X2_THROUGHPUT = 6;   // with frames in flight: 3 (scripts/policy_check.py: 2 M tiny splats, 1.9 tiles each, tau 264:
+                                                   // long items -26 %; the C2 generator, 3.6 tiles each: +10 % at the same tau)
 
 inline bool use_bucket_order(const gsr_ctx* c)
 {
@@ -350,7 +352,7 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
                       c->seg_len == SEG_LEN_WHOLE_BIN ? 0 : c->long_items >= 0 ? c->long_items : c->saturate ? -1 : 0, SEG_LEN_LONG,
                       (c->opt.flags & GSR_FLAG_THROUGHPUT) ? LONG_TAU_THROUGHPUT : LONG_TAU_EXACT,
                       (uint32_t)((g.bx_hi - g.bx_lo) * BIN_PX) * (uint32_t)c->H, c->quad_from,
-                      (c->opt.flags & GSR_FLAG_THROUGHPUT) ? 0u : LONG_TILES_X2_EXACT};
+                      (c->opt.flags & GSR_FLAG_THROUGHPUT) ? LONG_TILES_X2_THROUGHPUT : LONG_TILES_X2_EXACT};
         launch_bin(bb, g, c->n, s);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BIN], s));
         BlendBuffers bl{c->items, c->seg_start, c->bin_start, c->bin_list, c->rec, c->bbox, c->shcol, c->fb, c->partial,
