@@ -7,8 +7,8 @@ cp $R/bench_c3.json profiles/r02_bench_c3_exact.json
 cp $R/bench_c3_earlyout.json profiles/r02_bench_c3_earlyout.json
 cp $R/bench_c2.json profiles/r02_bench_c2_exact.json
 cp $R/bench_c4.json profiles/r02_bench_c4_exact.json
-cp $R/trace_1inflight/*/*kernel_stats.csv profiles/r02_kernel_stats_c3_exact_1inflight.csv
-cp $R/trace_3inflight/*/*kernel_stats.csv profiles/r02_kernel_stats_c3_exact_3inflight.csv
+cp $(ls -t $R/trace_1inflight/*/*kernel_stats.csv | head -1) profiles/r02_kernel_stats_c3_exact_1inflight.csv
+cp $(ls -t $R/trace_3inflight/*/*kernel_stats.csv | head -1) profiles/r02_kernel_stats_c3_exact_3inflight.csv
 python scripts/pmc_summary.py gpurun_out/pmc > profiles/r02_pmc_c3_exact.txt
 python scripts/make_blend_traffic.py gpurun_out/pmc > /dev/null
 for f in blend_stamps kernel_stamps valu_cost4; do [ -f gpurun_out/$f.txt ] && cp gpurun_out/$f.txt profiles/r02_$f.txt; done

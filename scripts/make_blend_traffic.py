@@ -3,8 +3,8 @@
 
 k_blend's HBM traffic and VALU instruction count per launch, for the two configurations bench.py runs: the timed region
 (several frames in flight, 2048-entry work items) and the one-frame leg (512-entry items).  Both launch 7 workgroups per
-CU, so they are told apart by dispatch order: under scripts/gpu_pmc.sh (--steps 12 --warmup 4, three contexts) the first
-3 + 4 + 12 = 19 k_blend dispatches of a pass belong to the timed region, the rest to the one-frame leg.
+CU, so each is profiled in runs of its own (scripts/gpu_pmc.sh: bench.py --timed-only with three frames in flight, and
+with one): every k_blend dispatch of a run belongs to one configuration.
 The file is stamped with the build id of the library the counters were collected on (bench.py refuses other builds).
 gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide read -> doubled (MI355X_MICROARCH.md, HBM); both counters
 are in KB."""
@@ -19,22 +19,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "pmc")
 build_id = sys.argv[2] if len(sys.argv) > 2 else open(os.path.join(src, "build_id.txt")).read().strip()
 
-THR_DISPATCHES = int(os.environ.get("THR_DISPATCHES", "19"))
-vals = {}   # (leg, counter) -> [values]
+vals = {}   # (leg, counter) -> [values]; leg 0 = pmc/inflight_*, leg 1 = pmc/solo_* (scripts/gpu_pmc.sh: one configuration per run)
 dur = {}
 grid_of = {}
-for f in glob.glob(os.path.join(src, "*", "*", "*counter_collection.csv")):
-    rows = [r for r in csv.DictReader(open(f)) if "k_blend" in r["Kernel_Name"]]
-    ids = sorted({int(r["Dispatch_Id"]) for r in rows})
-    thr = set(ids[:THR_DISPATCHES])
-    for r in rows:
-        which = 0 if int(r["Dispatch_Id"]) in thr else 1
-        vals.setdefault((which, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
-        dur.setdefault(which, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-        grid_of[which] = int(r["Grid_Size"]) // 256
+for which, legname in ((0, "inflight"), (1, "solo")):
+    for f in glob.glob(os.path.join(src, legname + "_*", "*", "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if "k_blend" not in r["Kernel_Name"]:
+                continue
+            vals.setdefault((which, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+            dur.setdefault(which, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+            grid_of[which] = int(r["Grid_Size"]) // 256
 grids = [0, 1]
 if not all((g, "FETCH_SIZE") in vals for g in grids):
-    raise SystemExit("expected k_blend dispatches of both legs in %s" % src)
+    raise SystemExit("expected k_blend dispatches of both legs (inflight_*, solo_*) in %s" % src)
 
 
 def leg(grid, what):
@@ -61,11 +59,11 @@ def leg(grid, what):
 doc = {
     "kernel": "k_blend",
     "build_id": build_id,
-    "workload": "C3 exact mode, bench.py --steps 12 --warmup 4 under rocprofv3 --pmc (kernels serialised by the profiler); medians per configuration",
+    "workload": "C3 exact mode, bench.py --timed-only --steps 24 --warmup 4 under rocprofv3 --pmc (kernels serialised by the profiler); medians per configuration",
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ counters, separate passes (scripts/gpu_pmc.sh); summary of all kernels in profiles/r02_pmc_c3_exact.txt",
     "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for 16-B-per-lane reads -> doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact; rocprofv3 reports both in KB (x1024); for this kernel's 32-byte record gathers the doubling is an upper bound: true traffic lies between fetch_raw + write and 2 x fetch_raw + write",
-    "frames_in_flight": leg(0, "GSR_FLAG_THROUGHPUT contexts (the timed region of the default bench): the first %d dispatches" % THR_DISPATCHES),
-    "one_frame": leg(1, "default context (bench.py's one_frame_in_flight leg): the remaining dispatches"),
+    "frames_in_flight": leg(0, "GSR_FLAG_THROUGHPUT contexts, three frames in flight (the timed region of the default bench)"),
+    "one_frame": leg(1, "exact context, one frame at a time (bench.py --frames-in-flight 1; the one_frame_in_flight leg uses the same)"),
     "note": "counts L2<->fabric traffic incl. Infinity Cache hits; the 32 MB record array is cache resident. Above the algorithmic 32D+16P because each 32-B record gather pulls a whole line and the segment partials are written, then re-read by the fold at the end of k_blend.",
 }
 json.dump(doc, open(os.path.join(ROOT, "profiles", "blend_traffic.json"), "w"), indent=1)

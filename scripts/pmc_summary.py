@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc counter_collection.csv files: per kernel, mean counter value per dispatch."""
+"""Summarise rocprofv3 --pmc counter_collection.csv files: per kernel, median counter value per dispatch.
+  python scripts/pmc_summary.py [gpurun_out/pmc] [leg]     leg = solo | inflight (scripts/gpu_pmc.sh), default solo"""
 import csv
 import glob
 import sys
 from collections import defaultdict
 
-def main(root):
+def main(root, leg="solo"):
     agg = defaultdict(lambda: defaultdict(list))
     dur = defaultdict(list)
-    for f in glob.glob(root + "/*/runc/*counter_collection.csv") + glob.glob(root + "/*/*/*counter_collection.csv"):
+    for f in sorted(set(glob.glob(root + "/" + leg + "_*/*/*counter_collection.csv"))):
         seen = set()
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("gsr::", "")
@@ -25,4 +26,4 @@ def main(root):
             print("     %-24s %16.1f" % (c, v[len(v) // 2]))
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc")
+    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc", sys.argv[2] if len(sys.argv) > 2 else "solo")
