@@ -37,6 +37,7 @@ struct FrameState {  // small per-frame device words, reset by k_begin_frame (mi
     uint32_t sorted_count;  // entries of depth_index: n, or the band's survivors (SortBuffers::count)
     uint32_t seg_len;       // the frame's compositor segment length (k_bin_finalize -> k_blend)
     uint32_t n_items;       // and its number of work items (directly behind seg_len: k_blend reads both through one pointer)
+    uint32_t win_len;       // and the length of a window segment, or 0 (k_bin_finalize, "front window")
 };
 
 }  // namespace
@@ -81,6 +82,10 @@ struct gsr_ctx {
     bool fuse_combine = true;
     bool saturate = true;             // skip quadrants that can no longer change (GSR_SATURATE=0: composite every entry)
     int long_items = -1;              // -1: long work items where the frame's optical depth says so (LONG_TAU), 0 / 1: pinned (GSR_LONG_ITEMS)
+    uint32_t win_from = 0, win_segs = 0, win_len = 0;   // front window of heavy bins (alloc_bins; GSR_WIN_FROM / GSR_WIN_SEGS / GSR_WIN_LEN)
+    uint32_t prio[3] = {0, 0, 0};                       // compositor wave priorities by queue position (alloc_bins; GSR_PRIO=a,b,c)
+    long prio_env[3] = {-1, -1, -1};
+    long win_env[3] = {-1, -1, -1};                     // those three knobs as read when the context was created (-1: not set)
     uint32_t* bin_rects = nullptr;
     float4* partial = nullptr;
     uint32_t bin_blocks = 0, bin_capacity = 0, bin_table_elems = 0, bin_nbins_alloc = 0;
@@ -238,6 +243,11 @@ constexpr uint32_t LOCAL_BUCKET_LIMIT = 48u << 10;
 constexpr uint32_t SEG_LEN_LONG = 32768;   // (16384: C4 k_blend 437 instead of 405 us -- its heaviest bins hold 50-100 k entries; 65536 measures the same)
 constexpr uint32_t LONG_TAU_EXACT = 340, LONG_TAU_THROUGHPUT = 120;
 constexpr uint32_t LONG_TILES_X2_EXACT = 9;   // one frame at a time: and at least 4.5 tiles per visible splat (k_bin_finalize)
+// Front window (k_bin_finalize): in a frame with long work items, a bin of at least WIN_FROM entries hands out its first
+// WIN_SEGS x WIN_LEN entries as concurrent segments; the workgroup that folds them continues behind the window.
+constexpr uint32_t WIN_FROM_EXACT = 0, WIN_SEGS_EXACT = 4, WIN_LEN_EXACT = 1024;
+constexpr uint32_t PRIO_FRAC_A = 0, PRIO_FRAC_B = 0, PRIO_FRAC_C = 0;   // of the compositor's grid, in 1/256 (see k_blend)
+constexpr uint32_t WIN_FROM_THROUGHPUT = 0, WIN_SEGS_THROUGHPUT = 4, WIN_LEN_THROUGHPUT = 1024;
 constexpr uint32_t LONG_TILES_X2_THROUGHPUT = 6;   // with frames in flight: 3 (scripts/policy_check.py: 2 M tiny splats, 1.9 tiles each, tau 264:
                                                    // long items -26 %; the C2 generator, 3.6 tiles each: +10 % at the same tau)
 
@@ -290,9 +300,24 @@ int alloc_bins(gsr_ctx* c)
         const long v = atol(e);
         if (v >= 256 && c->seg_len != SEG_LEN_WHOLE_BIN) c->seg_len = (uint32_t)(v / 256 * 256);
     }
+    // front window of heavy bins in frames with long work items (k_bin_finalize, k_blend)
+    c->win_from = throughput ? WIN_FROM_THROUGHPUT : WIN_FROM_EXACT;
+    c->win_segs = throughput ? WIN_SEGS_THROUGHPUT : WIN_SEGS_EXACT;
+    c->win_len = throughput ? WIN_LEN_THROUGHPUT : WIN_LEN_EXACT;
+    {   // wave priorities of the compositor's heaviest work items (k_blend), by queue position
+        const uint32_t grid = c->blend_grid;
+        c->prio[0] = grid * PRIO_FRAC_A / 256u; c->prio[1] = grid * PRIO_FRAC_B / 256u; c->prio[2] = grid * PRIO_FRAC_C / 256u;
+        for (int k = 0; k < 3; k++)
+            if (c->prio_env[k] >= 0) c->prio[k] = (uint32_t)c->prio_env[k];
+    }
+    if (c->win_env[0] >= 0) c->win_from = (uint32_t)c->win_env[0];   // GSR_WIN_FROM (0: no windows), GSR_WIN_SEGS, GSR_WIN_LEN: read at gsr_create
+    if (c->win_env[1] >= 0) c->win_segs = (uint32_t)std::max(2L, c->win_env[1]);
+    if (c->win_env[2] >= 0) c->win_len = (uint32_t)(std::max(512L, c->win_env[2]) / 256 * 256);
+    if (!c->fuse_combine || c->win_segs < 2) c->win_from = 0;   // the window's tail is continued by the folding workgroup of k_blend
+    if (c->win_from) c->win_from = std::max(c->win_from, c->win_len + 1u);   // a windowed bin has at least two segments
     // segments (each may need a partial slot): one per bin plus one per seg_len entries; work items: a heavy single-segment
     // bin is handed out as four (ITEM_TILE0), so up to three more per bin
-    const uint32_t want_segs = nbins + c->bin_capacity / c->seg_len + 16;
+    const uint32_t want_segs = nbins + c->bin_capacity / (c->win_from ? std::min(c->seg_len, c->win_len) : c->seg_len) + 16;
     const uint32_t want_items = want_segs + 3u * nbins;
     if (items_dirty || want_items > c->max_items) {
         c->max_items = want_items;
@@ -352,12 +377,13 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
                       c->seg_len == SEG_LEN_WHOLE_BIN ? 0 : c->long_items >= 0 ? c->long_items : c->saturate ? -1 : 0, SEG_LEN_LONG,
                       (c->opt.flags & GSR_FLAG_THROUGHPUT) ? LONG_TAU_THROUGHPUT : LONG_TAU_EXACT,
                       (uint32_t)((g.bx_hi - g.bx_lo) * BIN_PX) * (uint32_t)c->H, c->quad_from,
-                      (c->opt.flags & GSR_FLAG_THROUGHPUT) ? LONG_TILES_X2_THROUGHPUT : LONG_TILES_X2_EXACT};
+                      (c->opt.flags & GSR_FLAG_THROUGHPUT) ? LONG_TILES_X2_THROUGHPUT : LONG_TILES_X2_EXACT,
+                      c->win_from, c->win_segs, c->win_len};
         launch_bin(bb, g, c->n, s);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BIN], s));
         BlendBuffers bl{c->items, c->seg_start, c->bin_start, c->bin_list, c->rec, c->bbox, c->shcol, c->fb, c->partial,
                         &c->fstate->queue, c->seg_len, &c->fstate->seg_len, std::min<uint32_t>(c->max_items, c->blend_grid), c->bin_capacity,
-                        std::max(c->n, 1u), c->bin_done, c->saturate ? 1u : 0u};
+                        std::max(c->n, 1u), c->bin_done, c->saturate ? 1u : 0u, {c->prio[0], c->prio[1], c->prio[2]}};
         launch_blend(bl, g, c->opt.early_out_eps, s, (timing && !c->bin_done) ? c->ev[EV_BLEND] : nullptr);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_COMBINE], s));
     }
@@ -388,6 +414,7 @@ static std::vector<uint64_t> chain_signature(const gsr_ctx* c)
     U(c->n); U((uint64_t)c->W); U((uint64_t)c->H); U((uint64_t)g.bx_lo); U((uint64_t)g.bx_hi); U(c->sort_kpb); U(c->sort_blocks);
     U(c->bin_capacity); U(c->max_items); U(c->seg_len); U(c->seg_target_items); U(c->blend_grid); U(c->bin_blocks);
     U((uint64_t)c->opt.flags); U((uint64_t)(c->opt.early_out_eps * 1e9f)); U(c->bucket_order_now ? 1u : 0u); U(c->saturate ? 1u : 0u); U((uint64_t)c->items_by_size); U(c->quad_from); U((uint64_t)(int64_t)c->long_items);
+    U(c->win_from); U(c->win_segs); U(c->win_len); U(c->prio[0]); U(c->prio[1]); U(c->prio[2]);
     return v;
 }
 
@@ -591,6 +618,14 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
     if (const char* e = getenv("GSR_ITEMS_BY_SIZE")) c->items_by_size = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("GSR_QUAD_FROM")) c->quad_from = (uint32_t)std::max(0L, atol(e));
     if (const char* e = getenv("GSR_LONG_ITEMS")) c->long_items = atoi(e) != 0 ? 1 : 0; // pins the work-item length policy
+    if (const char* e = getenv("GSR_PRIO")) {   // "a,b,c": queue positions below which a work item runs at wave priority 3, 2, 1
+        long v[3] = {0, 0, 0};
+        if (sscanf(e, "%ld%*[,:]%ld%*[,:]%ld", &v[0], &v[1], &v[2]) >= 1)
+            for (int k = 0; k < 3; k++) c->prio_env[k] = std::max(0L, v[k]);
+    }
+    if (const char* e = getenv("GSR_WIN_FROM")) c->win_env[0] = std::max(0L, atol(e));
+    if (const char* e = getenv("GSR_WIN_SEGS")) c->win_env[1] = std::max(0L, atol(e));
+    if (const char* e = getenv("GSR_WIN_LEN")) c->win_env[2] = std::max(0L, atol(e));
     CREATE_TRY(hipMalloc((void**)&c->accum, 8 * sizeof(uint64_t)));
     CREATE_TRY(hipMemset(c->accum, 0, 8 * sizeof(uint64_t)));
     CREATE_TRY(hipHostMalloc((void**)&c->mailbox, 64, hipHostMallocMapped));
@@ -1139,6 +1174,20 @@ int gsr_read_sh_colors(gsr_ctx* c, float* rgba)
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpyAsync(rgba, c->shcol, (size_t)c->n * 16, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return GSR_OK;
+}
+
+int gsr_read_work_items(gsr_ctx* c, uint32_t* out)
+{
+    if (!c || !out) return c ? fail(c, GSR_ERR_ARG, "out is NULL") : GSR_ERR_ARG;
+    if (!c->have_frame) return fail(c, GSR_ERR_ARG, "no frame has been rendered yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    static_assert(offsetof(FrameState, n_items) == offsetof(FrameState, seg_len) + 4 && offsetof(FrameState, win_len) == offsetof(FrameState, seg_len) + 8,
+                  "seg_len, n_items, win_len are read through one pointer");
+    HIP_TRY(c, hipMemcpyAsync(out, &c->fstate->seg_len, 12, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const BinGrid g = make_grid(c);
+    out[3] = (uint32_t)((g.bx_hi - g.bx_lo) * g.nby);
     return GSR_OK;
 }
 

@@ -177,6 +177,7 @@ struct FinalizeArgs {
     uint32_t* bin_done;
     int long_policy; uint32_t seg_len_long, long_tau, npix;   // see BinBuffers
     uint32_t quad_from, long_tiles_x2;
+    uint32_t win_from, win_segs, win_len;   // front window of heavy bins (long work items only); see BinBuffers
 };
 
 // One workgroup of FIN_THREADS threads.  It runs as an EXTRA workgroup of k_bin_scatter (the scatter workgroups
@@ -242,18 +243,41 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa)
     // 8x8 quadrant (k_blend, ITEM_TILE0): meant to shorten the one-frame kernel's tail (its last workgroups hold the
     // heaviest bins), bit-identical, but measured slower at every threshold -- the bin is staged four times and a wave
     // that owns one quadrant pays the per-entry costs for a quarter of the pixels.  Off unless GSR_QUAD_FROM is set.
-    const uint32_t quad_from = (fa.by_size != 0 && fa.quad_from) ? fa.quad_from : 0xffffffffu;
+    // Front window (frames with long work items, fold inside the compositor): a whole-bin item is as long as the bin's
+    // saturation depth, and the heaviest bins' items were the one-frame kernel's pole (C3: the last waves ran ONE item for
+    // ~200 us of a 181 us kernel, the slots 49 % occupied).  A bin of at least win_from entries therefore hands out its
+    // first win_segs * win_len entries as win_segs concurrent segments (each from transmittance 1, through the partials);
+    // the workgroup whose arrival is last folds them and CONTINUES behind the window with the folded (colour, transmittance)
+    // in its registers, saturation test on (k_blend).  Such a bin's "full segments" are its window segments; it has no
+    // last-segment item.  Lighter bins stay whole-bin items.
+    const bool win = fa.win_from != 0u && fa.bin_done != nullptr && seg_min > seg_len_min && seg_min < 0x40000000u;
+    const uint32_t win_from = fa.win_from, win_segs = fa.win_segs, win_len = fa.win_len;
+    // the cut of a bin of c entries: nf full (or window) segments, and whether a last-segment (or whole-bin) item of r entries follows
+    auto cut = [&](uint32_t c, uint32_t& nf, uint32_t& r, bool& part) {
+        if (win) {
+            const bool w = c >= win_from;
+            nf = w ? min(win_segs, (c + win_len - 1u) / win_len) : 0u;
+            r = w ? 0u : c;
+            part = !w;
+        } else {
+            nf = c / seg_len;
+            r = c - nf * seg_len;
+            part = r || !nf;
+        }
+    };
+    const uint32_t quad_from = (fa.by_size != 0 && fa.quad_from && !win) ? fa.quad_from : 0xffffffffu;
     UN<3> mine = {{0, 0, 0}};   // entries, segments, full segments
     UN<1> extra = {{0}};        // extra work items (3 per heavy bin)
     for (int b = b0; b < b1; b++) {
         const uint32_t c = bin_total[b];
-        const uint32_t nf = c / seg_len, r = c - nf * seg_len;
+        uint32_t nf, r; bool part;
+        cut(c, nf, r, part);
         mine.v[0] += c;
-        mine.v[1] += nf + ((r || !nf) ? 1u : 0u);
+        mine.v[1] += nf + (part ? 1u : 0u);
         mine.v[2] += nf;
         const bool quad = !nf && c >= quad_from;
         extra.v[0] += quad ? 3u : 0u;
-        if (by_size && (r || !nf)) atomicAdd(&s_cls[partial_class(r)], quad ? 4u : 1u);
+        if (by_size && part) atomicAdd(&s_cls[partial_class(r)], quad ? 4u : 1u);
     }
     UN<3> tot;
     const UN<3> ex3 = block_exclusive_scan<3>(mine, s_w, &tot);   // (its barriers also order the class counts)
@@ -280,8 +304,8 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa)
     const bool fits = tot.v[0] <= capacity && n_items <= max_items;
     for (int b = b0; b < b1; b++) {
         const uint32_t c = bin_total[b];
-        const uint32_t nf = c / seg_len, r = c - nf * seg_len;
-        const bool part = r || !nf;
+        uint32_t nf, r; bool part;
+        cut(c, nf, r, part);
         bin_start[b] = fits ? ex : 0u;
         seg_start[b] = fits ? sx : 0u;
         if (fa.bin_done) fa.bin_done[b] = 0u;
@@ -306,6 +330,7 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa)
         *queue = queue_start;  // the compositor's workgroups take items 0..grid-1 by index, later ones from here
         seg_len_out[0] = seg_len;
         seg_len_out[1] = fits ? n_items : 0u;   // the compositor's queue length
+        seg_len_out[2] = win ? win_len : 0u;    // entries per window segment of a multi-segment bin (0: plain segments of seg_len)
         bin_start[nbins] = fits ? tot.v[0] : 0u;
         seg_start[nbins] = fits ? tot.v[1] : 0u;
         accum[4] = tot.v[0];  // entries this frame needs (the host sizes the regrowth from it)
@@ -572,7 +597,8 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
     }
     const FinalizeArgs fa{b.bin_total, nbins, b.seg_len, b.seg_target_items, b.items_by_size, b.seg_len_dev, b.max_items, b.capacity,
                           b.slots, n ? 1u : 0u, b.bin_start, b.seg_start, b.items, b.overflow, b.visible, b.tile_entries, b.accum,
-                          b.report, b.queue, b.queue_start, b.mailbox, b.bin_done, b.long_policy, b.seg_len_long, b.long_tau, b.npix, b.quad_from, b.long_tiles_x2};
+                          b.report, b.queue, b.queue_start, b.mailbox, b.bin_done, b.long_policy, b.seg_len_long, b.long_tau, b.npix, b.quad_from, b.long_tiles_x2,
+                          b.win_from, b.win_segs, b.win_len};
     const bool fused = n && nbins <= 4096;   // see k_bin_scatter
     if (!fused) hipLaunchKernelGGL(k_bin_finalize, dim3(1), dim3(FIN_THREADS), 0, s, fa);
     if (n) {

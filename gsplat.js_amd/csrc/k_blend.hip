@@ -77,7 +77,8 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
                                                          const float4* __restrict__ shcol, float4* __restrict__ fb,
                                                          float4* __restrict__ partial, uint32_t* __restrict__ queue,
                                                          BinGrid g, float eps, const uint32_t* __restrict__ seg_len_dev, uint32_t capacity,
-                                                         uint32_t nsplats, uint32_t* __restrict__ bin_done, uint32_t saturate)
+                                                         uint32_t nsplats, uint32_t* __restrict__ bin_done, uint32_t saturate,
+                                                         uint32_t prio_a, uint32_t prio_b, uint32_t prio_c)
 {
     const uint32_t seg_len = *seg_len_dev;  // this frame's list entries per work item (k_bin_finalize)
     // [0]: ux, uy, -dot(u, c - bin origin), wx   [1]: wy, -dot(w, c - bin origin), log2(opacity), blue   [2]: red, green
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lx = lane & 7, ly = lane >> 3;
     const uint32_t total_items = seg_len_dev[1];   // the frame's work items (k_bin_finalize; heavy bins count four)
+    const uint32_t wlen = seg_len_dev[2];          // entries per window segment of a multi-segment bin, or 0 (k_bin_finalize, "front window")
 
     // Work items come from one device-wide queue (items are ordered heaviest first), so a workgroup
     // that drew light items simply draws more: no static assignment, no long pole.
@@ -116,6 +118,17 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
         if (qi >= total_items) break;
         const uint32_t it = items[qi];
         const int bin = (int)(it & 0xffffu);
+        // Wave priority by the item's place in the queue (items are ordered heaviest first): the longest items are the
+        // kernel's pole when seven waves share a SIMD and every one of them gets a seventh of its issue slots -- the
+        // waves of the first prio_a items issue ahead of the others on their SIMDs, then those below prio_b, prio_c
+        // (longest job first; the lighter items fill the slots the heavy ones leave while they wait on LDS or barriers).
+        {
+            const int pr = (qi < prio_a ? 1 : 0) + (qi < prio_b ? 1 : 0) + (qi < prio_c ? 1 : 0);
+            if (pr == 3) __builtin_amdgcn_s_setprio(3);
+            else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+            else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
 #ifdef GSR_BLEND_STAMPS
         a_items++; a_item_t0 = (unsigned int)__builtin_amdgcn_s_memrealtime(); a_last_start = a_item_t0; a_item_vis0 = a_entries; a_item_bin = (unsigned int)bin;
 #endif
@@ -143,16 +156,34 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
         float g00 = 0.f, g10 = 0.f, g01 = 0.f, g11 = 0.f;
         float b00 = 0.f, b10 = 0.f, b01 = 0.f, b11 = 0.f;
 
+        // A bin with a front window (k_bin_finalize): its nseg items are the window's segments of wlen entries, and the
+        // entries behind the window belong to whichever workgroup folds the window (below).
+        const bool windowed = wlen != 0u && nseg > 1u;
+        const uint32_t step = windowed ? wlen : seg_len;
+        const uint32_t bin_begin = bin_start[bin];
         const uint32_t bin_end = min(bin_start[bin + 1], capacity);
-        const uint32_t begin = min(bin_start[bin] + seg * seg_len, bin_end);
-        const uint32_t end = min(begin + seg_len, bin_end);
-        const bool sat_item = saturate != 0u && end - begin > 2u * CHUNK;   // only long items test for saturation
-        bool done = false;
-        uint32_t alive = mask_sel;   // quadrants of mine that can still change (wave-uniform); see the saturation test below
+        uint32_t begin = min(bin_begin + seg * step, bin_end);
+        uint32_t end = min(begin + step, bin_end);
+        const uint32_t tail_begin = windowed ? min(bin_begin + nseg * wlen, bin_end) : bin_end;
+        // only long items test for saturation (a window segment starts from transmittance 1 like any segment: it cannot)
+        bool sat_item = saturate != 0u && !windowed && end - begin > 2u * CHUNK;
+        uint32_t sat_from = SAT_FROM;
+        // quadrants of mine that can still change (wave-uniform); see the saturation test below.  Quadrants that lie outside
+        // the image (the last bin row of 1080p: rows 1080..1087) never could: their pixels are not stored.
+        uint32_t alive0 = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (X0 + 8 * (q & 1) < g.W && Y0 + 8 * (q >> 1) < g.H) alive0 |= 1u << q;
+        alive0 &= mask_sel;
+        uint32_t alive = alive0;
+        bool done = alive0 == 0u;
+        if (done && lane == 0) atomicAdd(&s_done, 1u);
+        bool final_pass = false, write_fb = false;
 #ifdef GSR_BLEND_STAMPS
         a_item_len = end - begin;
 #endif
 
+        for (;;) {   // pass 1: the item's own entries; pass 2, only in the workgroup that folds a window: the entries behind it
         for (uint32_t base = begin; base < end; base += CHUNK) {
             STAMP(t_c0);
             __syncthreads();  // previous chunk fully consumed (and s_done visible)
@@ -285,7 +316,7 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
                     // work item (s_done).  Pixels with a zero channel finish only at T == 0.
                     // (Items of up to two chunks -- all a frame that does not saturate has -- never run the test, which
                     //  cost 3 % on C2, and nothing saturates within an item's first SAT_FROM entries.)
-                    if (sat_item && base - begin + c0 >= SAT_FROM) {
+                    if (sat_item && base - begin + c0 >= sat_from) {
                         constexpr float K = 0x1p-27f, NEAR = 1e-6f;   // nothing above NEAR can pass the test: a cheap filter first
 #define GSR_FINISHED(BIT, T, R, G, B_)                                                                          \
     if ((alive & (BIT)) && __ballot((T) >= NEAR) == 0ull &&                                                      \
@@ -312,24 +343,8 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
 #endif
         }
 
-#ifdef GSR_BLEND_STAMPS
+        if (nseg == 1u || final_pass) { write_fb = true; break; }
         {
-            const unsigned int d = (unsigned int)__builtin_amdgcn_s_memrealtime() - a_item_t0;
-            if (d > a_max_dur) { a_max_dur = d; a_max_len = a_item_len; a_max_vis = a_entries - a_item_vis0; a_max_bin = a_item_bin; }
-        }
-#endif
-        if (nseg == 1) {
-            // ---- the only segment: write the tile, premultiplied RGBA, alpha = 1 - T ----
-            const int x0 = X0 + lx, x1 = x0 + 8, y0 = Y0 + ly, y1 = y0 + 8;
-            if (y0 < g.H) {
-                if (x0 < g.W) fb[(size_t)y0 * g.W + x0] = make_float4(r00, g00, b00, 1.0f - T00);
-                if (x1 < g.W && !tile_item) fb[(size_t)y0 * g.W + x1] = make_float4(r10, g10, b10, 1.0f - T10);
-            }
-            if (y1 < g.H && !tile_item) {
-                if (x0 < g.W) fb[(size_t)y1 * g.W + x0] = make_float4(r01, g01, b01, 1.0f - T01);
-                if (x1 < g.W) fb[(size_t)y1 * g.W + x1] = make_float4(r11, g11, b11, 1.0f - T11);
-            }
-        } else {
             // ---- partial (colour, transmittance) of this segment, slot-major: fully coalesced ----
             float4* p0 = partial + (size_t)seg_start[bin] * BIN_PIXELS + wave * (TILE * TILE) + lane;
             float4* p = p0 + (size_t)seg * BIN_PIXELS;
@@ -338,59 +353,85 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
                 p[64] = make_float4(r10, g10, b10, T10);
                 p[128] = make_float4(r01, g01, b01, T01);
                 p[192] = make_float4(r11, g11, b11, T11);
-            } else {
-                // The workgroup that delivers a bin's LAST segment folds the bin itself (front to back, k_combine's fixed
-                // order: which workgroup does it changes nothing in the result), so the fold runs beside the other
-                // workgroups' arithmetic and the k_combine launch goes away.
-                // Visibility between workgroups on different XCDs (one L2 each) WITHOUT a release fence: an agent-scope
-                // release is buffer_wbl2, a write-back of the XCD's whole L2, and one per work item made the kernel 3.5x
-                // slower.  Instead the partials are the only data exchanged and they move with agent-scope accesses on
-                // both sides (sc1: the stores write through, the loads bypass the CU's L1): every storing wave drains its
-                // stores (vmcnt 0), the workgroup's barrier, then ONE lane counts the arrival with an agent-scope atomic
-                // add; the workgroup whose add came last takes one agent-scope acquire and loads behind a barrier
-                // (MI355X_MICROARCH.md, Workgroup dispatch ... inter-workgroup visibility, Valid forms).
-                typedef float v4f __attribute__((ext_vector_type(4)));
+                break;
+            }
+            // The workgroup that delivers a bin's LAST segment folds the bin itself (front to back, k_combine's fixed
+            // order: which workgroup does it changes nothing in the result), so the fold runs beside the other
+            // workgroups' arithmetic and the k_combine launch goes away.
+            // Visibility between workgroups on different XCDs (one L2 each) WITHOUT a release fence: an agent-scope
+            // release is buffer_wbl2, a write-back of the XCD's whole L2, and one per work item made the kernel 3.5x
+            // slower.  Instead the partials are the only data exchanged and they move with agent-scope accesses on
+            // both sides (sc1: the stores write through, the loads bypass the CU's L1): every storing wave drains its
+            // stores (vmcnt 0), the workgroup's barrier, then ONE lane counts the arrival with an agent-scope atomic
+            // add; the workgroup whose add came last takes one agent-scope acquire and loads behind a barrier
+            // (MI355X_MICROARCH.md, Workgroup dispatch ... inter-workgroup visibility, Valid forms).
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            {
                 const v4f o0 = {r00, g00, b00, T00}, o1 = {r10, g10, b10, T10}, o2 = {r01, g01, b01, T01}, o3 = {r11, g11, b11, T11};
                 asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:1024 sc1\n\t"
                              "global_store_dwordx4 %0, %3, off offset:2048 sc1\n\tglobal_store_dwordx4 %0, %4, off offset:3072 sc1\n\t"
                              "s_waitcnt vmcnt(0)"
                              :: "v"(p), "v"(o0), "v"(o1), "v"(o2), "v"(o3) : "memory");
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    const bool last = __hip_atomic_fetch_add(&bin_done[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nseg - 1u;
-                    if (last) {
-                        // one agent-scope acquire on the folding CU (buffer_inv sc1: drops this CU's L1, about 1.7 us, once
-                        // per multi-segment bin) in front of the barrier the other waves load behind.  The loads below are
-                        // sc1 and bypass the L1 by themselves; the acquire makes the hand-off the documented form
-                        // (MI355X_MICROARCH.md, Valid forms) rather than one that rests on that alone.
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    }
-                    s_last = last ? 1u : 0u;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const bool last = __hip_atomic_fetch_add(&bin_done[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nseg - 1u;
+                if (last) {
+                    // one agent-scope acquire on the folding CU (buffer_inv sc1: drops this CU's L1, about 1.7 us, once
+                    // per multi-segment bin) in front of the barrier the other waves load behind.  The loads below are
+                    // sc1 and bypass the L1 by themselves; the acquire makes the hand-off the documented form
+                    // (MI355X_MICROARCH.md, Valid forms) rather than one that rests on that alone.
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    s_done = 0;   // (a second pass starts with every tile live again)
                 }
-                __syncthreads();
-                if (s_last) {
-                    float cr[4] = {0.f, 0.f, 0.f, 0.f}, cg[4] = {0.f, 0.f, 0.f, 0.f}, cb[4] = {0.f, 0.f, 0.f, 0.f}, cT[4] = {1.f, 1.f, 1.f, 1.f};
-                    for (uint32_t k = 0; k < nseg; k++) {
-                        v4f v[4];
-                        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
-                                     "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:3072 sc1\n\t"
-                                     "s_waitcnt vmcnt(0)"
-                                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(p0 + (size_t)k * BIN_PIXELS) : "memory");
-#pragma unroll
-                        for (int slot = 0; slot < 4; slot++) {
-                            cr[slot] = __builtin_fmaf(cT[slot], v[slot].x, cr[slot]);
-                            cg[slot] = __builtin_fmaf(cT[slot], v[slot].y, cg[slot]);
-                            cb[slot] = __builtin_fmaf(cT[slot], v[slot].z, cb[slot]);
-                            cT[slot] = cT[slot] * v[slot].w;
-                        }
-                    }
-#pragma unroll
-                    for (int slot = 0; slot < 4; slot++) {
-                        const int x = X0 + lx + 8 * (slot & 1), y = Y0 + ly + 8 * (slot >> 1);
-                        if (x < g.W && y < g.H) fb[(size_t)y * g.W + x] = make_float4(cr[slot], cg[slot], cb[slot], 1.0f - cT[slot]);
-                    }
-                }
+                s_last = last ? 1u : 0u;
+            }
+            __syncthreads();
+            if (!s_last) break;
+            // fold, front to back, into the accumulators: C = C0 + T0*C1 + T0*T1*C2 + ..., T = T0*T1*...
+            r00 = r10 = r01 = r11 = 0.f; g00 = g10 = g01 = g11 = 0.f; b00 = b10 = b01 = b11 = 0.f;
+            T00 = T10 = T01 = T11 = 1.f;
+            for (uint32_t k = 0; k < nseg; k++) {
+                v4f v0, v1, v2, v3;
+                asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
+                             "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:3072 sc1\n\t"
+                             "s_waitcnt vmcnt(0)"
+                             : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(p0 + (size_t)k * BIN_PIXELS) : "memory");
+                r00 = __builtin_fmaf(T00, v0.x, r00); g00 = __builtin_fmaf(T00, v0.y, g00); b00 = __builtin_fmaf(T00, v0.z, b00); T00 = T00 * v0.w;
+                r10 = __builtin_fmaf(T10, v1.x, r10); g10 = __builtin_fmaf(T10, v1.y, g10); b10 = __builtin_fmaf(T10, v1.z, b10); T10 = T10 * v1.w;
+                r01 = __builtin_fmaf(T01, v2.x, r01); g01 = __builtin_fmaf(T01, v2.y, g01); b01 = __builtin_fmaf(T01, v2.z, b01); T01 = T01 * v2.w;
+                r11 = __builtin_fmaf(T11, v3.x, r11); g11 = __builtin_fmaf(T11, v3.y, g11); b11 = __builtin_fmaf(T11, v3.z, b11); T11 = T11 * v3.w;
+            }
+            if (tail_begin >= bin_end) { write_fb = true; break; }
+            // ---- behind the window: this workgroup goes on with the bin's remaining entries under the folded
+            //      transmittance, so the saturation test sees the true state of every pixel (from the first 64 entries on:
+            //      a window that already saturated the bin costs one staged chunk) ----
+            begin = tail_begin; end = bin_end;
+            final_pass = true;
+            sat_item = saturate != 0u;
+            sat_from = 0u;
+            alive = alive0;
+            done = alive0 == 0u;
+            if (done && lane == 0) atomicAdd(&s_done, 1u);
+        }
+        }   // passes
+#ifdef GSR_BLEND_STAMPS
+        {
+            const unsigned int d = (unsigned int)__builtin_amdgcn_s_memrealtime() - a_item_t0;
+            if (d > a_max_dur) { a_max_dur = d; a_max_len = a_item_len + (final_pass ? end - begin : 0u); a_max_vis = a_entries - a_item_vis0; a_max_bin = a_item_bin; }
+        }
+#endif
+        if (write_fb) {
+            // ---- write the tile, premultiplied RGBA, alpha = 1 - T ----
+            const int x0 = X0 + lx, x1 = x0 + 8, y0 = Y0 + ly, y1 = y0 + 8;
+            if (y0 < g.H) {
+                if (x0 < g.W) fb[(size_t)y0 * g.W + x0] = make_float4(r00, g00, b00, 1.0f - T00);
+                if (x1 < g.W && !tile_item) fb[(size_t)y0 * g.W + x1] = make_float4(r10, g10, b10, 1.0f - T10);
+            }
+            if (y1 < g.H && !tile_item) {
+                if (x0 < g.W) fb[(size_t)y1 * g.W + x0] = make_float4(r01, g01, b01, 1.0f - T01);
+                if (x1 < g.W) fb[(size_t)y1 * g.W + x1] = make_float4(r11, g11, b11, 1.0f - T11);
             }
         }
     }
@@ -459,7 +500,8 @@ void launch_blend(const BlendBuffers& b, const BinGrid& g, float early_out_eps, 
     const int nbins = (g.bx_hi - g.bx_lo) * g.nby;
     if (nbins <= 0) return;
     hipLaunchKernelGGL(k_blend, dim3(b.grid), dim3(BLEND_THREADS), 0, s, b.items, b.seg_start, b.bin_start, b.list, b.rec,
-                       b.shcol, b.fb, b.partial, b.queue, g, early_out_eps, b.seg_len_dev, b.capacity, b.nsplats, b.bin_done, b.saturate);
+                       b.shcol, b.fb, b.partial, b.queue, g, early_out_eps, b.seg_len_dev, b.capacity, b.nsplats, b.bin_done, b.saturate,
+                       b.prio[0], b.prio[1], b.prio[2]);
     if (between) (void)hipEventRecord(between, s);
     if (b.seg_len < 0x40000000u && !b.bin_done)
         hipLaunchKernelGGL(k_combine, dim3(nbins), dim3(BLEND_THREADS), 0, s, b.seg_start, (const float4*)b.partial, b.fb, g);

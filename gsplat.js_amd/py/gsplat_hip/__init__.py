@@ -64,7 +64,7 @@ EXPORTS = [
     "gsr_framebuffer_device_ptr", "gsr_stream_handle", "gsr_stream_order", "gsr_device_info", "gsplat_sort_host",
     "gsr_overflow_pending", "gsr_set_list_capacity", "gsr_scene_count", "gsr_build_id",
     "gsr_comm_unique_id", "gsr_comm_init", "gsr_comm_destroy", "gsr_allgather_frame_async", "gsr_read_frame_rgba8",
-    "gsr_frame8_device_ptr", "gsr_comm_stream_handle",
+    "gsr_frame8_device_ptr", "gsr_comm_stream_handle", "gsr_read_work_items",
 ]
 GSR_COMM_ID_BYTES = 128
 
@@ -132,6 +132,7 @@ def load_library(path=None):
     L.gsr_read_records.argtypes = [vp, vp, vp]
     L.gsr_read_bin_totals.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
     L.gsr_convert_rgba8_async.argtypes = [vp]
+    L.gsr_read_work_items.argtypes = [vp, vp]
     L.gsr_stream_order.argtypes = [vp, vp, ctypes.c_int32]
     L.gsr_pack_band_rgba8_async.argtypes = [vp, vp, ctypes.c_int32]
     L.gsr_unpack_slabs_rgba8_async.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
@@ -491,6 +492,13 @@ class HIPRenderer:
         nbx, nby = ctypes.c_int32(0), ctypes.c_int32(0)
         self._check(self._L.gsr_read_bin_totals(self._ctx, out.ctypes.data, ctypes.byref(nbx), ctypes.byref(nby)))
         return out[:nbx.value * nby.value].reshape(nby.value, nbx.value)
+
+    def work_items(self):
+        """How the last frame's bin lists were cut for the compositor: entries per segment, work items, entries per
+        front-window segment (0: no windows), bins."""
+        out = np.zeros(4, dtype=np.uint32)
+        self._check(self._L.gsr_read_work_items(self._ctx, out.ctypes.data))
+        return {"seg_len": int(out[0]), "items": int(out[1]), "win_len": int(out[2]), "bins": int(out[3])}
 
     def set_timing_interval(self, every):
         """Record stage events only on every `every`-th frame (they cost command-processor time on short frames)."""

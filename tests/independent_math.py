@@ -103,3 +103,20 @@ def splat_image(centre, C, opacity, rgb, W, H):
         img[..., k] = B * rgb[k]
     img[..., 3] = B
     return img, np.abs(q - 4.0) < 1e-3
+
+
+def composite_under(splats, W, H):
+    """premultiplied RGBA float64 [H, W, 4] of SEVERAL splats composited front to back with the reference's blend state
+    (WebGLRenderer.ts:139-142,282-285: blendFuncSeparate(ONE_MINUS_DST_ALPHA, ONE, ONE_MINUS_DST_ALPHA, ONE), FUNC_ADD,
+    cleared to 0), i.e. per fragment in draw order   dst.rgb += (1 - dst.a) * src.rgb;  dst.a += (1 - dst.a) * src.a
+    with src = (B * rgb, B) from frag.glsl.ts:13-21.  `splats`: dicts with centre, C, opacity, rgb and z (camera-space
+    depth); the draw order is the sort's front-to-back order, stated here as ascending z (wasm.cpp:14-51 sorts by row 2 of
+    viewProj, which is z times far/(far-near): callers keep the depths well apart, so the 16-bit quantisation cannot
+    tie them).  Also returns the union of the per-splat coverage-edge masks."""
+    img = np.zeros((H, W, 4))
+    edge = np.zeros((H, W), dtype=bool)
+    for sp in sorted(splats, key=lambda s: s["z"]):
+        src, e = splat_image(sp["centre"], sp["C"], sp["opacity"], sp["rgb"], W, H)
+        img += (1.0 - img[..., 3:4]) * src
+        edge |= e
+    return img, edge

@@ -318,6 +318,25 @@ def test_offaxis_splats_match_independent_closed_form(gh, oracle):
     assert checked == 8
 
 
+def test_overlapping_splats_match_independent_f64_under_composite(gh, oracle):
+    """Multi-splat compositing against tests/independent_math.py: 3-5 overlapping off-axis anisotropic splats per image,
+    composited in float64 with the reference's "under" blend (WebGLRenderer.ts:139-142,282-285, frag.glsl.ts:13-21) in
+    ascending camera depth.  Neither oracle.c nor the kernels' operation order is in the expected image; the same cases
+    pin oracle modes 0 and 1 (tests/test_oracle_render.py)."""
+    from test_oracle_render import overlap_cases
+    cases, (W, H, fx, fy) = overlap_cases(oracle)
+    r = gh.HIPRenderer(W, H)
+    for case in cases:
+        r.set_raw_scene(case["data"], case["pos"])
+        r.set_camera_arrays(case["view"], case["proj"], case["vp"], fx, fy)
+        r.render_async(); r.sync()
+        assert list(r.lastDepthIndex()) == list(np.argsort([f["z"] for f in case["forms"]], kind="stable"))
+        err = np.abs(r.readPixelsFloat().astype(np.float64) - case["want"]).max(axis=2)
+        err[case["edge"]] = 0.0
+        assert err.max() < 1e-4, err.max()
+    r.dispose()
+
+
 def test_full_size_c3_1m_1080p(gh, oracle, scenes):
     _full_size_checks(gh, oracle, scenes, "C3", 21)
 
@@ -884,7 +903,8 @@ def test_fold_inside_the_compositor_matches_the_separate_kernel(gh, monkeypatch)
     W, H = cfg["width"], cfg["height"]
     scene = gh.Scene()
     scene.setData(gh.synth.config_rows("C3"))
-    monkeypatch.setenv("GSR_FUSE_COMBINE", "0")
+    monkeypatch.setenv("GSR_LONG_ITEMS", "0")   # 512-entry segments: up to ~50 partials per bin (long items with a front
+    monkeypatch.setenv("GSR_FUSE_COMBINE", "0")  # window exist only with the fold inside k_blend: no k_combine counterpart)
     ref = gh.HIPRenderer(W, H)
     monkeypatch.delenv("GSR_FUSE_COMBINE")
     a, b = gh.HIPRenderer(W, H), gh.HIPRenderer(W, H)
@@ -1038,6 +1058,7 @@ def test_heavy_bins_split_into_tile_items_change_no_bit(gh, monkeypatch):
     W, H = cfg["width"], cfg["height"]
     scene = gh.Scene()
     scene.setData(gh.synth.config_rows("C3"))
+    monkeypatch.setenv("GSR_WIN_FROM", "0")   # (the front window replaces this option where it applies: keep whole-bin items here)
     for eps in (0.0, 1e-4):
         monkeypatch.setenv("GSR_QUAD_FROM", "0")
         whole = gh.HIPRenderer(W, H, early_out_eps=eps)
@@ -1058,3 +1079,57 @@ def test_heavy_bins_split_into_tile_items_change_no_bit(gh, monkeypatch):
                     assert np.abs(r.readPixelsFloat() - want).max() <= 2 * eps, k
         for r in (whole, split, split_all):
             r.dispose()
+
+
+@pytest.mark.gpu
+def test_front_window_of_heavy_bins(gh, oracle, scenes, monkeypatch):
+    """In a frame with long work items a heavy bin hands out its front window as concurrent segments; the workgroup whose
+    arrival is last folds them and continues behind the window under the folded transmittance (k_bin_finalize, k_blend).
+    The cut differs from the whole-bin cut by f32 association only: images within 2e-6, RGBA8 within one step, for the
+    default window and for extreme ones (two 512-entry segments and a long tail; eight segments; every bin windowed), on
+    C3, where the policy picks long items by itself.  The saturation skip changes no bit under a windowed cut either.
+    And on small scenes with the policy pinned (C1, C2: windows of 2 x 512 entries from 600 entries on) the image stays
+    within 2e-4 of the oracle (frag.glsl.ts:13-21, WebGLRenderer.ts:139-142)."""
+    cfg = gh.synth.CONFIGS["C3"]
+    W, H = cfg["width"], cfg["height"]
+    scene = gh.Scene()
+    scene.setData(gh.synth.config_rows("C3"))
+    monkeypatch.setenv("GSR_LONG_ITEMS", "1")   # (some poses of the orbit lie under the policy's threshold: pinned for all)
+    monkeypatch.setenv("GSR_WIN_FROM", "0")
+    whole = gh.HIPRenderer(W, H)
+    monkeypatch.delenv("GSR_WIN_FROM")
+    cuts = {"default": {}, "two_short": {"GSR_WIN_FROM": "600", "GSR_WIN_LEN": "512", "GSR_WIN_SEGS": "2"},
+            "eight": {"GSR_WIN_FROM": "1024", "GSR_WIN_LEN": "512", "GSR_WIN_SEGS": "8"},
+            "two_short_noskip": {"GSR_WIN_FROM": "600", "GSR_WIN_LEN": "512", "GSR_WIN_SEGS": "2", "GSR_SATURATE": "0"}}
+    rs = {}
+    for name, env in cuts.items():
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        rs[name] = gh.HIPRenderer(W, H)
+        for k in env:
+            monkeypatch.delenv(k)
+    for k in (5, 47, 88):
+        cam = gh.orbit_camera(k, 120, W, H, cfg["fx"])
+        whole.render(scene, cam)
+        want, want8 = whole.readPixelsFloat(), whole.readPixels().astype(np.int32)
+        imgs = {}
+        for name, r in rs.items():
+            r.render(scene, cam)
+            imgs[name] = r.readPixelsFloat()
+            assert np.abs(imgs[name] - want).max() <= 2e-6, (name, k)
+            assert np.abs(r.readPixels().astype(np.int32) - want8).max() <= 1, (name, k)
+        assert np.array_equal(imgs["two_short"], imgs["two_short_noskip"]), k
+        if k == 5:   # the default window is in use on C3 (the cut is not the whole-bin one)
+            assert not np.array_equal(imgs["default"], want)
+    for r in [whole] + list(rs.values()):
+        r.dispose()
+    monkeypatch.setenv("GSR_LONG_ITEMS", "1")
+    for k, v in cuts["two_short"].items():
+        monkeypatch.setenv(k, v)
+    for name, pose in (("C1", 40), ("C2", 13)):
+        c = gh.synth.CONFIGS[name]
+        rows, data, pos = scenes(name)
+        cam = _camera(gh, pose, c)
+        img, img8, di, st, oimg, odi, V, D = _render_pair(gh, oracle, data, pos, cam, c["width"], c["height"])
+        assert np.array_equal(di, odi)
+        assert np.abs(img.astype(np.float64) - oimg.astype(np.float64)).max() <= TOL_EXACT, name

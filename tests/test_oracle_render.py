@@ -211,6 +211,87 @@ def test_offaxis_anisotropic_image_matches_closed_form(oracle, mode):
     assert checked == 8
 
 
+def _overlap_case(oracle, rng, W, H, fx, fy, count):
+    """`count` off-axis, rotated, anisotropic splats that overlap on screen, at well separated depths, under one
+    camera -> (matrices, packed scene, per-splat closed forms) or None when a splat falls outside the usable range."""
+    import independent_math as im
+    eye = rng.normal(size=3)
+    eye *= rng.uniform(5.0, 8.0) / np.linalg.norm(eye)
+    target = rng.uniform(-0.4, 0.4, size=3)
+    R = im.look_at_rotation(eye, target, rng.uniform(-np.pi, np.pi))
+    view, proj, vp = im.camera_matrices(R, eye, fx, fy, W, H)
+    fwd = R[:, 2]
+    anchor = target + R[:, 0] * rng.uniform(-0.8, 0.8) + R[:, 1] * rng.uniform(-0.6, 0.6)   # off the optical axis
+    depths = np.sort(rng.uniform(-1.5, 1.5, size=count))
+    if np.diff(depths).min() < 0.12:
+        return None
+    splats = []
+    for k in range(count):
+        p = anchor + fwd * depths[k] + R[:, 0] * rng.uniform(-0.25, 0.25) + R[:, 1] * rng.uniform(-0.25, 0.25)
+        scale = np.exp(rng.uniform(np.log(0.05), np.log(0.3), size=3))
+        scale[rng.integers(3)] *= 3.0
+        splats.append(dict(pos=p, scale=scale, rgba=tuple(int(v) for v in rng.integers(60, 256, size=4)),
+                           rot=tuple(int(v) for v in rng.integers(0, 256, size=4))))
+    order = rng.permutation(count)                       # scene order is not depth order: the sort has to do it
+    data, pos = make_scene(oracle, [splats[i] for i in order])
+    forms = []
+    for j in range(count):
+        centre, C, pc = im.footprint(pos[3 * j:3 * j + 3].astype(np.float64), im.decode_cov4(data[8 * j:8 * j + 8]), view, fx, fy, W, H)
+        case = dict(centre=centre, C=C, pc=pc)
+        if not _usable(case, W, H) or max(C[0, 0], C[1, 1]) < 6.0:
+            return None
+        rgba = [v / 255.0 for v in splats[order[j]]["rgba"]]
+        forms.append(dict(centre=centre, C=C, opacity=rgba[3], rgb=rgba[:3], z=pc[2]))
+    return dict(view=view, proj=proj, vp=vp, data=data, pos=pos, forms=forms)
+
+
+def overlap_cases(oracle, want=6, W=160, H=120, fx=260.0, fy=240.0, seed=4242):
+    """the fixed list of multi-splat cases both the oracle test (here) and the GPU test use"""
+    import independent_math as im
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(4000):
+        case = _overlap_case(oracle, rng, W, H, fx, fy, int(rng.integers(3, 6)))
+        if case is None:
+            continue
+        img, edge = im.composite_under(case["forms"], W, H)
+        # the splats must really overlap: somewhere at least three of them contribute
+        layers = sum((im.splat_image(f["centre"], f["C"], f["opacity"], f["rgb"], W, H)[0][..., 3] > 0.02).astype(int) for f in case["forms"])
+        if layers.max() < 3 or (layers >= 2).sum() < 60:
+            continue
+        case["want"], case["edge"] = img, edge
+        out.append(case)
+        if len(out) == want:
+            break
+    assert len(out) == want
+    return out, (W, H, fx, fy)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_overlapping_splats_composite_matches_independent_f64_under_blend(oracle, mode):
+    """Multi-splat pin that does not come from oracle.c: 3-5 overlapping off-axis anisotropic splats per image, scene
+    order shuffled, composited in float64 with the reference's "under" blend in ascending camera depth
+    (independent_math.composite_under: WebGLRenderer.ts:282-285, frag.glsl.ts:13-21).  oracle modes 0 and 1 must agree
+    within 1e-4 away from coverage edges; so must the HIP path (test_gpu_parity.py, same cases)."""
+    cases, (W, H, fx, fy) = overlap_cases(oracle)
+    for case in cases:
+        img, di, V, D = oracle.render_scene(case["data"], case["pos"], case["view"], case["proj"], case["vp"], fx, fy, W, H,
+                                            mode=mode, threads=2)
+        assert V == len(case["forms"])
+        # the sort's order is the stated one: ascending camera depth
+        assert list(di) == list(np.argsort([f["z"] for f in case["forms"]], kind="stable"))
+        err = np.abs(img.astype(np.float64) - case["want"]).max(axis=2)
+        err[case["edge"]] = 0.0
+        assert err.max() < 1e-4, err.max()
+        # and the order matters in these cases: back to front would be a different image
+        back = np.zeros_like(case["want"])
+        import independent_math as im
+        for f in sorted(case["forms"], key=lambda s: -s["z"]):
+            src, _ = im.splat_image(f["centre"], f["C"], f["opacity"], f["rgb"], W, H)
+            back += (1.0 - back[..., 3:4]) * src
+        assert np.abs(back - case["want"]).max() > 1e-2
+
+
 def test_rgba8_rop_mode_quantifies_the_canvas_gap(oracle, scenes):
     """oracle mode 2 re-quantises the destination to RGBA8 after every fragment, like the reference's default drawing
     buffer (WebGLRenderer.ts:38,139-142,282-285).  It is a model used to QUANTIFY how far a browser canvas is from the
