@@ -37,7 +37,7 @@ struct FrameState {  // small per-frame device words, reset by k_begin_frame (mi
     uint32_t sorted_count;  // entries of depth_index: n, or the band's survivors (SortBuffers::count)
     uint32_t seg_len;       // the frame's compositor segment length (k_bin_finalize -> k_blend)
     uint32_t n_items;       // and its number of work items (directly behind seg_len: k_blend reads both through one pointer)
-    uint32_t win_len;       // and the length of a window segment, or 0 (k_bin_finalize, "front window")
+    uint32_t spec;          // and 1 when the frame's segments are speculative (k_bin_finalize)
 };
 
 }  // namespace
@@ -75,17 +75,17 @@ struct gsr_ctx {
     // binning
     uint32_t *bin_table = nullptr, *bin_total = nullptr, *bin_start = nullptr, *bin_list = nullptr;
     uint32_t *seg_start = nullptr, *items = nullptr;
-    uint32_t* bin_done = nullptr;     // per-bin arrival counters of the compositor (null: separate k_combine launch)
+    unsigned long long* bin_mask = nullptr;   // per-bin arrival masks of the compositor (null: separate k_combine launch)
+    uint32_t* bin_sat = nullptr;              // per-bin "saturated in front of segment ..." words, with bin_mask
     int items_by_size = 1;            // work items heaviest first (k_bin_finalize); GSR_ITEMS_BY_SIZE
     uint32_t quad_from = 0;           // whole-bin items from this many entries go to four workgroups, one per tile (GSR_QUAD_FROM); 0 = off,
                                       // the default: measured slower (C3 k_blend 184 -> 203 / 215 / 238 us from 4096 / 3072 / 2048 entries)
     bool fuse_combine = true;
     bool saturate = true;             // skip quadrants that can no longer change (GSR_SATURATE=0: composite every entry)
     int long_items = -1;              // -1: long work items where the frame's optical depth says so (LONG_TAU), 0 / 1: pinned (GSR_LONG_ITEMS)
-    uint32_t win_from = 0, win_segs = 0, win_len = 0;   // front window of heavy bins (alloc_bins; GSR_WIN_FROM / GSR_WIN_SEGS / GSR_WIN_LEN)
-    uint32_t prio[3] = {0, 0, 0};                       // compositor wave priorities by queue position (alloc_bins; GSR_PRIO=a,b,c)
-    long prio_env[3] = {-1, -1, -1};
-    long win_env[3] = {-1, -1, -1};                     // those three knobs as read when the context was created (-1: not set)
+    uint32_t blend_sub = 1;           // compositor waves per 16x16 tile: 1 (k_blend) or 2 (k_blend2); alloc_bins, GSR_BLEND_SUB
+    int blend_sub_env = 0;
+    int spec = 0;                     // GSR_SPEC=1: dense frames as speculative segments (k_bin_finalize) instead of whole-bin work items
     uint32_t* bin_rects = nullptr;
     float4* partial = nullptr;
     uint32_t bin_blocks = 0, bin_capacity = 0, bin_table_elems = 0, bin_nbins_alloc = 0;
@@ -215,6 +215,9 @@ constexpr uint32_t BLEND_WG_PER_CU_EXACT = 7;
 // contexts and was best while the fold of the partials was a kernel of its own; with the fold inside k_blend 7 is
 // (bench.py, three frames in flight, C3: 3324 -> 3400 frames/s, reproducible; C2 -0.8 %, C4 and early-out unchanged).
 constexpr uint32_t BLEND_WG_PER_CU_THROUGHPUT = 7;
+// Two waves per tile (k_blend2, 512-thread workgroups): three workgroups per CU are resident (6 waves per SIMD).
+constexpr uint32_t BLEND_WG_PER_CU_SUB2 = 3;
+constexpr uint32_t SUB2_MAX_BINS = 4096, SEG_LEN_MIN_SUB2 = 1024;
 constexpr uint32_t SEG_LEN_WHOLE_BIN = 0x7fffff00u;
 
 // Sort order.  Up to BUCKET_ORDER_MAX_N splats the radix sort runs high digit first with one workgroup per bucket
@@ -243,11 +246,6 @@ constexpr uint32_t LOCAL_BUCKET_LIMIT = 48u << 10;
 constexpr uint32_t SEG_LEN_LONG = 32768;   // (16384: C4 k_blend 437 instead of 405 us -- its heaviest bins hold 50-100 k entries; 65536 measures the same)
 constexpr uint32_t LONG_TAU_EXACT = 340, LONG_TAU_THROUGHPUT = 120;
 constexpr uint32_t LONG_TILES_X2_EXACT = 9;   // one frame at a time: and at least 4.5 tiles per visible splat (k_bin_finalize)
-// Front window (k_bin_finalize): in a frame with long work items, a bin of at least WIN_FROM entries hands out its first
-// WIN_SEGS x WIN_LEN entries as concurrent segments; the workgroup that folds them continues behind the window.
-constexpr uint32_t WIN_FROM_EXACT = 0, WIN_SEGS_EXACT = 4, WIN_LEN_EXACT = 1024;
-constexpr uint32_t PRIO_FRAC_A = 0, PRIO_FRAC_B = 0, PRIO_FRAC_C = 0;   // of the compositor's grid, in 1/256 (see k_blend)
-constexpr uint32_t WIN_FROM_THROUGHPUT = 0, WIN_SEGS_THROUGHPUT = 4, WIN_LEN_THROUGHPUT = 1024;
 constexpr uint32_t LONG_TILES_X2_THROUGHPUT = 6;   // with frames in flight: 3 (scripts/policy_check.py: 2 M tiny splats, 1.9 tiles each, tau 264:
                                                    // long items -26 %; the C2 generator, 3.6 tiles each: +10 % at the same tau)
 
@@ -275,7 +273,10 @@ int alloc_bins(gsr_ctx* c)
         if (int r = dev_alloc(c, &c->bin_total, nbins)) return r;
         if (int r = dev_alloc(c, &c->bin_start, nbins + 1)) return r;
         if (int r = dev_alloc(c, &c->seg_start, nbins + 1)) return r;
-        if (c->fuse_combine) { if (int r = dev_alloc(c, &c->bin_done, nbins)) return r; }
+        if (c->fuse_combine) {
+            if (int r = dev_alloc(c, &c->bin_mask, nbins)) return r;
+            if (int r = dev_alloc(c, &c->bin_sat, nbins)) return r;
+        }
         c->bin_nbins_alloc = nbins;
         items_dirty = true;
     }
@@ -287,7 +288,17 @@ int alloc_bins(gsr_ctx* c)
     const bool throughput = (c->opt.flags & GSR_FLAG_THROUGHPUT) != 0;
     c->seg_len = c->opt.early_out_eps > 0.0f ? SEG_LEN_WHOLE_BIN : SEG_LEN_MIN;
     c->seg_target_items = throughput ? SEG_TARGET_THROUGHPUT : SEG_TARGET_EXACT;
-    c->blend_grid = (throughput ? BLEND_WG_PER_CU_THROUGHPUT : BLEND_WG_PER_CU_EXACT) * (uint32_t)std::max(c->cu_count, 1);
+    // Waves per tile.  Two (k_blend2) halve a wave's serial walk over a work item -- the pole of a frame rendered alone, where a
+    // wave needs ~560 cycles per entry visit whatever else the chip does -- and pay with occupancy (24 instead of 28 waves
+    // per CU) and saturation tests at chunk instead of 64-entry boundaries.  Measured one frame at a time: C3 k_blend 194 ->
+    // 147 us, C1 20 -> 15; C2 (short segments) 77 -> 86, with 1024-entry segments 80; C4, whose 8160 bins keep every slot
+    // busy: 412 -> 509; three frames in flight, C3: 5280 -> 4410 frames/s.  So: contexts that render one frame at a time, up
+    // to SUB2_MAX_BINS bins, with segments of at least 1024 entries.  (Leaving the choice to k_bin_finalize per frame --
+    // both kernels launched, the other one returning at once -- cost 4.5 us per frame for the idle launch.)
+    c->blend_sub = c->blend_sub_env ? (uint32_t)c->blend_sub_env : (!throughput && nbins <= SUB2_MAX_BINS) ? 2u : 1u;
+    if (c->quad_from) c->blend_sub = 1;   // (tile items give every wave one quadrant: one wave per tile only)
+    if (c->blend_sub == 2 && c->seg_len != SEG_LEN_WHOLE_BIN) c->seg_len = SEG_LEN_MIN_SUB2;
+    c->blend_grid = (c->blend_sub == 2 ? BLEND_WG_PER_CU_SUB2 : throughput ? BLEND_WG_PER_CU_THROUGHPUT : BLEND_WG_PER_CU_EXACT) * (uint32_t)std::max(c->cu_count, 1);
     if (const char* e = getenv("GSR_SEG_TARGET")) {  // tuning knob: full segments a frame is cut into at least
         const long v = atol(e);
         if (v >= 1) c->seg_target_items = (uint32_t)v;
@@ -300,24 +311,9 @@ int alloc_bins(gsr_ctx* c)
         const long v = atol(e);
         if (v >= 256 && c->seg_len != SEG_LEN_WHOLE_BIN) c->seg_len = (uint32_t)(v / 256 * 256);
     }
-    // front window of heavy bins in frames with long work items (k_bin_finalize, k_blend)
-    c->win_from = throughput ? WIN_FROM_THROUGHPUT : WIN_FROM_EXACT;
-    c->win_segs = throughput ? WIN_SEGS_THROUGHPUT : WIN_SEGS_EXACT;
-    c->win_len = throughput ? WIN_LEN_THROUGHPUT : WIN_LEN_EXACT;
-    {   // wave priorities of the compositor's heaviest work items (k_blend), by queue position
-        const uint32_t grid = c->blend_grid;
-        c->prio[0] = grid * PRIO_FRAC_A / 256u; c->prio[1] = grid * PRIO_FRAC_B / 256u; c->prio[2] = grid * PRIO_FRAC_C / 256u;
-        for (int k = 0; k < 3; k++)
-            if (c->prio_env[k] >= 0) c->prio[k] = (uint32_t)c->prio_env[k];
-    }
-    if (c->win_env[0] >= 0) c->win_from = (uint32_t)c->win_env[0];   // GSR_WIN_FROM (0: no windows), GSR_WIN_SEGS, GSR_WIN_LEN: read at gsr_create
-    if (c->win_env[1] >= 0) c->win_segs = (uint32_t)std::max(2L, c->win_env[1]);
-    if (c->win_env[2] >= 0) c->win_len = (uint32_t)(std::max(512L, c->win_env[2]) / 256 * 256);
-    if (!c->fuse_combine || c->win_segs < 2) c->win_from = 0;   // the window's tail is continued by the folding workgroup of k_blend
-    if (c->win_from) c->win_from = std::max(c->win_from, c->win_len + 1u);   // a windowed bin has at least two segments
     // segments (each may need a partial slot): one per bin plus one per seg_len entries; work items: a heavy single-segment
     // bin is handed out as four (ITEM_TILE0), so up to three more per bin
-    const uint32_t want_segs = nbins + c->bin_capacity / (c->win_from ? std::min(c->seg_len, c->win_len) : c->seg_len) + 16;
+    const uint32_t want_segs = nbins + c->bin_capacity / c->seg_len + 16;
     const uint32_t want_items = want_segs + 3u * nbins;
     if (items_dirty || want_items > c->max_items) {
         c->max_items = want_items;
@@ -373,18 +369,18 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
         if (!c->n) HIP_TRY(c, hipMemsetAsync(c->bin_total, 0, sizeof(uint32_t) * nbins, s));
         BinBuffers bb{c->depth_index, &c->fstate->sorted_count, c->bin_table, c->slots, c->rect_idx, c->bin_rects, c->bin_total, c->bin_start, c->seg_start,
                       c->items, c->bin_list, &c->fstate->overflow, &c->fstate->visible, &c->fstate->tile_entries,
-                      c->accum, c->mailbox_dev, c->fstate->report, c->bin_capacity, c->max_items, c->seg_len, &c->fstate->seg_len, c->items_by_size, &c->fstate->queue, std::min<uint32_t>(c->max_items, c->blend_grid), c->seg_target_items, c->bin_blocks, c->bin_done,
+                      c->accum, c->mailbox_dev, c->fstate->report, c->bin_capacity, c->max_items, c->seg_len, &c->fstate->seg_len, c->items_by_size, &c->fstate->queue, std::min<uint32_t>(c->max_items, c->blend_grid), c->seg_target_items, c->bin_blocks, c->bin_mask, c->bin_sat,
                       c->seg_len == SEG_LEN_WHOLE_BIN ? 0 : c->long_items >= 0 ? c->long_items : c->saturate ? -1 : 0, SEG_LEN_LONG,
                       (c->opt.flags & GSR_FLAG_THROUGHPUT) ? LONG_TAU_THROUGHPUT : LONG_TAU_EXACT,
                       (uint32_t)((g.bx_hi - g.bx_lo) * BIN_PX) * (uint32_t)c->H, c->quad_from,
                       (c->opt.flags & GSR_FLAG_THROUGHPUT) ? LONG_TILES_X2_THROUGHPUT : LONG_TILES_X2_EXACT,
-                      c->win_from, c->win_segs, c->win_len};
+                      (uint32_t)c->spec};
         launch_bin(bb, g, c->n, s);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BIN], s));
         BlendBuffers bl{c->items, c->seg_start, c->bin_start, c->bin_list, c->rec, c->bbox, c->shcol, c->fb, c->partial,
                         &c->fstate->queue, c->seg_len, &c->fstate->seg_len, std::min<uint32_t>(c->max_items, c->blend_grid), c->bin_capacity,
-                        std::max(c->n, 1u), c->bin_done, c->saturate ? 1u : 0u, {c->prio[0], c->prio[1], c->prio[2]}};
-        launch_blend(bl, g, c->opt.early_out_eps, s, (timing && !c->bin_done) ? c->ev[EV_BLEND] : nullptr);
+                        std::max(c->n, 1u), c->bin_mask, c->bin_sat, c->saturate ? 1u : 0u, c->blend_sub};
+        launch_blend(bl, g, c->opt.early_out_eps, s, (timing && !c->bin_mask) ? c->ev[EV_BLEND] : nullptr);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_COMBINE], s));
     }
     HIP_TRY(c, hipGetLastError());
@@ -409,12 +405,12 @@ static std::vector<uint64_t> chain_signature(const gsr_ctx* c)
     auto U = [&v](uint64_t x) { v.push_back(x); };
     P(c->px); P(c->py); P(c->pz); P(c->cov0); P(c->cov1); P(c->cov2); P(c->rgba); P(c->sh_r); P(c->sh_g); P(c->sh_b); P(c->shcol);
     P(c->depth); P(c->keys); P(c->keys_tmp); P(c->idx_tmp); P(c->depth_index); P(c->block_hist); P(c->fstate);
-    P(c->rec); P(c->bbox); P(c->slots); P(c->rect_idx); P(c->bin_table); P(c->bin_rects); P(c->bin_total); P(c->bin_start); P(c->seg_start); P(c->bin_done);
+    P(c->rec); P(c->bbox); P(c->slots); P(c->rect_idx); P(c->bin_table); P(c->bin_rects); P(c->bin_total); P(c->bin_start); P(c->seg_start); P(c->bin_mask); P(c->bin_sat);
     P(c->items); P(c->bin_list); P(c->partial); P(c->fb); P(c->accum); P(c->cam_dev);
     U(c->n); U((uint64_t)c->W); U((uint64_t)c->H); U((uint64_t)g.bx_lo); U((uint64_t)g.bx_hi); U(c->sort_kpb); U(c->sort_blocks);
     U(c->bin_capacity); U(c->max_items); U(c->seg_len); U(c->seg_target_items); U(c->blend_grid); U(c->bin_blocks);
     U((uint64_t)c->opt.flags); U((uint64_t)(c->opt.early_out_eps * 1e9f)); U(c->bucket_order_now ? 1u : 0u); U(c->saturate ? 1u : 0u); U((uint64_t)c->items_by_size); U(c->quad_from); U((uint64_t)(int64_t)c->long_items);
-    U(c->win_from); U(c->win_segs); U(c->win_len); U(c->prio[0]); U(c->prio[1]); U(c->prio[2]);
+    U((uint64_t)c->spec); U(c->blend_sub);
     return v;
 }
 
@@ -502,7 +498,7 @@ int finish_frame(gsr_ctx* c)
         t = a + b;
         if (render) {
             HIP_TRY(c, hipEventElapsedTime(&d, ev[EV_SORT], ev[EV_BIN]));
-            if (c->bin_done) {   // the fold of multi-segment bins runs inside k_blend: one stage, no event in between
+            if (c->bin_mask) {   // the fold of multi-segment bins runs inside k_blend: one stage, no event in between
                 HIP_TRY(c, hipEventElapsedTime(&e, ev[EV_BIN], ev[EV_COMBINE]));
             } else {
                 HIP_TRY(c, hipEventElapsedTime(&e, ev[EV_BIN], ev[EV_BLEND]));
@@ -618,14 +614,8 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
     if (const char* e = getenv("GSR_ITEMS_BY_SIZE")) c->items_by_size = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("GSR_QUAD_FROM")) c->quad_from = (uint32_t)std::max(0L, atol(e));
     if (const char* e = getenv("GSR_LONG_ITEMS")) c->long_items = atoi(e) != 0 ? 1 : 0; // pins the work-item length policy
-    if (const char* e = getenv("GSR_PRIO")) {   // "a,b,c": queue positions below which a work item runs at wave priority 3, 2, 1
-        long v[3] = {0, 0, 0};
-        if (sscanf(e, "%ld%*[,:]%ld%*[,:]%ld", &v[0], &v[1], &v[2]) >= 1)
-            for (int k = 0; k < 3; k++) c->prio_env[k] = std::max(0L, v[k]);
-    }
-    if (const char* e = getenv("GSR_WIN_FROM")) c->win_env[0] = std::max(0L, atol(e));
-    if (const char* e = getenv("GSR_WIN_SEGS")) c->win_env[1] = std::max(0L, atol(e));
-    if (const char* e = getenv("GSR_WIN_LEN")) c->win_env[2] = std::max(0L, atol(e));
+    if (const char* e = getenv("GSR_SPEC")) c->spec = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("GSR_BLEND_SUB")) c->blend_sub_env = atoi(e) == 2 ? 2 : atoi(e) == 1 ? 1 : 0;
     CREATE_TRY(hipMalloc((void**)&c->accum, 8 * sizeof(uint64_t)));
     CREATE_TRY(hipMemset(c->accum, 0, 8 * sizeof(uint64_t)));
     CREATE_TRY(hipHostMalloc((void**)&c->mailbox, 64, hipHostMallocMapped));
@@ -670,7 +660,7 @@ int gsr_destroy(gsr_ctx* c)
     dev_free(&c->depth); dev_free(&c->keys); dev_free(&c->keys_tmp); dev_free(&c->idx_tmp); dev_free(&c->depth_index);
     dev_free(&c->block_hist); dev_free(&c->rec); dev_free(&c->bbox); dev_free(&c->slots); dev_free(&c->rect_idx);
     dev_free(&c->bin_table); dev_free(&c->bin_total); dev_free(&c->bin_start); dev_free(&c->bin_list);
-    dev_free(&c->seg_start); dev_free(&c->bin_done); dev_free(&c->items); dev_free(&c->partial); dev_free(&c->bin_rects);
+    dev_free(&c->seg_start); dev_free(&c->bin_mask); dev_free(&c->bin_sat); dev_free(&c->items); dev_free(&c->partial); dev_free(&c->bin_rects);
     drop_graph(c);
     dev_free(&c->cam_dev);
     dev_free(&c->fstate); dev_free(&c->accum); dev_free(&c->fb); dev_free(&c->fb8);
@@ -1182,12 +1172,13 @@ int gsr_read_work_items(gsr_ctx* c, uint32_t* out)
     if (!c || !out) return c ? fail(c, GSR_ERR_ARG, "out is NULL") : GSR_ERR_ARG;
     if (!c->have_frame) return fail(c, GSR_ERR_ARG, "no frame has been rendered yet");
     HIP_TRY(c, hipSetDevice(c->device));
-    static_assert(offsetof(FrameState, n_items) == offsetof(FrameState, seg_len) + 4 && offsetof(FrameState, win_len) == offsetof(FrameState, seg_len) + 8,
-                  "seg_len, n_items, win_len are read through one pointer");
+    static_assert(offsetof(FrameState, n_items) == offsetof(FrameState, seg_len) + 4 && offsetof(FrameState, spec) == offsetof(FrameState, seg_len) + 8,
+                  "seg_len, n_items, spec are read through one pointer");
     HIP_TRY(c, hipMemcpyAsync(out, &c->fstate->seg_len, 12, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const BinGrid g = make_grid(c);
-    out[3] = (uint32_t)((g.bx_hi - g.bx_lo) * g.nby);
+    out[3] = c->blend_sub;
+    out[4] = (uint32_t)((g.bx_hi - g.bx_lo) * g.nby);
     return GSR_OK;
 }
 

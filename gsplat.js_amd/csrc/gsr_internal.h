@@ -175,21 +175,21 @@ struct BinBuffers {
     uint32_t max_items;
     uint32_t seg_len;            // minimum list entries per compositor work item (multiple of 256); k_bin_finalize
                                  // raises it for long lists and publishes the frame's value in *seg_len_dev
-    uint32_t* seg_len_dev;       // [0] the frame's segment length, [1] its number of work items, [2] its window segment length (or 0)
+    uint32_t* seg_len_dev;       // [0] the frame's segment length, [1] its number of work items, [2] 1 = speculative segments
     int32_t items_by_size;       // order the bins' last segments by size class (one frame at a time) or leave them in raster order
     uint32_t* queue;             // the compositor's work-item counter, set to queue_start (= its grid size) by k_bin_finalize
     uint32_t queue_start;
     uint32_t seg_target_items;   // full segments the frame should be cut into at least (long lists -> longer segments)
     uint32_t nblocks;
-    uint32_t* bin_done;          // nbins: the compositor's per-bin arrival counters, zeroed by the finalize step (may be null)
+    unsigned long long* bin_mask; // nbins: the compositor's per-bin arrival masks (one bit per segment), zeroed by the finalize step (may be null)
+    uint32_t* bin_sat;           // nbins: segments in front of which the bin is known to be saturated (0xffffffff: not known), with bin_mask
     int32_t long_policy;         // work items of at least seg_len_long entries: 1 always, 0 never, -1 where the frame's optical depth >= long_tau
     uint32_t seg_len_long, long_tau;
     uint32_t npix;               // pixels of this context's band (the optical depth is per pixel)
     uint32_t quad_from;          // single-item bins with at least this many entries become four work items, one per 16x16 tile (0: never)
     uint32_t long_tiles_x2;      // long work items also need this many 16x16 tiles per visible splat, times two (0: no such condition)
-    uint32_t win_from;           // frames with long work items: a bin of at least this many entries hands out its front window as
-    uint32_t win_segs, win_len;  // up to win_segs concurrent segments of win_len entries; the workgroup that folds them continues
-                                 // behind the window under the folded transmittance (0: whole-bin items only); needs bin_done
+    uint32_t spec;               // dense frames (long_policy): 1 = speculative segments -- the plain cut, handed out layer by layer, segments
+                                 // behind a saturated prefix skipped (needs bin_mask) --, 0 = whole-bin work items of seg_len_long entries
 };
 void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s);
 
@@ -205,14 +205,14 @@ struct BlendBuffers {
     float4* partial;            // max_items * 1024 float4: per-segment (colour, transmittance), slot = seg_start[bin] + segment
     uint32_t* queue;            // device-wide work-item counter, zero at frame start
     uint32_t seg_len;           // host's minimum; >= 0x40000000: one item per bin (early termination mode)
-    const uint32_t* seg_len_dev; // [0] the frame's segment length, [1] its number of work items, [2] window segment length or 0 (k_bin_finalize)
+    const uint32_t* seg_len_dev; // [0] the frame's segment length, [1] its number of work items, [2] 1 = speculative segments (k_bin_finalize)
     uint32_t grid;              // persistent workgroups launched
     uint32_t capacity;          // entries the list can hold
     uint32_t nsplats;
-    uint32_t* bin_done;         // nbins arrival counters, zeroed by the finalize step: the workgroup delivering a bin's last
-                                // segment folds the bin inside k_blend; null = the separate k_combine launch does it
+    unsigned long long* bin_mask; // nbins arrival masks, zeroed by the finalize step: the workgroup delivering a bin's last
+    uint32_t* bin_sat;          // segment folds the bin inside k_blend; null = the separate k_combine launch does it.  bin_sat: see BinBuffers
     uint32_t saturate;          // 1: quadrants whose pixels can no longer change are skipped (bit-identical; k_blend); 0: A/B knob
-    uint32_t prio[3];           // work items below these queue positions run at wave priority 3 / >= 2 / >= 1 (0: no priorities)
+    uint32_t sub;               // waves per 16x16 tile: 1 (k_blend, 256-thread workgroups) or 2 (k_blend2: halves a wave's serial walk)
 };
 // `between` (may be null) is recorded after k_blend and before k_combine
 void launch_blend(const BlendBuffers& b, const BinGrid& g, float early_out_eps, hipStream_t s, hipEvent_t between);

@@ -174,16 +174,18 @@ struct FinalizeArgs {
     uint64_t *visible, *tile_entries, *accum, *report;
     uint32_t* queue; uint32_t queue_start;
     uint64_t* mailbox;
-    uint32_t* bin_done;
+    unsigned long long* bin_mask; uint32_t* bin_sat;
     int long_policy; uint32_t seg_len_long, long_tau, npix;   // see BinBuffers
     uint32_t quad_from, long_tiles_x2;
-    uint32_t win_from, win_segs, win_len;   // front window of heavy bins (long work items only); see BinBuffers
+    uint32_t spec;   // dense frames: 1 = speculative segments, 0 = whole-bin work items; see BinBuffers
 };
+constexpr int FIN_LAYERS = 64;   // segments per bin at most (one bit each in the bin's arrival mask, k_blend)
+constexpr int FIN_SCRATCH_WORDS = FIN_LAYERS * 64;   // LDS words the finalize step needs from its caller: (layer, size class) counters
 
 // One workgroup of FIN_THREADS threads.  It runs as an EXTRA workgroup of k_bin_scatter (the scatter workgroups
 // compute the bin starts they need themselves), so its ~9 us no longer sit between the column scan and the scatter;
 // k_bin_finalize is the stand-alone form for frames without splats.
-__device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa)
+__device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa, uint32_t* __restrict__ scratch /* LDS, FIN_SCRATCH_WORDS */)
 {
     const uint32_t* __restrict__ bin_total = fa.bin_total;
     const int nbins = fa.nbins;
@@ -222,8 +224,19 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa)
     // 1.6 M splats: tau 394, 3.6 tiles per splat, long items 8 % slower; C3: 5.3 tiles per splat, 23 % faster)
     const bool dense = (uint64_t)ent_tot.v[1] * (16u * 256u) >= (uint64_t)fa.long_tau * 255u * (uint64_t)fa.npix &&
                        (uint64_t)ctot.v[1] * 2u >= (uint64_t)fa.long_tiles_x2 * ctot.v[0];
+    // How a dense frame is cut (gsr_api.cpp, "Work-item length"):
+    //  * speculative segments (fa.spec, needs the arrival masks): the SAME cut as a frame that does not saturate -- plain
+    //    segments of seg_len entries, every one composited from transmittance 1 -- but handed out layer by layer (every
+    //    bin's first segment, then every second one, ...; heaviest bins first inside a layer), and k_blend skips a segment
+    //    once a folded prefix of its bin is known to be saturated.  Bins that never saturate are composited by as many
+    //    workgroups as they have segments (the one-frame kernel's pole used to be single whole-bin items of 1.5-3.4 k entries
+    //    that never saturate: 195 us each), bins that do saturate cost their front segments only.
+    //  * whole-bin work items (seg_len_long; GSR_SPEC=0 or the separate k_combine launch): one item per bin, which stops
+    //    where the bin saturates.
+    const bool dense_mode = seg_len_min < 0x40000000u && (fa.long_policy > 0 || (fa.long_policy < 0 && dense));
+    const bool spec = dense_mode && fa.spec != 0u && fa.bin_mask != nullptr;
     uint32_t seg_min = seg_len_min;
-    if (seg_len_min < 0x40000000u && (fa.long_policy > 0 || (fa.long_policy < 0 && dense))) seg_min = max(seg_len_min, fa.seg_len_long);
+    if (dense_mode && !spec) seg_min = max(seg_len_min, fa.seg_len_long);
     // segment length of this frame (a multiple of 256; the whole-bin sentinel of early termination passes through)
     // long items are ordered heaviest first in every mode: the few that run long must not start late (three frames in
     // flight, C3: 4970 -> 5310 frames/s); short segments in throughput contexts stay in raster order (C2: 11 550 vs 11 250)
@@ -238,34 +251,21 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa)
     // Streams of the scan: entries, segments, full segments.
     __shared__ uint32_t s_cls[FIN_CLASSES];
     if (threadIdx.x < FIN_CLASSES) s_cls[threadIdx.x] = 0;
+    if (spec)
+        for (int k = threadIdx.x; k < FIN_SCRATCH_WORDS; k += FIN_THREADS) scratch[k] = 0;
     __syncthreads();
     // Heavy single-item bins as FOUR work items, one per 16x16 tile, each wave of the workgroup that draws one taking one
     // 8x8 quadrant (k_blend, ITEM_TILE0): meant to shorten the one-frame kernel's tail (its last workgroups hold the
     // heaviest bins), bit-identical, but measured slower at every threshold -- the bin is staged four times and a wave
     // that owns one quadrant pays the per-entry costs for a quarter of the pixels.  Off unless GSR_QUAD_FROM is set.
-    // Front window (frames with long work items, fold inside the compositor): a whole-bin item is as long as the bin's
-    // saturation depth, and the heaviest bins' items were the one-frame kernel's pole (C3: the last waves ran ONE item for
-    // ~200 us of a 181 us kernel, the slots 49 % occupied).  A bin of at least win_from entries therefore hands out its
-    // first win_segs * win_len entries as win_segs concurrent segments (each from transmittance 1, through the partials);
-    // the workgroup whose arrival is last folds them and CONTINUES behind the window with the folded (colour, transmittance)
-    // in its registers, saturation test on (k_blend).  Such a bin's "full segments" are its window segments; it has no
-    // last-segment item.  Lighter bins stay whole-bin items.
-    const bool win = fa.win_from != 0u && fa.bin_done != nullptr && seg_min > seg_len_min && seg_min < 0x40000000u;
-    const uint32_t win_from = fa.win_from, win_segs = fa.win_segs, win_len = fa.win_len;
-    // the cut of a bin of c entries: nf full (or window) segments, and whether a last-segment (or whole-bin) item of r entries follows
+    // the cut of a bin of c entries: nf full segments, and whether a last segment of r entries follows (an empty bin is one
+    // item: its pixels are cleared).  At most FIN_LAYERS segments per bin: the last one takes whatever is left.
     auto cut = [&](uint32_t c, uint32_t& nf, uint32_t& r, bool& part) {
-        if (win) {
-            const bool w = c >= win_from;
-            nf = w ? min(win_segs, (c + win_len - 1u) / win_len) : 0u;
-            r = w ? 0u : c;
-            part = !w;
-        } else {
-            nf = c / seg_len;
-            r = c - nf * seg_len;
-            part = r || !nf;
-        }
+        nf = min(c / seg_len, (uint32_t)FIN_LAYERS - 1u);
+        r = c - nf * seg_len;
+        part = r || !nf;
     };
-    const uint32_t quad_from = (fa.by_size != 0 && fa.quad_from && !win) ? fa.quad_from : 0xffffffffu;
+    const uint32_t quad_from = (fa.by_size != 0 && fa.quad_from && !spec) ? fa.quad_from : 0xffffffffu;
     UN<3> mine = {{0, 0, 0}};   // entries, segments, full segments
     UN<1> extra = {{0}};        // extra work items (3 per heavy bin)
     for (int b = b0; b < b1; b++) {
@@ -277,14 +277,27 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa)
         mine.v[2] += nf;
         const bool quad = !nf && c >= quad_from;
         extra.v[0] += quad ? 3u : 0u;
-        if (by_size && part) atomicAdd(&s_cls[partial_class(r)], quad ? 4u : 1u);
+        if (spec) {   // one counter per (layer, size class of the bin, heaviest first)
+            const int col = FIN_CLASSES - 1 - partial_class(c);
+            for (uint32_t k = 0; k < nf + (part ? 1u : 0u); k++) atomicAdd(&scratch[k * FIN_CLASSES + col], 1u);
+        } else if (by_size && part) atomicAdd(&s_cls[partial_class(r)], quad ? 4u : 1u);
     }
     UN<3> tot;
     const UN<3> ex3 = block_exclusive_scan<3>(mine, s_w, &tot);   // (its barriers also order the class counts)
     UN<1> extra_tot = {{0}};
     if (quad_from != 0xffffffffu) block_exclusive_scan<1>(extra, s_w, &extra_tot);   // (uniform)
     uint32_t ex = ex3.v[0], sx = ex3.v[1], fx = ex3.v[2];
-    if (by_size && threadIdx.x < WAVE) {   // class counts -> first item index of each class, heaviest class first
+    if (spec) {   // (layer, class) counts -> first item index of each: exclusive scan of the 4096 counters, four per thread
+        static_assert(FIN_SCRATCH_WORDS == 4 * FIN_THREADS, "four counters per thread");
+        UN<1> four = {{scratch[4 * threadIdx.x] + scratch[4 * threadIdx.x + 1] + scratch[4 * threadIdx.x + 2] + scratch[4 * threadIdx.x + 3]}}, ftot;
+        uint32_t run = block_exclusive_scan<1>(four, s_w, &ftot).v[0];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t cnt = scratch[4 * threadIdx.x + j];
+            scratch[4 * threadIdx.x + j] = run;
+            run += cnt;
+        }
+    } else if (by_size && threadIdx.x < WAVE) {   // class counts -> first item index of each class, heaviest class first
         static_assert(FIN_CLASSES == WAVE, "one class per lane");
         const uint32_t cnt = s_cls[FIN_CLASSES - 1 - threadIdx.x];
         uint32_t inc = cnt;
@@ -308,8 +321,11 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa)
         cut(c, nf, r, part);
         bin_start[b] = fits ? ex : 0u;
         seg_start[b] = fits ? sx : 0u;
-        if (fa.bin_done) fa.bin_done[b] = 0u;
-        if (fits) {
+        if (fa.bin_mask) { fa.bin_mask[b] = 0ull; fa.bin_sat[b] = 0xffffffffu; }
+        if (fits && spec) {
+            const int col = FIN_CLASSES - 1 - partial_class(c);
+            for (uint32_t k = 0; k < nf + (part ? 1u : 0u); k++) items[atomicAdd(&scratch[k * FIN_CLASSES + col], 1u)] = (uint32_t)b | (k << 16);
+        } else if (fits) {
             for (uint32_t k = 0; k < nf; k++) items[fx + k] = (uint32_t)b | (k << 16);
             if (part) {
                 if (!nf && c >= quad_from) {   // (by_size holds)
@@ -330,7 +346,7 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa)
         *queue = queue_start;  // the compositor's workgroups take items 0..grid-1 by index, later ones from here
         seg_len_out[0] = seg_len;
         seg_len_out[1] = fits ? n_items : 0u;   // the compositor's queue length
-        seg_len_out[2] = win ? win_len : 0u;    // entries per window segment of a multi-segment bin (0: plain segments of seg_len)
+        seg_len_out[2] = spec ? 1u : 0u;        // speculative segments: k_blend tests folded prefixes for saturation and skips behind them
         bin_start[nbins] = fits ? tot.v[0] : 0u;
         seg_start[nbins] = fits ? tot.v[1] : 0u;
         accum[4] = tot.v[0];  // entries this frame needs (the host sizes the regrowth from it)
@@ -353,7 +369,11 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa)
     }
 }
 
-__global__ __launch_bounds__(FIN_THREADS) void k_bin_finalize(FinalizeArgs fa) { bin_finalize_body(fa); }
+__global__ __launch_bounds__(FIN_THREADS) void k_bin_finalize(FinalizeArgs fa)
+{
+    extern __shared__ uint32_t s_fin[];   // FIN_SCRATCH_WORDS
+    bin_finalize_body(fa, s_fin);
+}
 
 // ---------------------------------------------------------------------------
 // scatter: list[...] = splat index, bins in raster order, depth order inside a bin.
@@ -417,7 +437,8 @@ __global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(8,
 {
     static_assert(FIN_THREADS == SCAT_THREADS, "the finalize step runs as a workgroup of this kernel");
     if (FUSED && blockIdx.x == gridDim.x - 1) {   // the extra workgroup: bin starts, work items and frame counters for the compositor
-        if (blockIdx.y == 0) bin_finalize_body(fa);
+        extern __shared__ uint32_t s_fin[];   // this workgroup's share of the kernel's dynamic LDS (>= FIN_SCRATCH_WORDS, launch_bin)
+        if (blockIdx.y == 0) bin_finalize_body(fa, s_fin);
         return;
     }
     const uint32_t blk = xcd_group_remap(blockIdx.x, gridDim.x - (FUSED ? 1u : 0u));   // neighbouring rank blocks on one XCD (gsr_internal.h)
@@ -575,7 +596,8 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
     const BinSlices sl = make_slices(nbxb, g.nby);
     // 8 groups of 4 steps where their table still lets two workgroups share a CU, else 4 groups of 8 steps
     const bool eight = scatter_lds_bytes(sl.w, sl.h, 8) <= SCAT_LDS_TWO_PER_CU;
-    const size_t lds = scatter_lds_bytes(sl.w, sl.h, eight ? 8 : 4);
+    // (the finalize step, when it runs as this kernel's extra workgroup, uses FIN_SCRATCH_WORDS of the dynamic LDS)
+    const size_t lds = std::max(scatter_lds_bytes(sl.w, sl.h, eight ? 8 : 4), FIN_SCRATCH_WORDS * sizeof(uint32_t));
     // dynamic LDS above the 64 KiB default needs the attribute raised (4K: 8160 bins -> 146 KiB).  Set per call:
     // the attribute belongs to the current device's copy of the kernel, and this is off the per-frame fast path
     // for the common sizes (1080p needs 64 KiB).
@@ -597,10 +619,10 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
     }
     const FinalizeArgs fa{b.bin_total, nbins, b.seg_len, b.seg_target_items, b.items_by_size, b.seg_len_dev, b.max_items, b.capacity,
                           b.slots, n ? 1u : 0u, b.bin_start, b.seg_start, b.items, b.overflow, b.visible, b.tile_entries, b.accum,
-                          b.report, b.queue, b.queue_start, b.mailbox, b.bin_done, b.long_policy, b.seg_len_long, b.long_tau, b.npix, b.quad_from, b.long_tiles_x2,
-                          b.win_from, b.win_segs, b.win_len};
+                          b.report, b.queue, b.queue_start, b.mailbox, b.bin_mask, b.bin_sat, b.long_policy, b.seg_len_long, b.long_tau, b.npix, b.quad_from, b.long_tiles_x2,
+                          b.spec};
     const bool fused = n && nbins <= 4096;   // see k_bin_scatter
-    if (!fused) hipLaunchKernelGGL(k_bin_finalize, dim3(1), dim3(FIN_THREADS), 0, s, fa);
+    if (!fused) hipLaunchKernelGGL(k_bin_finalize, dim3(1), dim3(FIN_THREADS), FIN_SCRATCH_WORDS * sizeof(uint32_t), s, fa);
     if (n) {
         const dim3 grid(b.nblocks + (fused ? 1 : 0), sl.sx * sl.sy), block(SCAT_THREADS);
 #define GSR_LAUNCH_SCATTER(G, F)                                                                                                    \

@@ -51,6 +51,9 @@ constexpr uint32_t SAT_FROM = CHUNK;   // entries of a long work item before its
 // 100 MHz, common to all XCDs), [7] entry visits, [8] items, [9] start of the last item, [10] longest item (ticks),
 // [11] its entries, [12] its entry visits, [13] its bin.  Never compiled into the shipped library.
 __device__ unsigned int g_blend_stamps[4096 * 4 * 16];
+// per bin (whole-bin work items: GSR_SPEC=0): [0] entries, [1] entries staged before the item ended (its saturation depth, or
+// all), [2..5] entry visits of the four waves, [6] the item's duration (s_memrealtime ticks, 10 ns), [7] its start tick
+__device__ unsigned int g_bin_info[16384 * 8];
 #define STAMP(v) const unsigned int v = (unsigned int)__builtin_readcyclecounter()
 #ifdef GSR_BLEND_COUNT_QUADS   // slow: counts visited quadrants, those without a covered pixel, and covered pixels
 #define GSR_COUNT_QUAD(q) { const unsigned long long cb_ = __ballot((q) <= 4.0f); a_quads++; a_empty += cb_ == 0ull; a_cov += __popcll(cb_); }
@@ -62,14 +65,20 @@ __device__ unsigned int g_blend_stamps[4096 * 4 * 16];
 #define GSR_COUNT_QUAD(q)
 #endif
 
-// 7 waves per SIMD: the kernel needs 74 VGPRs unconstrained (6 waves); capped at 72 it spills one register pair that is
-// stored once per workgroup and reloaded once per work item, and the seventh wave hides more of the LDS/barrier
-// waits (measured: k_blend -5.7 % alone; 8 waves = 64 VGPRs spills inside the loops and is no better).
 // (Fetching the next entry's record before the current entry's arithmetic -- two register sets, loop unrolled by two --
 //  was measured 24 % SLOWER at 7 and at 6 waves: the compiler's s_waitcnt placement in the rotated loop waits for the
 //  new reads as well, and the extra scalar control costs more than the hidden LDS latency; the other waves of the
 //  SIMD already cover that latency.)
-__global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_blend(const uint32_t* __restrict__ items,
+//
+// SUB = 2 ("two waves per tile", one frame at a time): the pole of the kernel is one wave's serial walk over its tile's
+// entries -- a wave ALONE on its SIMD needs ~560 cycles per entry visit (a 256-workgroup grid, one wave per SIMD: 503 us for
+// the 1.93 M visits of a C3 frame), so a bin whose tiles take 600 visits runs 160-200 us whatever else the chip does (wave
+// priorities change nothing, measured).  With 8 waves per workgroup, waves 0-3 (part 0) walk the first half of every
+// 256-entry chunk under the running transmittance and waves 4-7 (part 1) the second half from (colour 0, transmittance
+// 1); "under" is associative, so part 1's chunk partial goes through LDS and part 0 folds it at the chunk boundary
+// (C += T*C', T *= T'), where it also runs the saturation test and hands the live quadrants to part 1.
+template <int SUB>
+__device__ __forceinline__ void blend_body(const uint32_t* __restrict__ items,
                                                          const uint32_t* __restrict__ seg_start,
                                                          const uint32_t* __restrict__ bin_start,
                                                          const uint32_t* __restrict__ list,
@@ -77,8 +86,8 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
                                                          const float4* __restrict__ shcol, float4* __restrict__ fb,
                                                          float4* __restrict__ partial, uint32_t* __restrict__ queue,
                                                          BinGrid g, float eps, const uint32_t* __restrict__ seg_len_dev, uint32_t capacity,
-                                                         uint32_t nsplats, uint32_t* __restrict__ bin_done, uint32_t saturate,
-                                                         uint32_t prio_a, uint32_t prio_b, uint32_t prio_c)
+                                                         uint32_t nsplats, unsigned long long* __restrict__ bin_mask,
+                                                         uint32_t* __restrict__ bin_sat, uint32_t saturate)
 {
     const uint32_t seg_len = *seg_len_dev;  // this frame's list entries per work item (k_bin_finalize)
     // [0]: ux, uy, -dot(u, c - bin origin), wx   [1]: wy, -dot(w, c - bin origin), log2(opacity), blue   [2]: red, green
@@ -87,19 +96,21 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
     __shared__ uint32_t s_done;
     __shared__ uint32_t s_item;
     __shared__ uint32_t s_last;
+    __shared__ float s_part[SUB == 2 ? 4 * 16 * WAVE : 1];   // part 1's chunk partial: [tile][4 pixels x (r, g, b, T)][lane]
+    __shared__ uint32_t s_alive[4];                           // part 0's live quadrants of each tile, for part 1
 
     const int nbxb = g.bx_hi - g.bx_lo;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, part = SUB == 2 ? (int)(threadIdx.x >> 8) : 0;   // (tile, half of a chunk)
     const int lx = lane & 7, ly = lane >> 3;
     const uint32_t total_items = seg_len_dev[1];   // the frame's work items (k_bin_finalize; heavy bins count four)
-    const uint32_t wlen = seg_len_dev[2];          // entries per window segment of a multi-segment bin, or 0 (k_bin_finalize, "front window")
+    const bool spec = seg_len_dev[2] != 0u;        // the frame's segments are speculative (k_bin_finalize): prefix tests and skips below
 
     // Work items come from one device-wide queue (items are ordered heaviest first), so a workgroup
     // that drew light items simply draws more: no static assignment, no long pole.
     // The first item of a workgroup is its own index (the queue starts at gridDim.x, k_bin_finalize sets it): a
     // kernel start with ~2000 workgroups drawing from one counter serialises ~2000 same-address atomics.
 #ifdef GSR_BLEND_STAMPS
-    unsigned int a_waitA = 0, a_stage = 0, a_waitB = 0, a_comp = 0, a_entries = 0;
+    unsigned int a_waitA = 0, a_stage = 0, a_waitB = 0, a_comp = 0, a_entries = 0, a_staged = 0;
     unsigned int a_quads = 0, a_empty = 0, a_cov = 0;
     unsigned int a_items = 0, a_last_start = 0, a_max_dur = 0, a_max_len = 0, a_max_vis = 0, a_max_bin = 0, a_item_t0 = 0, a_item_vis0 = 0, a_item_len = 0, a_item_bin = 0;
     const unsigned int t_kernel0 = (unsigned int)__builtin_readcyclecounter();
@@ -118,19 +129,8 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
         if (qi >= total_items) break;
         const uint32_t it = items[qi];
         const int bin = (int)(it & 0xffffu);
-        // Wave priority by the item's place in the queue (items are ordered heaviest first): the longest items are the
-        // kernel's pole when seven waves share a SIMD and every one of them gets a seventh of its issue slots -- the
-        // waves of the first prio_a items issue ahead of the others on their SIMDs, then those below prio_b, prio_c
-        // (longest job first; the lighter items fill the slots the heavy ones leave while they wait on LDS or barriers).
-        {
-            const int pr = (qi < prio_a ? 1 : 0) + (qi < prio_b ? 1 : 0) + (qi < prio_c ? 1 : 0);
-            if (pr == 3) __builtin_amdgcn_s_setprio(3);
-            else if (pr == 2) __builtin_amdgcn_s_setprio(2);
-            else if (pr == 1) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-        }
 #ifdef GSR_BLEND_STAMPS
-        a_items++; a_item_t0 = (unsigned int)__builtin_amdgcn_s_memrealtime(); a_last_start = a_item_t0; a_item_vis0 = a_entries; a_item_bin = (unsigned int)bin;
+        a_items++; a_item_t0 = (unsigned int)__builtin_amdgcn_s_memrealtime(); a_last_start = a_item_t0; a_item_vis0 = a_entries; a_item_bin = (unsigned int)bin; a_staged = 0;
 #endif
         // A tile item (ITEM_TILE0 + t: a heavy single-segment bin, handed out as four items): this workgroup composites
         // tile t alone and every wave takes ONE of its 8x8 quadrants -- one pixel per lane, the (.)00 accumulators --
@@ -156,18 +156,12 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
         float g00 = 0.f, g10 = 0.f, g01 = 0.f, g11 = 0.f;
         float b00 = 0.f, b10 = 0.f, b01 = 0.f, b11 = 0.f;
 
-        // A bin with a front window (k_bin_finalize): its nseg items are the window's segments of wlen entries, and the
-        // entries behind the window belong to whichever workgroup folds the window (below).
-        const bool windowed = wlen != 0u && nseg > 1u;
-        const uint32_t step = windowed ? wlen : seg_len;
-        const uint32_t bin_begin = bin_start[bin];
         const uint32_t bin_end = min(bin_start[bin + 1], capacity);
-        uint32_t begin = min(bin_begin + seg * step, bin_end);
-        uint32_t end = min(begin + step, bin_end);
-        const uint32_t tail_begin = windowed ? min(bin_begin + nseg * wlen, bin_end) : bin_end;
-        // only long items test for saturation (a window segment starts from transmittance 1 like any segment: it cannot)
-        bool sat_item = saturate != 0u && !windowed && end - begin > 2u * CHUNK;
-        uint32_t sat_from = SAT_FROM;
+        const uint32_t begin = min(bin_start[bin] + seg * seg_len, bin_end);
+        const uint32_t end = seg + 1u == nseg ? bin_end : min(begin + seg_len, bin_end);   // (a bin has at most 64 segments: the last takes the rest)
+        // only long items test for saturation while they run, and only where the transmittance is the true one: whole bins
+        // and a bin's first segment (later segments start from 1 and find out through the folded prefixes, below)
+        const bool sat_item = saturate != 0u && seg == 0u && end - begin > 2u * CHUNK;
         // quadrants of mine that can still change (wave-uniform); see the saturation test below.  Quadrants that lie outside
         // the image (the last bin row of 1080p: rows 1080..1087) never could: their pixels are not stored.
         uint32_t alive0 = 0;
@@ -177,24 +171,87 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
         alive0 &= mask_sel;
         uint32_t alive = alive0;
         bool done = alive0 == 0u;
-        if (done && lane == 0) atomicAdd(&s_done, 1u);
-        bool final_pass = false, write_fb = false;
+        if (done && lane == 0 && part == 0) atomicAdd(&s_done, 1u);
+        if (SUB == 2 && part == 0 && lane == 0) s_alive[wave] = alive0;   // (read by part 1 behind the first chunk's two barriers)
 #ifdef GSR_BLEND_STAMPS
         a_item_len = end - begin;
 #endif
+        // Speculative segments: a segment at or behind a prefix of its bin that is known to be saturated (bin_sat, set by
+        // the workgroup whose arrival completed that prefix) cannot change a bit of the image: it is not composited, it only
+        // counts its arrival.  The decision must be the same in all four waves: one lane reads the word (an atomic, so the
+        // value comes from memory and not from a stale line of this XCD's L2), the others take it from LDS.
+        bool skipped = false;
+        if (spec && seg > 0u) {
+            if (threadIdx.x == 0) s_last = __hip_atomic_fetch_min(&bin_sat[bin], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= seg ? 1u : 0u;
+            __syncthreads();
+            skipped = s_last != 0u;
+        }
 
-        for (;;) {   // pass 1: the item's own entries; pass 2, only in the workgroup that folds a window: the entries behind it
-        for (uint32_t base = begin; base < end; base += CHUNK) {
+        // fold part 1's chunk partial (LDS) behind part 0's state: C += T*C', T *= T'
+#define GSR_FOLD_PART()                                                                                                  \
+    {                                                                                                                    \
+        const float* sp_ = s_part + wave * (16 * WAVE) + lane;                                                           \
+        r00 = __builtin_fmaf(T00, sp_[0 * WAVE], r00); g00 = __builtin_fmaf(T00, sp_[1 * WAVE], g00); b00 = __builtin_fmaf(T00, sp_[2 * WAVE], b00); T00 = T00 * sp_[3 * WAVE];       \
+        r10 = __builtin_fmaf(T10, sp_[4 * WAVE], r10); g10 = __builtin_fmaf(T10, sp_[5 * WAVE], g10); b10 = __builtin_fmaf(T10, sp_[6 * WAVE], b10); T10 = T10 * sp_[7 * WAVE];       \
+        r01 = __builtin_fmaf(T01, sp_[8 * WAVE], r01); g01 = __builtin_fmaf(T01, sp_[9 * WAVE], g01); b01 = __builtin_fmaf(T01, sp_[10 * WAVE], b01); T01 = T01 * sp_[11 * WAVE];    \
+        r11 = __builtin_fmaf(T11, sp_[12 * WAVE], r11); g11 = __builtin_fmaf(T11, sp_[13 * WAVE], g11); b11 = __builtin_fmaf(T11, sp_[14 * WAVE], b11); T11 = T11 * sp_[15 * WAVE];  \
+    }
+        // ---- saturation that changes no bit ----
+        // A pixel whose transmittance is below 2^-27 of its smallest colour channel is finished: every later
+        // weight is w <= T (opacity <= 1, exp <= 1), colours are <= 1, so w*c is under half an ulp of each channel
+        // and fma(w, c, C) returns C; its alpha is 1 - T = 1.0f for any T that small.  The segment's own T
+        // would still shrink, but only ever multiplies later segments' colours (the fold), whose terms are then
+        // under half an ulp of the folded colour as well: the image is bit-identical to compositing every entry
+        // (test_saturated_quadrants_are_skipped_without_changing_a_bit).  A quadrant whose 64 pixels are all
+        // finished drops out of `alive`; a tile with no live quadrant is done, a bin with no live tile ends its
+        // work item (s_done).  Pixels with a zero channel finish only at T == 0.
+#define GSR_FINISHED(BIT, T, R, G, B_)                                                                          \
+    if ((alive & (BIT)) && __ballot((T) >= NEAR) == 0ull &&                                                      \
+        __ballot(!((T) < K * fminf((R), fminf((G), (B_))) || (T) == 0.0f)) == 0ull)                              \
+        alive &= ~(BIT);
+#define GSR_SAT_TEST()                                                                                           \
+    {                                                                                                            \
+        constexpr float K = 0x1p-27f, NEAR = 1e-6f;   /* nothing above NEAR can pass the test: a cheap filter first */ \
+        GSR_FINISHED(1u, T00, r00, g00, b00)                                                                     \
+        GSR_FINISHED(2u, T10, r10, g10, b10)                                                                     \
+        GSR_FINISHED(4u, T01, r01, g01, b01)                                                                     \
+        GSR_FINISHED(8u, T11, r11, g11, b11)                                                                     \
+    }
+        bool pending = false;   // SUB == 2: part 1's partial of the last composited chunk is in LDS, not folded yet (uniform)
+        for (uint32_t base = begin; base < end && !skipped; base += CHUNK) {
             STAMP(t_c0);
             __syncthreads();  // previous chunk fully consumed (and s_done visible)
             STAMP(t_cA);
-            if (s_done == BLEND_THREADS / WAVE) break;  // every tile of the bin is saturated
+            if (SUB == 2 && pending) {
+                // part 0: the chunk just composited ends with part 1's half; then the tests that need the true state
+                if (part == 0 && !done) {
+                    GSR_FOLD_PART()
+                    if (eps > 0.0f) {
+                        const float tmax = fmaxf(fmaxf(T00, T10), fmaxf(T01, T11));
+                        if (__ballot(tmax >= eps) == 0ull) alive = 0u;
+                    }
+                    if (sat_item && base - begin >= SAT_FROM) GSR_SAT_TEST()
+                    if (alive == 0u) {
+                        done = true;
+                        if (lane == 0) atomicAdd(&s_done, 1u);
+                    }
+                    if (lane == 0) s_alive[wave] = alive;
+                }
+                pending = false;
+            }
+            if (SUB == 1 && s_done == 4u) break;  // every tile of the bin is saturated
+#ifdef GSR_BLEND_STAMPS
+            a_staged = min(base + CHUNK, end) - begin;
+#endif
             // ---- stage one entry per thread: record, unpacked colour, and a 16-bit mask of the bin's
             //      8x8-pixel quadrants the splat can touch (bit = tile*4 + quadrant).  The mask is a
             //      conservative cull only: a quadrant is dropped when it lies outside the oriented box
             //      |vPosition.x|,|vPosition.y| <= 2 (separating axes u, w) or farther from the centre than the
             //      longer semi-axis.  Pixels that pass are still tested exactly (q <= 4) below. ----
-            const uint32_t e = base + threadIdx.x;
+            // (two waves per tile: two threads per entry, thread t and t + 256, each testing two of the four quadrant rows
+            //  -- one byte of the mask -- and writing its share of the record)
+            const uint32_t slot = threadIdx.x & (CHUNK - 1), half = SUB == 2 ? threadIdx.x >> 8 : 0u;
+            const uint32_t e = base + slot;
             uint32_t mask = 0;
             if (e < end) {
                 const uint32_t i = min(list[e], nsplats - 1u);
@@ -212,7 +269,9 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
                     dcol[k] = dd * dd;
                 }
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
+                for (int rr = 0; rr < 4 / SUB; rr++) {
+                    // quadrant row r of the bin: all four (one wave per tile), or rows 2*half, 2*half + 1 (two threads per entry)
+                    const int r = SUB == 2 ? (int)(2u * half) + rr : rr;
                     const float dc = (float)(binY0 + 8 * r + 4) - ra.y;
                     const float ur = ra.w * dc, wr = rb.y * dc;
                     const float dd = fmaxf(fabsf(dc) - 3.5f, 0.0f);
@@ -220,33 +279,62 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const bool hit = fabsf(ucol[k] + ur) <= eu && fabsf(wcol[k] + wr) <= ew && (dcol[k] + d2) * minlen2 <= 4.002f;
-                        // quadrant (k, r) of the bin -> tile (k>>1, r>>1), quadrant (k&1, r&1)
-                        if (hit) mask |= 1u << ((((r >> 1) * 2 + (k >> 1)) << 2) + ((r & 1) * 2 + (k & 1)));
+                        // quadrant (k, r) of the bin -> tile (k>>1, r>>1), quadrant (k&1, r&1): bit tile*4 + quadrant (SUB == 2: of
+                        // this thread's byte, which holds the tile row r>>1 = half)
+                        if (hit) mask |= 1u << (((((SUB == 2 ? 0 : rr >> 1) * 2) + (k >> 1)) << 2) + ((rr & 1) * 2 + (k & 1)));
                     }
                 }
-                const uint32_t rgb8 = __float_as_uint(rb.w);
-                float cr = (float)(rgb8 & 0xffu) * (1.0f / 255.0f), cg = (float)((rgb8 >> 8) & 0xffu) * (1.0f / 255.0f),
-                      cb = (float)((rgb8 >> 16) & 0xffu) * (1.0f / 255.0f);
-                if (rgb8 & RGB8_IN_SHCOL) {  // SH-coloured splat: the projection kernel evaluated its colour for this view
-                    const float4 sc = shcol[i];
-                    cr = sc.x; cg = sc.y; cb = sc.z;
-                }
                 const float cxr = ra.x - bx0c, cyr = ra.y - by0c;
-                const float ncu = -__builtin_fmaf(ra.w, cyr, ra.z * cxr), ncw = -__builtin_fmaf(rb.y, cyr, rb.x * cxr);
-                s_rec[0][threadIdx.x] = make_float4(ra.z, ra.w, ncu, rb.x);
-                s_rec[1][threadIdx.x] = make_float4(rb.y, ncw, rb.z, cb);
-                *reinterpret_cast<float2*>(&s_rec[2][threadIdx.x]) = make_float2(cr, cg);
+                if (half == 0u) {
+                    const uint32_t rgb8 = __float_as_uint(rb.w);
+                    float cr = (float)(rgb8 & 0xffu) * (1.0f / 255.0f), cg = (float)((rgb8 >> 8) & 0xffu) * (1.0f / 255.0f),
+                          cb = (float)((rgb8 >> 16) & 0xffu) * (1.0f / 255.0f);
+                    if (rgb8 & RGB8_IN_SHCOL) {  // SH-coloured splat: the projection kernel evaluated its colour for this view
+                        const float4 sc = shcol[i];
+                        cr = sc.x; cg = sc.y; cb = sc.z;
+                    }
+                    const float ncw = -__builtin_fmaf(rb.y, cyr, rb.x * cxr);
+                    s_rec[1][slot] = make_float4(rb.y, ncw, rb.z, cb);
+                    *reinterpret_cast<float2*>(&s_rec[2][slot]) = make_float2(cr, cg);
+                }
+                if (SUB == 1 || half == 1u) {
+                    const float ncu = -__builtin_fmaf(ra.w, cyr, ra.z * cxr);
+                    s_rec[0][slot] = make_float4(ra.z, ra.w, ncu, rb.x);
+                }
             }
-            s_mask[threadIdx.x] = mask;
+            if (SUB == 2) reinterpret_cast<uint8_t*>(s_mask)[slot * 4u + half] = (uint8_t)mask;   // (bytes 2, 3 are never read)
+            else s_mask[slot] = mask;
             STAMP(t_cS);
             __syncthreads();
             STAMP(t_cB);
+            if (SUB == 2) {
+                if (s_done == 4u) break;   // every tile of the bin is saturated (the chunk just staged is not needed)
+                if (part == 1) alive = s_alive[wave];
+            }
 
             if (!done) {
                 const uint32_t cnt = min((uint32_t)CHUNK, end - base);
+                // two waves per tile: part 0 takes the first half of the chunk's entries that touch the tile, part 1 the second
+                // half -- by count, so that the two waves walk about equally long, and by the entries' masks ALONE: were the
+                // live quadrants taken into account, the cut -- and with it the f32 association of pixels that are still live
+                // -- would depend on what the saturation skip has dropped, which must not change a bit
+                uint32_t hits_half = 0, hits_before = 0;
+                if (SUB == 2) {
+                    uint32_t h = 0;
+#pragma unroll
+                    for (uint32_t c0 = 0; c0 < CHUNK; c0 += WAVE) h += (uint32_t)__popcll(__ballot(((s_mask[c0 + lane] >> mask_shift) & alive0) != 0u));
+                    hits_half = (h + 1u) >> 1;
+                }
                 for (uint32_t c0 = 0; c0 < cnt; c0 += WAVE) {
-                    const uint32_t mine = (s_mask[c0 + lane] >> mask_shift) & alive;  // entry (c0+lane) vs my live quadrants
+                    const uint32_t touch = (s_mask[c0 + lane] >> mask_shift) & alive0;
+                    const uint32_t mine = touch & alive;  // entry (c0+lane) vs my live quadrants
                     uint64_t bal = __ballot(mine != 0u);
+                    if (SUB == 2) {
+                        const uint64_t all = __ballot(touch != 0u);
+                        const uint32_t rank = hits_before + __builtin_amdgcn_mbcnt_hi((uint32_t)(all >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)all, 0u));
+                        hits_before += (uint32_t)__popcll(all);
+                        bal = __ballot(mine != 0u && (rank < hits_half) == (part == 0));
+                    }
 #ifdef GSR_BLEND_STAMPS
                     a_entries += __popcll(bal);
 #endif
@@ -297,7 +385,7 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
 #undef GSR_FETCH
 #undef GSR_ENTRY
 #undef GSR_QUAD
-                    if (eps > 0.0f) {
+                    if (SUB == 1 && eps > 0.0f) {
                         const float tmax = fmaxf(fmaxf(T00, T10), fmaxf(T01, T11));
                         if (__ballot(tmax >= eps) == 0ull) {
                             done = true;
@@ -305,28 +393,11 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
                             break;
                         }
                     }
-                    // ---- saturation that changes no bit (after every 64 entries of a long item) ----
-                    // A pixel whose transmittance is below 2^-27 of its smallest colour channel is finished: every later
-                    // weight is w <= T (opacity <= 1, exp <= 1), colours are <= 1, so w*c is under half an ulp of each channel
-                    // and fma(w, c, C) returns C; its alpha is 1 - T = 1.0f for any T that small.  The segment's own T
-                    // would still shrink, but only ever multiplies later segments' colours (the fold), whose terms are then
-                    // under half an ulp of the folded colour as well: the image is bit-identical to compositing every entry
-                    // (test_saturated_quadrants_are_skipped_without_changing_a_bit).  A quadrant whose 64 pixels are all
-                    // finished drops out of `alive`; a tile with no live quadrant is done, a bin with no live tile ends its
-                    // work item (s_done).  Pixels with a zero channel finish only at T == 0.
-                    // (Items of up to two chunks -- all a frame that does not saturate has -- never run the test, which
-                    //  cost 3 % on C2, and nothing saturates within an item's first SAT_FROM entries.)
-                    if (sat_item && base - begin + c0 >= sat_from) {
-                        constexpr float K = 0x1p-27f, NEAR = 1e-6f;   // nothing above NEAR can pass the test: a cheap filter first
-#define GSR_FINISHED(BIT, T, R, G, B_)                                                                          \
-    if ((alive & (BIT)) && __ballot((T) >= NEAR) == 0ull &&                                                      \
-        __ballot(!((T) < K * fminf((R), fminf((G), (B_))) || (T) == 0.0f)) == 0ull)                              \
-        alive &= ~(BIT);
-                        GSR_FINISHED(1u, T00, r00, g00, b00)
-                        GSR_FINISHED(2u, T10, r10, g10, b10)
-                        GSR_FINISHED(4u, T01, r01, g01, b01)
-                        GSR_FINISHED(8u, T11, r11, g11, b11)
-#undef GSR_FINISHED
+                    // (one wave per tile: after every 64 entries of a long item.  Items of up to two chunks -- all a frame
+                    //  that does not saturate has -- never run the test, which cost 3 % on C2, and nothing saturates within
+                    //  an item's first SAT_FROM entries.  Two waves per tile: at the chunk boundaries, above.)
+                    if (SUB == 1 && sat_item && base - begin + c0 >= SAT_FROM) {
+                        GSR_SAT_TEST()
                         if (alive == 0u) {
                             done = true;
                             if (lane == 0) atomicAdd(&s_done, 1u);
@@ -334,6 +405,18 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
                         }
                     }
                 }
+            }
+            if (SUB == 2) {
+                if (part == 1) {   // my half of the chunk, from (0, 1): to LDS for part 0, and start over
+                    float* sp = s_part + wave * (16 * WAVE) + lane;
+                    sp[0 * WAVE] = r00; sp[1 * WAVE] = g00; sp[2 * WAVE] = b00; sp[3 * WAVE] = T00;
+                    sp[4 * WAVE] = r10; sp[5 * WAVE] = g10; sp[6 * WAVE] = b10; sp[7 * WAVE] = T10;
+                    sp[8 * WAVE] = r01; sp[9 * WAVE] = g01; sp[10 * WAVE] = b01; sp[11 * WAVE] = T01;
+                    sp[12 * WAVE] = r11; sp[13 * WAVE] = g11; sp[14 * WAVE] = b11; sp[15 * WAVE] = T11;
+                    r00 = r10 = r01 = r11 = 0.f; g00 = g10 = g01 = g11 = 0.f; b00 = b10 = b01 = b11 = 0.f;
+                    T00 = T10 = T01 = T11 = 1.f;
+                }
+                pending = true;
             }
 #ifdef GSR_BLEND_STAMPS
             {
@@ -343,17 +426,37 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
 #endif
         }
 
-        if (nseg == 1u || final_pass) { write_fb = true; break; }
+        if (SUB == 2) {
+            __syncthreads();
+            if (pending && part == 0 && !done) GSR_FOLD_PART()
+        }
+#undef GSR_SAT_TEST
+#undef GSR_FINISHED
+#undef GSR_FOLD_PART
+#ifdef GSR_BLEND_STAMPS
         {
+            const unsigned int d = (unsigned int)__builtin_amdgcn_s_memrealtime() - a_item_t0;
+            if (d > a_max_dur) { a_max_dur = d; a_max_len = a_item_len; a_max_vis = a_entries - a_item_vis0; a_max_bin = a_item_bin; }
+            if (nseg == 1u && bin < 16384 && lane == 0 && part == 0) {
+                unsigned int* bi = g_bin_info + (size_t)bin * 8;
+                bi[2 + wave] = a_entries - a_item_vis0;
+                if (wave == 0) { bi[0] = end - begin; bi[1] = a_staged; bi[6] = d; bi[7] = a_item_t0; }
+            }
+        }
+#endif
+        bool write_fb = nseg == 1u;
+        if (nseg > 1u) {
             // ---- partial (colour, transmittance) of this segment, slot-major: fully coalesced ----
             float4* p0 = partial + (size_t)seg_start[bin] * BIN_PIXELS + wave * (TILE * TILE) + lane;
             float4* p = p0 + (size_t)seg * BIN_PIXELS;
-            if (!bin_done) {   // k_combine folds the bin after this kernel
-                p[0] = make_float4(r00, g00, b00, T00);
-                p[64] = make_float4(r10, g10, b10, T10);
-                p[128] = make_float4(r01, g01, b01, T01);
-                p[192] = make_float4(r11, g11, b11, T11);
-                break;
+            if (!bin_mask) {   // k_combine folds the bin after this kernel
+                if (part == 0) {
+                    p[0] = make_float4(r00, g00, b00, T00);
+                    p[64] = make_float4(r10, g10, b10, T10);
+                    p[128] = make_float4(r01, g01, b01, T01);
+                    p[192] = make_float4(r11, g11, b11, T11);
+                }
+                continue;
             }
             // The workgroup that delivers a bin's LAST segment folds the bin itself (front to back, k_combine's fixed
             // order: which workgroup does it changes nothing in the result), so the fold runs beside the other
@@ -363,10 +466,11 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
             // slower.  Instead the partials are the only data exchanged and they move with agent-scope accesses on
             // both sides (sc1: the stores write through, the loads bypass the CU's L1): every storing wave drains its
             // stores (vmcnt 0), the workgroup's barrier, then ONE lane counts the arrival with an agent-scope atomic
-            // add; the workgroup whose add came last takes one agent-scope acquire and loads behind a barrier
+            // (its segment's bit in the bin's mask); the workgroup whose arrival completes the mask -- or, with speculative
+            // segments, a prefix of it -- takes one agent-scope acquire and loads behind a barrier
             // (MI355X_MICROARCH.md, Workgroup dispatch ... inter-workgroup visibility, Valid forms).
             typedef float v4f __attribute__((ext_vector_type(4)));
-            {
+            if (!skipped && part == 0) {   // (the state is part 0's: part 1's halves have been folded into it)
                 const v4f o0 = {r00, g00, b00, T00}, o1 = {r10, g10, b10, T10}, o2 = {r01, g01, b01, T01}, o3 = {r11, g11, b11, T11};
                 asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:1024 sc1\n\t"
                              "global_store_dwordx4 %0, %3, off offset:2048 sc1\n\tglobal_store_dwordx4 %0, %4, off offset:3072 sc1\n\t"
@@ -374,25 +478,46 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
                              :: "v"(p), "v"(o0), "v"(o1), "v"(o2), "v"(o3) : "memory");
             }
             __syncthreads();
+            // What this arrival completes (one lane decides, s_last carries it): FOLD_FINAL | n = the whole bin: fold its first n
+            // segments and write the pixels; n alone = a prefix of n segments (a power of two): fold it and test whether the
+            // bin is saturated there; 0 = nothing.
+            constexpr uint32_t FOLD_FINAL = 0x80000000u;
             if (threadIdx.x == 0) {
-                const bool last = __hip_atomic_fetch_add(&bin_done[bin], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nseg - 1u;
-                if (last) {
+                const unsigned long long bit = 1ull << seg, all = nseg >= 64u ? ~0ull : (1ull << nseg) - 1ull;
+                const unsigned long long now = __hip_atomic_fetch_or(&bin_mask[bin], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | bit;
+                uint32_t role = 0;
+                if (now == all) {
+                    // segments behind a saturated prefix may have been skipped (their partials are stale): fold the prefix
+                    // only -- the same bits as folding everything, had everything been composited (the saturation skip's
+                    // argument, above: every later term is under half an ulp of the folded colour).  The word is read
+                    // with an atomic: a skipped segment saw a value <= its index, and this read must not see an older one.
+                    const uint32_t sat = spec ? __hip_atomic_fetch_min(&bin_sat[bin], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+                    role = FOLD_FINAL | min(nseg, sat);
+                } else if (spec && saturate != 0u) {
+                    // the largest prefix of 2^j segments that this arrival completed (bit `seg` was its last missing one)
+                    for (uint32_t b = 32u; b > seg; b >>= 1)
+                        if (b < nseg && (now & ((1ull << b) - 1ull)) == (1ull << b) - 1ull) { role = b; break; }
+                    if (role && __hip_atomic_fetch_min(&bin_sat[bin], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= role) role = 0;   // known already
+                }
+                if (role) {
                     // one agent-scope acquire on the folding CU (buffer_inv sc1: drops this CU's L1, about 1.7 us, once
-                    // per multi-segment bin) in front of the barrier the other waves load behind.  The loads below are
+                    // per fold) in front of the barrier the other waves load behind.  The loads below are
                     // sc1 and bypass the L1 by themselves; the acquire makes the hand-off the documented form
                     // (MI355X_MICROARCH.md, Valid forms) rather than one that rests on that alone.
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    s_done = 0;   // (a second pass starts with every tile live again)
+                    s_done = 0;   // (counts the tiles that pass the prefix test below)
                 }
-                s_last = last ? 1u : 0u;
+                s_last = role;
             }
             __syncthreads();
-            if (!s_last) break;
+            const uint32_t role = s_last;
+            if (!role) continue;
+            const uint32_t nfold = role & ~FOLD_FINAL;
             // fold, front to back, into the accumulators: C = C0 + T0*C1 + T0*T1*C2 + ..., T = T0*T1*...
             r00 = r10 = r01 = r11 = 0.f; g00 = g10 = g01 = g11 = 0.f; b00 = b10 = b01 = b11 = 0.f;
             T00 = T10 = T01 = T11 = 1.f;
-            for (uint32_t k = 0; k < nseg; k++) {
+            for (uint32_t k = 0; k < (part == 0 ? nfold : 0u); k++) {
                 v4f v0, v1, v2, v3;
                 asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
                              "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:3072 sc1\n\t"
@@ -403,26 +528,24 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
                 r01 = __builtin_fmaf(T01, v2.x, r01); g01 = __builtin_fmaf(T01, v2.y, g01); b01 = __builtin_fmaf(T01, v2.z, b01); T01 = T01 * v2.w;
                 r11 = __builtin_fmaf(T11, v3.x, r11); g11 = __builtin_fmaf(T11, v3.y, g11); b11 = __builtin_fmaf(T11, v3.z, b11); T11 = T11 * v3.w;
             }
-            if (tail_begin >= bin_end) { write_fb = true; break; }
-            // ---- behind the window: this workgroup goes on with the bin's remaining entries under the folded
-            //      transmittance, so the saturation test sees the true state of every pixel (from the first 64 entries on:
-            //      a window that already saturated the bin costs one staged chunk) ----
-            begin = tail_begin; end = bin_end;
-            final_pass = true;
-            sat_item = saturate != 0u;
-            sat_from = 0u;
-            alive = alive0;
-            done = alive0 == 0u;
-            if (done && lane == 0) atomicAdd(&s_done, 1u);
+            if (role & FOLD_FINAL) write_fb = true;
+            else {
+                // ---- prefix test: is every pixel of the bin finished after these nfold segments?  (The criterion of the
+                //      saturation skip: transmittance under 2^-27 of the smallest colour channel, or zero.)  Then no segment
+                //      from nfold on can change a bit: publish it; later segments skip, the final fold stops here. ----
+                constexpr float K = 0x1p-27f;
+                bool fin = true;
+                if (alive0 & 1u) fin = fin && __ballot(!(T00 < K * fminf(r00, fminf(g00, b00)) || T00 == 0.0f)) == 0ull;
+                if (alive0 & 2u) fin = fin && __ballot(!(T10 < K * fminf(r10, fminf(g10, b10)) || T10 == 0.0f)) == 0ull;
+                if (alive0 & 4u) fin = fin && __ballot(!(T01 < K * fminf(r01, fminf(g01, b01)) || T01 == 0.0f)) == 0ull;
+                if (alive0 & 8u) fin = fin && __ballot(!(T11 < K * fminf(r11, fminf(g11, b11)) || T11 == 0.0f)) == 0ull;
+                if (fin && lane == 0 && part == 0) atomicAdd(&s_done, 1u);
+                __syncthreads();
+                if (threadIdx.x == 0 && s_done == 4u)
+                    (void)__hip_atomic_fetch_min(&bin_sat[bin], nfold, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
-        }   // passes
-#ifdef GSR_BLEND_STAMPS
-        {
-            const unsigned int d = (unsigned int)__builtin_amdgcn_s_memrealtime() - a_item_t0;
-            if (d > a_max_dur) { a_max_dur = d; a_max_len = a_item_len + (final_pass ? end - begin : 0u); a_max_vis = a_entries - a_item_vis0; a_max_bin = a_item_bin; }
-        }
-#endif
-        if (write_fb) {
+        if (write_fb && part == 0) {
             // ---- write the tile, premultiplied RGBA, alpha = 1 - T ----
             const int x0 = X0 + lx, x1 = x0 + 8, y0 = Y0 + ly, y1 = y0 + 8;
             if (y0 < g.H) {
@@ -436,7 +559,7 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
         }
     }
 #ifdef GSR_BLEND_STAMPS
-    if (lane == 0 && blockIdx.x < 4096) {
+    if (lane == 0 && blockIdx.x < 4096 && part == 0) {
         unsigned int* o = g_blend_stamps + ((size_t)blockIdx.x * 4 + wave) * 16;
         o[0] = (unsigned int)__builtin_readcyclecounter() - t_kernel0; o[1] = a_waitA; o[2] = a_stage; o[3] = a_waitB; o[4] = a_comp;
         o[5] = t_real0; o[6] = (unsigned int)__builtin_amdgcn_s_memrealtime(); o[7] = a_entries;
@@ -450,14 +573,40 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
 #endif
 }
 
+// 7 waves per SIMD: the kernel needs 74 VGPRs unconstrained (6 waves); capped at 72 it spills one register pair that is
+// stored once per workgroup and reloaded once per work item, and the seventh wave hides more of the LDS/barrier
+// waits (measured: k_blend -5.7 % alone; 8 waves = 64 VGPRs spills inside the loops and is no better).
+#define GSR_BLEND_PARAMS                                                                                                  \
+    const uint32_t *__restrict__ items, const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ bin_start,   \
+        const uint32_t *__restrict__ list, const Record *__restrict__ rec, const float4 *__restrict__ shcol,              \
+        float4 *__restrict__ fb, float4 *__restrict__ partial, uint32_t *__restrict__ queue, BinGrid g, float eps,        \
+        const uint32_t *__restrict__ seg_len_dev, uint32_t capacity, uint32_t nsplats,                                    \
+        unsigned long long *__restrict__ bin_mask, uint32_t *__restrict__ bin_sat, uint32_t saturate
+#define GSR_BLEND_ARGS items, seg_start, bin_start, list, rec, shcol, fb, partial, queue, g, eps, seg_len_dev, capacity, nsplats, bin_mask, bin_sat, saturate
+__global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_blend(GSR_BLEND_PARAMS)
+{
+    blend_body<1>(GSR_BLEND_ARGS);
+}
+// two waves per tile: 512-thread workgroups, three per CU (6 waves per SIMD, 80 registers)
+__global__ __launch_bounds__(2 * BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_blend2(GSR_BLEND_PARAMS)
+{
+    blend_body<2>(GSR_BLEND_ARGS);
+}
+#undef GSR_BLEND_PARAMS
+#undef GSR_BLEND_ARGS
+
 #ifdef GSR_BLEND_STAMPS
 extern "C" int gsr_debug_blend_stamps(unsigned int* out /* 4096*4*16 */)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blend_stamps), sizeof g_blend_stamps) == hipSuccess ? 0 : -1;
 }
+extern "C" int gsr_debug_bin_info(unsigned int* out /* 16384*8 */)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bin_info), sizeof g_bin_info) == hipSuccess ? 0 : -1;
+}
 #endif
 
-// Fold the per-segment partials of every multi-segment bin, front to back -- the stand-alone form (BlendBuffers::bin_done
+// Fold the per-segment partials of every multi-segment bin, front to back -- the stand-alone form (BlendBuffers::bin_mask
 // null); by default the fold runs inside k_blend and this kernel is not launched.  A thread folds its four
 // pixels as four independent chains and the segment loop is unrolled, so 16 loads are in flight per
 // thread: the kernel is a latency-bound read of the partials (85 MB on C3 with 512-entry segments).
@@ -499,11 +648,14 @@ void launch_blend(const BlendBuffers& b, const BinGrid& g, float early_out_eps, 
 {
     const int nbins = (g.bx_hi - g.bx_lo) * g.nby;
     if (nbins <= 0) return;
-    hipLaunchKernelGGL(k_blend, dim3(b.grid), dim3(BLEND_THREADS), 0, s, b.items, b.seg_start, b.bin_start, b.list, b.rec,
-                       b.shcol, b.fb, b.partial, b.queue, g, early_out_eps, b.seg_len_dev, b.capacity, b.nsplats, b.bin_done, b.saturate,
-                       b.prio[0], b.prio[1], b.prio[2]);
+    if (b.sub == 2)
+        hipLaunchKernelGGL(k_blend2, dim3(b.grid), dim3(2 * BLEND_THREADS), 0, s, b.items, b.seg_start, b.bin_start, b.list, b.rec,
+                           b.shcol, b.fb, b.partial, b.queue, g, early_out_eps, b.seg_len_dev, b.capacity, b.nsplats, b.bin_mask, b.bin_sat, b.saturate);
+    else
+        hipLaunchKernelGGL(k_blend, dim3(b.grid), dim3(BLEND_THREADS), 0, s, b.items, b.seg_start, b.bin_start, b.list, b.rec,
+                           b.shcol, b.fb, b.partial, b.queue, g, early_out_eps, b.seg_len_dev, b.capacity, b.nsplats, b.bin_mask, b.bin_sat, b.saturate);
     if (between) (void)hipEventRecord(between, s);
-    if (b.seg_len < 0x40000000u && !b.bin_done)
+    if (b.seg_len < 0x40000000u && !b.bin_mask)
         hipLaunchKernelGGL(k_combine, dim3(nbins), dim3(BLEND_THREADS), 0, s, b.seg_start, (const float4*)b.partial, b.fb, g);
 }
 

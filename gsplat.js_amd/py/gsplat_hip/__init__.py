@@ -494,11 +494,12 @@ class HIPRenderer:
         return out[:nbx.value * nby.value].reshape(nby.value, nbx.value)
 
     def work_items(self):
-        """How the last frame's bin lists were cut for the compositor: entries per segment, work items, entries per
-        front-window segment (0: no windows), bins."""
-        out = np.zeros(4, dtype=np.uint32)
+        """How the last frame's bin lists were cut for the compositor: entries per segment, work items, whether the segments
+        were speculative (GSR_SPEC=1: segments behind a saturated prefix of their bin are skipped), the compositor's waves per
+        16x16 tile (which of its two kernels ran), bins."""
+        out = np.zeros(5, dtype=np.uint32)
         self._check(self._L.gsr_read_work_items(self._ctx, out.ctypes.data))
-        return {"seg_len": int(out[0]), "items": int(out[1]), "win_len": int(out[2]), "bins": int(out[3])}
+        return {"seg_len": int(out[0]), "items": int(out[1]), "speculative": bool(out[2]), "waves_per_tile": int(out[3]), "bins": int(out[4])}
 
     def set_timing_interval(self, every):
         """Record stage events only on every `every`-th frame (they cost command-processor time on short frames)."""

@@ -173,10 +173,11 @@ int gsr_set_timing_interval(gsr_ctx *ctx, uint32_t every);
 int gsr_read_keys(gsr_ctx *ctx, uint32_t *keys /* n, 17-bit */, int32_t *minmax /* 2 */);
 int gsr_read_records(gsr_ctx *ctx, float *rec /* 8n */, int32_t *bbox /* 4n: x0,y0,x1,y1 */);
 int gsr_read_sh_colors(gsr_ctx *ctx, float *rgba /* 4n: evaluated SH colour of every splat that has one */);
-/* How the last rendered frame's bin lists were cut into compositor work items (the cut changes no depth order, only
- * f32 association): out[0] = list entries per segment, out[1] = work items, out[2] = entries per front-window segment
- * of a heavy bin (0: no windows in this frame), out[3] = bins of the context's band. */
-int gsr_read_work_items(gsr_ctx *ctx, uint32_t *out /* 4 */);
+/* How the last rendered frame's bin lists were handed to the compositor (the choices change no depth order, only f32
+ * association): out[0] = list entries per segment, out[1] = work items, out[2] = 1 when the segments were speculative
+ * (GSR_SPEC=1: segments behind a saturated prefix of their bin are skipped; same bits as out[2] = 0), out[3] = waves
+ * per 16x16 tile (1: k_blend, 2: k_blend2), out[4] = bins of the context's band. */
+int gsr_read_work_items(gsr_ctx *ctx, uint32_t *out /* 5 */);
 
 /* ---- multi-GPU helpers ---- */
 /* Entries per 32x32 bin of the last rendered frame, row-major over the context's band (cost model for balanced bands). */

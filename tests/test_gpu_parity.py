@@ -641,7 +641,9 @@ def test_cpp_caller_matches_python_host(gh, scenes, tmp_path):
     f = tmp_path / "c1.splat"
     f.write_bytes(np.asarray(rows, dtype=np.uint8).tobytes())
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gsplat.js_amd", "lib", "bench_cabi")
-    out = subprocess.run([exe, "--config", "C1", "--rows", str(f), "--frames", "30", "--warmup", "5", "--dump", str(tmp_path / "cpp")],
+    # (--in-flight 1: contexts of the same kind as the Python host's below; throughput contexts composite with the other kernel,
+    #  same pixels to f32 association)
+    out = subprocess.run([exe, "--config", "C1", "--rows", str(f), "--frames", "30", "--warmup", "5", "--in-flight", "1", "--dump", str(tmp_path / "cpp")],
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     line = json.loads(out.stdout.strip().splitlines()[-1])
@@ -1021,18 +1023,17 @@ def test_saturated_quadrants_are_skipped_without_changing_a_bit(gh, monkeypatch,
 
 @pytest.mark.gpu
 def test_long_and_short_work_items_agree(gh, monkeypatch):
-    """The work-item length is chosen per frame from the frame's optical depth (k_bin_finalize): long items where the
-    scene saturates.  The two cuts of a bin's list differ in f32 association order only: images within 2e-6, RGBA8
-    within one step, and the policy picks long items on C3 (tau 362) and short ones on C2 (tau 74) -- seen through the
-    number of work items, which the segment count of the statistics does not expose, so through the images: the
-    automatic choice equals the pinned one bit for bit."""
+    """The work-item length is chosen per frame from the frame's optical depth (k_bin_finalize): whole bins where the
+    scene saturates (C3, tau 362), short segments where it does not (C2, tau 74).  The two cuts of a bin's list differ in
+    f32 association order only: images within 2e-6, RGBA8 within one step; what the policy picked is read back with
+    gsr_read_work_items (whole bins: as many work items as bins), and the automatic choice equals the pinned one bit for bit."""
     for name, expect in (("C3", "1"), ("C2", "0")):
         cfg = gh.synth.CONFIGS[name]
         W, H = cfg["width"], cfg["height"]
         scene = gh.Scene()
         scene.setData(gh.synth.config_rows(name))
         cam = gh.orbit_camera(17, 120, W, H, cfg["fx"])
-        imgs = {}
+        imgs, whole = {}, {}
         for mode in ("0", "1", "auto"):
             if mode == "auto":
                 monkeypatch.delenv("GSR_LONG_ITEMS", raising=False)
@@ -1041,10 +1042,14 @@ def test_long_and_short_work_items_agree(gh, monkeypatch):
             r = gh.HIPRenderer(W, H)
             r.render(scene, cam)
             imgs[mode] = (r.readPixelsFloat(), r.readPixels())
+            wi = r.work_items()
+            whole[mode] = wi["items"] == wi["bins"]
+            assert wi["waves_per_tile"] == 2 and not wi["speculative"]
             r.dispose()
         assert np.abs(imgs["0"][0] - imgs["1"][0]).max() <= 2e-6
         assert np.abs(imgs["0"][1].astype(np.int32) - imgs["1"][1].astype(np.int32)).max() <= 1
         assert np.array_equal(imgs["auto"][0], imgs[expect][0]), name
+        assert whole["1"] and not whole["0"] and whole["auto"] == (expect == "1"), name
 
 
 @pytest.mark.gpu
@@ -1058,7 +1063,7 @@ def test_heavy_bins_split_into_tile_items_change_no_bit(gh, monkeypatch):
     W, H = cfg["width"], cfg["height"]
     scene = gh.Scene()
     scene.setData(gh.synth.config_rows("C3"))
-    monkeypatch.setenv("GSR_WIN_FROM", "0")   # (the front window replaces this option where it applies: keep whole-bin items here)
+    monkeypatch.setenv("GSR_BLEND_SUB", "1")   # (tile items give every wave one quadrant: the one-wave-per-tile kernel, for all three)
     for eps in (0.0, 1e-4):
         monkeypatch.setenv("GSR_QUAD_FROM", "0")
         whole = gh.HIPRenderer(W, H, early_out_eps=eps)
@@ -1082,54 +1087,98 @@ def test_heavy_bins_split_into_tile_items_change_no_bit(gh, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_front_window_of_heavy_bins(gh, oracle, scenes, monkeypatch):
-    """In a frame with long work items a heavy bin hands out its front window as concurrent segments; the workgroup whose
-    arrival is last folds them and continues behind the window under the folded transmittance (k_bin_finalize, k_blend).
-    The cut differs from the whole-bin cut by f32 association only: images within 2e-6, RGBA8 within one step, for the
-    default window and for extreme ones (two 512-entry segments and a long tail; eight segments; every bin windowed), on
-    C3, where the policy picks long items by itself.  The saturation skip changes no bit under a windowed cut either.
-    And on small scenes with the policy pinned (C1, C2: windows of 2 x 512 entries from 600 entries on) the image stays
-    within 2e-4 of the oracle (frag.glsl.ts:13-21, WebGLRenderer.ts:139-142)."""
-    cfg = gh.synth.CONFIGS["C3"]
-    W, H = cfg["width"], cfg["height"]
+@pytest.mark.parametrize("sub", ["1", "2"])
+def test_speculative_segments_equal_the_plain_cut_bit_for_bit(gh, monkeypatch, sub):
+    """(An option, GSR_SPEC=1; dense frames are cut into whole-bin work items by default, which measured faster.)  A dense
+    frame cut into the same plain segments as any other frame, handed out layer by layer; the workgroup whose arrival
+    completes a power-of-two prefix of a bin folds it and tests it for saturation, segments behind a saturated prefix are
+    skipped and the final fold stops there (k_bin_finalize, k_blend).  Nothing that is skipped could have changed a bit
+    (every later term is under half an ulp of the folded colour), so the image must EQUAL the plain cut's
+    (GSR_LONG_ITEMS=0), f32 and RGBA8 -- whichever segments happened to be skipped in a given run: rendered twice, and
+    with either compositor kernel (one or two waves per tile).  Whole-bin work items differ by f32 association."""
+    monkeypatch.setenv("GSR_BLEND_SUB", sub)
+    for name, poses in (("C3", (5, 17, 47, 88)), ("C4", (9,))):
+        cfg = gh.synth.CONFIGS[name]
+        W, H = cfg["width"], cfg["height"]
+        scene = gh.Scene()
+        scene.setData(gh.synth.config_rows(name))
+        monkeypatch.setenv("GSR_LONG_ITEMS", "0")
+        plain = gh.HIPRenderer(W, H)
+        monkeypatch.setenv("GSR_LONG_ITEMS", "1")
+        whole = gh.HIPRenderer(W, H)
+        monkeypatch.setenv("GSR_SPEC", "1")
+        spec = gh.HIPRenderer(W, H)
+        monkeypatch.delenv("GSR_SPEC")
+        monkeypatch.delenv("GSR_LONG_ITEMS")
+        for k in poses:
+            cam = gh.orbit_camera(k, 120, W, H, cfg["fx"])
+            plain.render(scene, cam)
+            want, want8 = plain.readPixelsFloat(), plain.readPixels()
+            assert not plain.work_items()["speculative"] and plain.work_items()["waves_per_tile"] == int(sub)
+            for _ in range(2):
+                spec.render(scene, cam)
+                assert spec.work_items() == dict(plain.work_items(), speculative=True)
+                assert np.array_equal(spec.readPixelsFloat(), want), (name, k)
+                assert np.array_equal(spec.readPixels(), want8), (name, k)
+            whole.render(scene, cam)
+            assert not whole.work_items()["speculative"] and whole.work_items()["items"] == whole.work_items()["bins"]
+            assert np.abs(whole.readPixelsFloat() - want).max() <= 2e-6, (name, k)
+        for r in (plain, spec, whole):
+            r.dispose()
+
+
+@pytest.mark.gpu
+def test_two_waves_per_tile_agree_with_one(gh, oracle, scenes, monkeypatch):
+    """k_blend2 gives every 16x16 tile two waves: the first walks the first half of each 256-entry chunk's hits under the
+    running transmittance, the second the other half from (colour 0, transmittance 1), folded at the chunk boundary
+    (associativity of "under": frag.glsl.ts:13-21 with the blend state of WebGLRenderer.ts:139-142).  Same depth order,
+    another f32 association than k_blend: images within 2e-6 of each other on C3 (whole-bin items, saturation skip on and
+    off bit-identical within the kernel) and C2 (short segments), and within 2e-4 of the oracle on C1 and C2 with either
+    kernel.  Contexts that render one frame at a time use it up to 4096 bins; throughput contexts and 4K keep k_blend."""
+    for name, poses in (("C3", (11, 73)), ("C2", (40,))):
+        cfg = gh.synth.CONFIGS[name]
+        W, H = cfg["width"], cfg["height"]
+        scene = gh.Scene()
+        scene.setData(gh.synth.config_rows(name))
+        monkeypatch.setenv("GSR_BLEND_SUB", "1")
+        one = gh.HIPRenderer(W, H)
+        monkeypatch.setenv("GSR_BLEND_SUB", "2")
+        two = gh.HIPRenderer(W, H)
+        monkeypatch.setenv("GSR_SATURATE", "0")
+        monkeypatch.setenv("GSR_LONG_ITEMS", "1")
+        two_all = gh.HIPRenderer(W, H)
+        monkeypatch.delenv("GSR_SATURATE")
+        two_pinned = gh.HIPRenderer(W, H)
+        monkeypatch.delenv("GSR_LONG_ITEMS")
+        monkeypatch.delenv("GSR_BLEND_SUB")
+        auto = gh.HIPRenderer(W, H)
+        thr = gh.HIPRenderer(W, H, throughput=True)
+        for k in poses:
+            cam = gh.orbit_camera(k, 120, W, H, cfg["fx"])
+            imgs = {}
+            for key, r in (("one", one), ("two", two), ("two_all", two_all), ("two_pinned", two_pinned), ("auto", auto), ("thr", thr)):
+                r.render(scene, cam)
+                imgs[key] = r.readPixelsFloat()
+            assert one.work_items()["waves_per_tile"] == 1 and two.work_items()["waves_per_tile"] == 2
+            assert auto.work_items()["waves_per_tile"] == 2 and thr.work_items()["waves_per_tile"] == 1
+            assert np.abs(imgs["one"] - imgs["two"]).max() <= 2e-6, (name, k)
+            assert np.array_equal(imgs["two"], imgs["auto"]), (name, k)
+            assert np.array_equal(imgs["two_all"], imgs["two_pinned"]), (name, k)   # the saturation skip changes no bit here either
+        for r in (one, two, two_all, two_pinned, auto, thr):
+            r.dispose()
+    for sub in ("1", "2"):
+        monkeypatch.setenv("GSR_BLEND_SUB", sub)
+        for name, pose in (("C1", 40), ("C2", 13)):
+            c = gh.synth.CONFIGS[name]
+            rows, data, pos = scenes(name)
+            cam = _camera(gh, pose, c)
+            img, img8, di, st, oimg, odi, V, D = _render_pair(gh, oracle, data, pos, cam, c["width"], c["height"])
+            assert np.array_equal(di, odi)
+            assert np.abs(img.astype(np.float64) - oimg.astype(np.float64)).max() <= TOL_EXACT, (sub, name)
+    monkeypatch.delenv("GSR_BLEND_SUB")
+    w4 = gh.HIPRenderer(3840, 2160)      # 8160 bins: one wave per tile
     scene = gh.Scene()
-    scene.setData(gh.synth.config_rows("C3"))
-    monkeypatch.setenv("GSR_LONG_ITEMS", "1")   # (some poses of the orbit lie under the policy's threshold: pinned for all)
-    monkeypatch.setenv("GSR_WIN_FROM", "0")
-    whole = gh.HIPRenderer(W, H)
-    monkeypatch.delenv("GSR_WIN_FROM")
-    cuts = {"default": {}, "two_short": {"GSR_WIN_FROM": "600", "GSR_WIN_LEN": "512", "GSR_WIN_SEGS": "2"},
-            "eight": {"GSR_WIN_FROM": "1024", "GSR_WIN_LEN": "512", "GSR_WIN_SEGS": "8"},
-            "two_short_noskip": {"GSR_WIN_FROM": "600", "GSR_WIN_LEN": "512", "GSR_WIN_SEGS": "2", "GSR_SATURATE": "0"}}
-    rs = {}
-    for name, env in cuts.items():
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        rs[name] = gh.HIPRenderer(W, H)
-        for k in env:
-            monkeypatch.delenv(k)
-    for k in (5, 47, 88):
-        cam = gh.orbit_camera(k, 120, W, H, cfg["fx"])
-        whole.render(scene, cam)
-        want, want8 = whole.readPixelsFloat(), whole.readPixels().astype(np.int32)
-        imgs = {}
-        for name, r in rs.items():
-            r.render(scene, cam)
-            imgs[name] = r.readPixelsFloat()
-            assert np.abs(imgs[name] - want).max() <= 2e-6, (name, k)
-            assert np.abs(r.readPixels().astype(np.int32) - want8).max() <= 1, (name, k)
-        assert np.array_equal(imgs["two_short"], imgs["two_short_noskip"]), k
-        if k == 5:   # the default window is in use on C3 (the cut is not the whole-bin one)
-            assert not np.array_equal(imgs["default"], want)
-    for r in [whole] + list(rs.values()):
-        r.dispose()
-    monkeypatch.setenv("GSR_LONG_ITEMS", "1")
-    for k, v in cuts["two_short"].items():
-        monkeypatch.setenv(k, v)
-    for name, pose in (("C1", 40), ("C2", 13)):
-        c = gh.synth.CONFIGS[name]
-        rows, data, pos = scenes(name)
-        cam = _camera(gh, pose, c)
-        img, img8, di, st, oimg, odi, V, D = _render_pair(gh, oracle, data, pos, cam, c["width"], c["height"])
-        assert np.array_equal(di, odi)
-        assert np.abs(img.astype(np.float64) - oimg.astype(np.float64)).max() <= TOL_EXACT, name
+    scene.setData(gh.synth.config_rows("C1"))
+    w4.render(scene, gh.orbit_camera(3, 120, 3840, 2160, 2264.0))
+    assert w4.work_items()["waves_per_tile"] == 1
+    w4.dispose()
