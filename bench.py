@@ -120,6 +120,59 @@ def cpu_baseline(gh, cfg, data, pos, sample_frames=2, sort_calls=10):
     }
 
 
+def other_config(gh, name, device, F, frames=120):
+    """The same measurement on another BASELINE.json configuration, outside the headline's timed region: frames/s with F
+    frames in flight and one frame at a time, stage times (HIP events, one frame at a time), counts, overflow counters.
+    The scene is built on the device from the .splat rows (gsr_set_scene_rows: bit-identical to the host's Scene.setData,
+    tests/test_gpu_parity.py), which spares the host's covariance loop for 5 M splats."""
+    cfg = gh.synth.CONFIGS[name]
+    W, H, N = cfg["width"], cfg["height"], cfg["n"]
+    rows = gh.synth.config_rows(name)
+    poses = [gh.orbit_camera(k, ORBIT_FRAMES, W, H, cfg["fx"]).f32() for k in range(ORBIT_FRAMES)]
+    rs = [gh.HIPRenderer(W, H, device=device, throughput=F > 1, timing=True) for _ in range(F)]
+    solo = gh.HIPRenderer(W, H, device=device, timing=True)
+    for rr in rs + [solo]:
+        rr.set_scene_rows(rows)
+        rr.set_timing_interval(8)
+        for j in range(SETUP_FRAMES):   # LSD-order first frame, bucket-order decision, graph captures: not a frame's work
+            rr.set_camera_arrays(*poses[j], cfg["fx"], cfg["fx"])
+            rr.render_async()
+        rr.sync()
+        rr.reset_stats()
+    del rows
+
+    def run(ctxs, count):
+        t0 = time.perf_counter()
+        for k in range(count):
+            rr = ctxs[k % len(ctxs)]
+            rr.set_camera_arrays(*poses[k % ORBIT_FRAMES], cfg["fx"], cfg["fx"])
+            rr.render_async()
+        for rr in ctxs:
+            rr.sync()
+        return count / (time.perf_counter() - t0)
+
+    run(rs, 2 * F)
+    fps = run(rs, frames)
+    run([solo], 2)
+    solo.reset_stats()
+    fps1 = run([solo], max(30, frames // 2))
+    s1 = solo.stats()
+    f1 = max(int(s1["frames"]), 1)
+    sf = max(int(s1["sum_frames"]), 1)
+    sts = [rr.stats() for rr in rs + [solo]]
+    out = {"workload": "%s: %d synthetic gaussians (seed %d), %dx%d, 120-pose orbit" % (name, N, cfg["seed"], W, H),
+           "frames_per_sec": fps, "frames_in_flight": F, "frames": frames,
+           "one_frame_in_flight": {"frames_per_sec": fps1, "ms_per_frame": 1e3 / fps1,
+                                   "stage_ms": {k: s1["sum_ms_" + k] / f1 for k in ("project_key", "sort", "bin", "blend", "combine", "total")}},
+           "counts": {"N": N, "V": s1["sum_visible"] / sf, "D_tiles16": s1["sum_tile_entries"] / sf,
+                      "bin_entries32": s1["sum_bin_entries"] / sf, "P": W * H},
+           "work_items": solo.work_items(),
+           "overflow_frames": sum(int(x["overflow_frames"]) for x in sts), "dropped_frames": sum(int(x["dropped_frames"]) for x in sts)}
+    for rr in rs + [solo]:
+        rr.dispose()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,6 +182,8 @@ def main():
     ap.add_argument("--early-out-eps", type=float, default=0.0,
                     help="0 = no approximate termination (default): every fragment that can change a bit of the image is composited")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the secondary measurements on C2 (300 k, 1080p) and C4 (5 M, 3840x2160) that follow the C3 legs")
     ap.add_argument("--timed-only", action="store_true",
                     help="skip the untimed secondary legs (one frame in flight, latency, readback, sort alone) and the CPU baseline: "
                          "for profiler runs, so that every traced launch belongs to the timed configuration")
@@ -327,10 +382,12 @@ def main():
     # secondary leg outside the timed region: ONE frame in flight on a context tuned for that (no GSR_FLAG_THROUGHPUT)
     # -> per-frame latency and uncontended stage times
     solo = None
+    r_solo_sub = 1
     if F > 1 and world == 1 and not args.timed_only:
         sr = gh.HIPRenderer(W, H, device=local_rank, early_out_eps=args.early_out_eps, timing=True)
         for k in range(4):
             sr.render(scene, gh.orbit_camera(k, ORBIT_FRAMES, W, H, cfg["fx"]))
+        r_solo_sub = sr.work_items()["waves_per_tile"]
         sr.reset_stats()
         t1 = time.perf_counter()
         for k in range(60):
@@ -458,6 +515,7 @@ def main():
         blend_ms = solo["stage_ms"]["blend"] if solo else ms["blend"]
         ach_solo = b_blend / (blend_ms * 1e-3) / 1e9 if blend_ms > 0 else 0.0
         sm = solo["stage_ms"] if solo else ms   # per-stage figures: uncontended times when several frames were in flight
+        kernel_name = "k_blend2" if (solo and r_solo_sub == 2) else "k_blend"
         out = {
             "metric": "frames_per_sec", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
@@ -472,7 +530,7 @@ def main():
             "sorted_splats_per_sec": N / ((sm["project_key"] + sm["sort"]) * 1e-3) if (sm["project_key"] + sm["sort"]) > 0 else None,
             "stage_ms": ms,
             "counts": {"N": N, "V": V, "D_tiles16": D, "bin_entries32": E, "P": band_px},
-            "roofline": {"bound": "hbm", "kernel": "k_blend", "achieved": ach_solo, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "valu", "kernel": kernel_name, "achieved": ach_solo, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_solo / HBM_PEAK_GBS, "traffic": traffic_solo if solo else traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": b_blend, "avg_launch_ms": blend_ms,
                          "frames_in_flight_of_this_figure": 1 if solo else F,
@@ -480,8 +538,9 @@ def main():
                              "frames_in_flight": F, "avg_launch_ms": ms["blend"], "achieved": ach, "frac": ach / HBM_PEAK_GBS,
                              "traffic": traffic,
                              "note": "event pairs around k_blend while other frames' kernels share the GPU: overlap-inflated"},
-                         "note": "the compositor is bound by VALU issue and wave stalls (barriers, LDS reads), not by HBM "
-                                 "(SURVEY 8(d) honest note); see valu and DESIGN.md section 8"},
+                         "note": "achieved / peak / frac / traffic are the HBM figures the contract asks for (algorithmic bytes over the "
+                                 "launch duration); the kernel itself is bound by VALU issue and by a wave's serial walk over its "
+                                 "entries, not by HBM (SURVEY 8(d) honest note): see `valu` and DESIGN.md section 8"},
             # secondary ceiling: VALU issue.  peak = what tools/valu_cost.hip sustains on this chip for the compositor's
             # own instruction mix (11 VALU of a covered quadrant incl. v_exp_f32 and v_pk_fma_f32, operands in VGPRs,
             # 7 waves/SIMD like k_blend, wall clock): 0.651e12 wave-instr/s (profiles/r02_valu_cost4.txt)
@@ -491,8 +550,14 @@ def main():
             "overflow_frames": overflow_frames, "dropped_frames": dropped_frames,
             "build_id": gh.build_id(),
             "stage_roofline": {
-                "sort": {"bytes": b_sort, "ms": sm["sort"], "GBps": b_sort / (sm["sort"] * 1e-3) / 1e9 if sm["sort"] else 0,
-                         "frac": b_sort / (sm["sort"] * 1e-3) / 1e9 / HBM_PEAK_GBS if sm["sort"] else 0},
+                # 52 N covers the whole sort path of wasm.cpp (key + min/max: 28 N, radix passes: 24 N): over key pass + radix
+                # stage (the sort-only leg); the radix stage alone moves 24 N + the 8 N of keys it writes and re-reads
+                "sort": (lambda t: {"bytes": b_sort, "ms": t, "GBps": b_sort / (t * 1e-3) / 1e9 if t else 0,
+                                    "frac": b_sort / (t * 1e-3) / 1e9 / HBM_PEAK_GBS if t else 0,
+                                    "note": "key + min/max pass and radix stage together (gsr_sort)"})(
+                    (solo["sort_only"]["ms_key_minmax"] + solo["sort_only"]["ms_quantise_radix"]) if solo else sm["project_key"] + sm["sort"]),
+                "radix": {"bytes": 32.0 * N, "ms": sm["sort"], "GBps": 32.0 * N / (sm["sort"] * 1e-3) / 1e9 if sm["sort"] else 0,
+                          "frac": 32.0 * N / (sm["sort"] * 1e-3) / 1e9 / HBM_PEAK_GBS if sm["sort"] else 0},
                 "project_key": {"bytes": b_proj + 16.0 * N, "ms": sm["project_key"],
                                 "GBps": (b_proj + 16.0 * N) / (sm["project_key"] * 1e-3) / 1e9 if sm["project_key"] else 0},
                 "bin": {"bytes": b_bin, "ms": sm["bin"], "GBps": b_bin / (sm["bin"] * 1e-3) / 1e9 if sm["bin"] else 0},
@@ -503,6 +568,8 @@ def main():
             "band_edges": band_edges_used,
             "device": r.device_info(),
         }
+        if world == 1 and args.config == "C3" and not args.timed_only and not args.no_other_configs and not emu:
+            out["other_configs"] = {name: other_config(gh, name, local_rank, F) for name in ("C2", "C4")}
         if world == 1 and not args.no_cpu_baseline and not args.timed_only:
             out["cpu_baseline"] = cpu_baseline(gh, cfg, scene.data[:8 * N], scene.positions)
         print(json.dumps(out))
