@@ -282,10 +282,14 @@ def main():
                             timing=True, throughput=F > 1)
         rs.append(rr)
     if in_library:
-        ids = [[gh.new_group_id() for _ in range(F)] if rank == 0 else None]
+        # ONE communicator and ONE exchange stream per rank, shared by its F contexts: the collectives of a rank's frames in
+        # flight are issued in frame order on every rank (several communicators per device with collectives in flight on
+        # separate streams can deadlock when ranks schedule them in different orders)
+        ids = [gh.new_group_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
-        for rr, cid in zip(rs, ids[0]):      # one communicator per context: frames in flight exchange independently
-            rr.join_group(cid, rank, world, edges)
+        rs[0].join_group(ids[0], rank, world, edges)
+        for rr in rs[1:]:
+            rr.share_group(rs[0])
     for rr in rs:
         rr.render(scene, gh.orbit_camera(0, ORBIT_FRAMES, W, H, cfg["fx"]))  # uploads the scene, first frame
         rr.set_timing_interval(max(1, args.timing_interval))
@@ -573,7 +577,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not args.timed_only:
             out["cpu_baseline"] = cpu_baseline(gh, cfg, scene.data[:8 * N], scene.positions)
         print(json.dumps(out))
-    for rr in rs:
+    for rr in reversed(rs):    # (contexts that share rs[0]'s communicator go first)
         rr.dispose()
     if world > 1:
         dist.barrier()

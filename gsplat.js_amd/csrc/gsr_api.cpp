@@ -114,6 +114,9 @@ struct gsr_ctx {
 
     // multi-GPU exchange (gsr_comm_init): RCCL communicator, its stream, the RGBA8 slab / gathered slabs / full frame
     ncclComm_t comm = nullptr;
+    gsr_allgather_fn comm_fn = nullptr;   // gsr_comm_init_custom: the caller's collective in place of ncclAllGather
+    void* comm_fn_user = nullptr;
+    bool comm_owned = true;               // false: communicator and exchange stream belong to another context (gsr_comm_share)
     int comm_rank = 0, comm_world = 0, slab_w = 0;
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_packed = nullptr, ev_slab_free = nullptr;
@@ -1319,13 +1322,15 @@ RcclApi& rccl()
 void comm_release(gsr_ctx* c)
 {
     if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
-    if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
+    if (c->comm && c->comm_owned && rccl().ok) (void)rccl().CommDestroy(c->comm);
     c->comm = nullptr;
+    c->comm_fn = nullptr; c->comm_fn_user = nullptr;
     if (c->ev_packed) (void)hipEventDestroy(c->ev_packed);
     if (c->ev_slab_free) (void)hipEventDestroy(c->ev_slab_free);
     c->ev_packed = c->ev_slab_free = nullptr;
-    if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+    if (c->comm_stream && c->comm_owned) (void)hipStreamDestroy(c->comm_stream);
     c->comm_stream = nullptr;
+    c->comm_owned = true;
     dev_free(&c->slab); dev_free(&c->gathered); dev_free(&c->frame8);
     c->comm_world = 0; c->frame8_valid = false;
 }
@@ -1346,22 +1351,22 @@ int gsr_comm_unique_id(uint8_t* id)
     return GSR_OK;
 }
 
-int gsr_comm_init(gsr_ctx* c, const uint8_t* id, int32_t rank, int32_t world, const int32_t* x0, const int32_t* x1)
+// everything of gsr_comm_init but the communicator: argument checks, the context's band, slab / gathered / frame buffers,
+// the exchange stream (its own, or `shared_stream`) and the two ordering events
+static int comm_setup(gsr_ctx* c, const char* who, int32_t rank, int32_t world, const int32_t* x0, const int32_t* x1, hipStream_t shared_stream)
 {
-    if (!c) return GSR_ERR_ARG;
-    if (!id || !x0 || !x1 || world < 1 || world > MAX_SLABS || rank < 0 || rank >= world)
-        return fail(c, GSR_ERR_ARG, "gsr_comm_init: bad argument (1 <= world <= %d, 0 <= rank < world)", MAX_SLABS);
-    if (!c->W || !c->H) return fail(c, GSR_ERR_ARG, "gsr_comm_init: set the framebuffer size first");
-    if (!rccl().ok) return fail(c, GSR_ERR_COMM, "%s", rccl().error.c_str());
+    if (!x0 || !x1 || world < 1 || world > MAX_SLABS || rank < 0 || rank >= world)
+        return fail(c, GSR_ERR_ARG, "%s: bad argument (1 <= world <= %d, 0 <= rank < world)", who, MAX_SLABS);
+    if (!c->W || !c->H) return fail(c, GSR_ERR_ARG, "%s: set the framebuffer size first", who);
     int sw = BIN_PX;
     for (int q = 0; q < world; q++) {
         // every rank must hold the same edges: whole 32-px bin columns, contiguous, covering the image
         const int want0 = q ? x1[q - 1] : 0;
         if (x0[q] != want0 || x1[q] <= x0[q] || x0[q] % BIN_PX || (x1[q] % BIN_PX && x1[q] != c->W) || x1[q] > c->W)
-            return fail(c, GSR_ERR_ARG, "gsr_comm_init: band %d = [%d,%d) (bands are contiguous runs of whole %d-px columns)", q, x0[q], x1[q], BIN_PX);
+            return fail(c, GSR_ERR_ARG, "%s: band %d = [%d,%d) (bands are contiguous runs of whole %d-px columns)", who, q, x0[q], x1[q], BIN_PX);
         sw = std::max(sw, x1[q] - x0[q]);
     }
-    if (x1[world - 1] != c->W) return fail(c, GSR_ERR_ARG, "gsr_comm_init: the bands end at %d, the image is %d wide", x1[world - 1], c->W);
+    if (x1[world - 1] != c->W) return fail(c, GSR_ERR_ARG, "%s: the bands end at %d, the image is %d wide", who, x1[world - 1], c->W);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     comm_release(c);
@@ -1375,13 +1380,50 @@ int gsr_comm_init(gsr_ctx* c, const uint8_t* id, int32_t rank, int32_t world, co
         return r;
     HIP_TRY(c, hipMemsetAsync(c->slab, 0, slab_px * 4, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    if (shared_stream) { c->comm_stream = shared_stream; c->comm_owned = false; }
+    else HIP_TRY(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&c->ev_slab_free, hipEventDisableTiming));
+    c->comm_rank = rank; c->comm_world = world;
+    return GSR_OK;
+}
+
+int gsr_comm_init(gsr_ctx* c, const uint8_t* id, int32_t rank, int32_t world, const int32_t* x0, const int32_t* x1)
+{
+    if (!c) return GSR_ERR_ARG;
+    if (!id) return fail(c, GSR_ERR_ARG, "gsr_comm_init: id is NULL");
+    if (!rccl().ok) return fail(c, GSR_ERR_COMM, "%s", rccl().error.c_str());
+    if (int r = comm_setup(c, "gsr_comm_init", rank, world, x0, x1, nullptr)) return r;
     ncclUniqueId u;
     memcpy(u.internal, id, GSR_COMM_ID_BYTES);
-    RCCL_TRY(c, rccl().CommInitRank(&c->comm, world, u, rank));   // collective: returns when every rank has joined
-    c->comm_rank = rank; c->comm_world = world;
+    const ncclResult_t nr = rccl().CommInitRank(&c->comm, world, u, rank);   // collective: returns when every rank has joined
+    if (nr != ncclSuccess) {
+        c->comm = nullptr;
+        comm_release(c);
+        return fail(c, GSR_ERR_COMM, "ncclCommInitRank failed: %s", rccl().GetErrorString(nr));
+    }
+    return GSR_OK;
+}
+
+int gsr_comm_share(gsr_ctx* c, gsr_ctx* leader)
+{
+    if (!c || !leader) return GSR_ERR_ARG;
+    if (c == leader || (!leader->comm && !leader->comm_fn) || !leader->comm_owned)
+        return fail(c, GSR_ERR_ARG, "gsr_comm_share: the other context must have joined a group itself (gsr_comm_init)");
+    if (c->device != leader->device || c->W != leader->W || c->H != leader->H)
+        return fail(c, GSR_ERR_ARG, "gsr_comm_share: both contexts must be on one device and of one size");
+    if (int r = comm_setup(c, "gsr_comm_share", leader->comm_rank, leader->comm_world, leader->comm_edges.x0, leader->comm_edges.x1, leader->comm_stream))
+        return r;
+    c->comm = leader->comm; c->comm_fn = leader->comm_fn; c->comm_fn_user = leader->comm_fn_user;
+    return GSR_OK;
+}
+
+int gsr_comm_init_custom(gsr_ctx* c, int32_t rank, int32_t world, const int32_t* x0, const int32_t* x1, gsr_allgather_fn fn, void* user)
+{
+    if (!c) return GSR_ERR_ARG;
+    if (!fn) return fail(c, GSR_ERR_ARG, "gsr_comm_init_custom: fn is NULL");
+    if (int r = comm_setup(c, "gsr_comm_init_custom", rank, world, x0, x1, nullptr)) return r;
+    c->comm_fn = fn; c->comm_fn_user = user;
     return GSR_OK;
 }
 
@@ -1396,7 +1438,7 @@ int gsr_comm_destroy(gsr_ctx* c)
 int gsr_allgather_frame_async(gsr_ctx* c)
 {
     if (!c) return GSR_ERR_ARG;
-    if (!c->comm) return fail(c, GSR_ERR_ARG, "gsr_allgather_frame_async: gsr_comm_init has not been called");
+    if (!c->comm && !c->comm_fn) return fail(c, GSR_ERR_ARG, "gsr_allgather_frame_async: gsr_comm_init has not been called");
     if (!c->have_frame) return fail(c, GSR_ERR_ARG, "gsr_allgather_frame_async: nothing rendered yet");
     HIP_TRY(c, hipSetDevice(c->device));
     // never ship a band the compositor did not draw: if the device has reported a list overflow, regrow and render
@@ -1410,7 +1452,12 @@ int gsr_allgather_frame_async(gsr_ctx* c)
     HIP_TRY(c, hipEventRecord(c->ev_packed, c->stream));
     // exchange stream: collective + de-slab, overlapping the next frame's kernels on the render stream
     HIP_TRY(c, hipStreamWaitEvent(c->comm_stream, c->ev_packed, 0));
-    RCCL_TRY(c, rccl().AllGather(c->slab, c->gathered, (size_t)c->slab_w * c->H * 4, ncclUint8, c->comm, c->comm_stream));
+    if (c->comm_fn) {
+        if (const int r = c->comm_fn(c->comm_fn_user, c->slab, c->gathered, (uint64_t)c->slab_w * c->H * 4, (void*)c->comm_stream))
+            return fail(c, GSR_ERR_COMM, "the custom all-gather returned %d", r);
+    } else {
+        RCCL_TRY(c, rccl().AllGather(c->slab, c->gathered, (size_t)c->slab_w * c->H * 4, ncclUint8, c->comm, c->comm_stream));
+    }
     HIP_TRY(c, hipEventRecord(c->ev_slab_free, c->comm_stream));
     launch_unpack_slabs_rgba8(c->gathered, c->frame8, c->W, c->H, c->slab_w, c->comm_world, c->comm_edges, c->comm_stream);
     HIP_TRY(c, hipGetLastError());
@@ -1423,6 +1470,19 @@ int gsr_read_frame_rgba8(gsr_ctx* c, uint8_t* out)
     if (!c || !out) return c ? fail(c, GSR_ERR_ARG, "out is NULL") : GSR_ERR_ARG;
     if (!c->frame8_valid) return fail(c, GSR_ERR_ARG, "gsr_read_frame_rgba8: no gathered frame yet (gsr_allgather_frame_async)");
     HIP_TRY(c, hipSetDevice(c->device));
+    // The band of the gathered frame was packed right behind a frame that the host had only enqueued: if that frame's lists did
+    // not fit, the compositor drew nothing and the band is the preceding image.  The device has said so by now: wait for
+    // the render stream, and if an overflow is pending (or frames were dropped and not reported yet) repair the context and
+    // refuse the frame instead of handing out a stale band.
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (overflow_pending(c) || c->dropped_unreported) {
+        if (int r = sync_and_repair(c)) return r;
+        HIP_TRY(c, hipStreamSynchronize(c->comm_stream));
+        c->dropped_unreported = 0;
+        c->frame8_valid = false;
+        return fail(c, GSR_ERR_OVERFLOW, "the gathered frame holds a band that was not composited (its bin lists did not fit); the lists "
+                                         "have been regrown: render and gather the frame again");
+    }
     HIP_TRY(c, hipMemcpyAsync(out, c->frame8, (size_t)c->W * c->H * 4, hipMemcpyDeviceToHost, c->comm_stream));
     HIP_TRY(c, hipStreamSynchronize(c->comm_stream));
     return GSR_OK;

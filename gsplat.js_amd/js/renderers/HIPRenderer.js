@@ -102,8 +102,11 @@ class HIPRenderer {
             }
             pushCamera();
             for (const p of passes) p.render();
-            if (group) {   // band frame + framebuffer all-gather, ordered on the device; readPixels() waits for it
-                this._n.renderAsync(this._h);
+            if (group) {
+                // band frame, then the framebuffer all-gather; readPixels() waits for the exchange.  The frame is rendered with
+                // the blocking call, which repairs a bin-list overflow (regrow + render again) before the band is packed:
+                // behind renderAsync the host would not know yet that the compositor drew nothing, and ship the old band.
+                this._n.render(this._h);
                 this._n.allgatherFrameAsync(this._h);
             } else {
                 this._n.render(this._h);

@@ -64,8 +64,9 @@ EXPORTS = [
     "gsr_framebuffer_device_ptr", "gsr_stream_handle", "gsr_stream_order", "gsr_device_info", "gsplat_sort_host",
     "gsr_overflow_pending", "gsr_set_list_capacity", "gsr_scene_count", "gsr_build_id",
     "gsr_comm_unique_id", "gsr_comm_init", "gsr_comm_destroy", "gsr_allgather_frame_async", "gsr_read_frame_rgba8",
-    "gsr_frame8_device_ptr", "gsr_comm_stream_handle", "gsr_read_work_items",
+    "gsr_frame8_device_ptr", "gsr_comm_stream_handle", "gsr_read_work_items", "gsr_comm_share", "gsr_comm_init_custom",
 ]
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p)
 GSR_COMM_ID_BYTES = 128
 
 
@@ -154,6 +155,9 @@ def load_library(path=None):
     L.gsr_build_id.restype = ctypes.c_char_p
     L.gsr_comm_unique_id.argtypes = [vp]
     L.gsr_comm_init.argtypes = [vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+    L.gsr_comm_share.argtypes = [vp, vp]
+    L.gsr_comm_init_custom.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
+                                       ALLGATHER_FN, vp]
     L.gsr_comm_destroy.argtypes = [vp]
     L.gsr_allgather_frame_async.argtypes = [vp]
     L.gsr_read_frame_rgba8.argtypes = [vp, vp]
@@ -540,6 +544,25 @@ class HIPRenderer:
         cid = (ctypes.c_uint8 * GSR_COMM_ID_BYTES).from_buffer_copy(bytes(comm_id))
         x0, x1 = edge_arrays(edges)
         self._check(self._L.gsr_comm_init(self._ctx, cid, rank, world, x0, x1))
+
+    def share_group(self, leader):
+        """This context (another frame in flight of the same rank) uses `leader`'s communicator and exchange stream."""
+        self._check(self._L.gsr_comm_share(self._ctx, leader._ctx))
+
+    def join_group_custom(self, rank, world, edges, allgather):
+        """Test hook (gsr_comm_init_custom): `allgather(send_ptr, recv_ptr, bytes_per_rank, stream)` replaces ncclAllGather."""
+        x0, x1 = edge_arrays(edges)
+
+        def _cb(user, send, recv, nbytes, stream):
+            try:
+                allgather(send, recv, int(nbytes), stream)
+                return 0
+            except Exception:      # never let an exception cross the C frame
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._allgather_cb = ALLGATHER_FN(_cb)   # keep the trampoline alive as long as the context
+        self._check(self._L.gsr_comm_init_custom(self._ctx, rank, world, x0, x1, self._allgather_cb, None))
 
     def leave_group(self):
         self._check(self._L.gsr_comm_destroy(self._ctx))

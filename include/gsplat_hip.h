@@ -212,8 +212,27 @@ int gsr_unpack_slabs_rgba8_async(gsr_ctx *ctx, const void *gathered, void *image
 #define GSR_COMM_ID_BYTES 128
 int gsr_comm_unique_id(uint8_t *id /* GSR_COMM_ID_BYTES */);
 int gsr_comm_init(gsr_ctx *ctx, const uint8_t *id, int32_t rank, int32_t world, const int32_t *x0, const int32_t *x1);
+/* A second (third, ...) context of the SAME rank -- frames in flight -- joins the group `leader` has joined: it uses
+ * leader's communicator and exchange stream (so a rank's collectives are issued on ONE stream, in the order of the
+ * gsr_allgather_frame_async calls, which must be the same on every rank) and gets its own slab and frame buffers.
+ * Several communicators per device with collectives in flight on different streams are the RCCL/NCCL case that can
+ * deadlock when the ranks' collectives are scheduled in different orders; this avoids it.  Destroy the sharing
+ * contexts (or gsr_comm_destroy them) before the leader. */
+int gsr_comm_share(gsr_ctx *ctx, gsr_ctx *leader);
+/* Test hook: gsr_comm_init with the caller's collective in place of ncclAllGather, for hosts that cannot form an RCCL
+ * communicator of more than one rank (RCCL refuses two ranks on one device) but want to run the exchange's choreography
+ * -- band pack, slab padding to the widest band, event ordering against the render stream, de-slab with unequal edges --
+ * with world > 1.  gsr_allgather_frame_async calls fn(user, send, recv, bytes_per_rank, stream) on the host in place of
+ * ncclAllGather: send = this rank's slab, recv = [world][bytes_per_rank], both device memory; work enqueued on `stream`
+ * (a hipStream_t, the exchange stream) before the call has packed the slab, work enqueued on it afterwards reads recv.
+ * fn may block.  Returns non-zero on failure.  No product path uses it. */
+typedef int (*gsr_allgather_fn)(void *user, const void *send, void *recv, uint64_t bytes_per_rank, void *stream);
+int gsr_comm_init_custom(gsr_ctx *ctx, int32_t rank, int32_t world, const int32_t *x0, const int32_t *x1, gsr_allgather_fn fn,
+                         void *user);
 int gsr_comm_destroy(gsr_ctx *ctx);
 int gsr_allgather_frame_async(gsr_ctx *ctx);
+/* Waits for the exchange AND for the render stream; returns GSR_ERR_OVERFLOW (after regrowing the lists) instead of a frame
+ * when the frame behind the gathered band did not fit its bin lists: render and gather it again. */
 int gsr_read_frame_rgba8(gsr_ctx *ctx, uint8_t *out /* w*h*4: the gathered frame */);
 void *gsr_frame8_device_ptr(gsr_ctx *ctx);    /* uint8[h][w][4], the gathered frame on the device */
 void *gsr_comm_stream_handle(gsr_ctx *ctx);   /* hipStream_t the exchange runs on */

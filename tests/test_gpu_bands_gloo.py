@@ -70,3 +70,82 @@ def test_two_rank_band_render_equals_full_frame(tmp_path, world):
     out = str(tmp_path / "result.txt")
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert open(out).read() == "ok"
+
+
+def _exchange_worker(rank, world, port, out):
+    """The LIBRARY's exchange (gsr_allgather_frame_async: pack -> collective -> de-slab, event-ordered against the render
+    stream) with world > 1 on one GPU: RCCL refuses two ranks per device, so the collective is injected
+    (gsr_comm_init_custom) as a host-staged gloo all-gather; everything around it is the product path.  Unequal
+    (cost-balanced) bands, two contexts per rank sharing the group (frames in flight), frames back to back; every rank
+    must read the single-context RGBA8 frame byte for byte through gsr_read_frame_rgba8.
+    (Reference entry that has to keep working on every rank: renderer.render(scene, camera),
+    src/renderers/WebGLRenderer.ts:241-296.)"""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "gsplat.js_amd", "py"))
+    import torch
+    import torch.distributed as dist
+    import gsplat_hip as gh
+    from gsplat_hip import bands
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = gh.synth.CONFIGS["C1"]
+        W, H = cfg["width"], cfg["height"]
+        scene = gh.Scene()
+        scene.setData(gh.synth.config_rows("C1"))
+        cams = [gh.orbit_camera(k, width=W, height=H, fx=cfg["fx"]) for k in (3, 38, 71, 104)]
+        # cost-balanced, hence unequal, edges from a calibration frame (the same on every rank)
+        cal = gh.HIPRenderer(W, H, device=0)
+        cal.render(scene, cams[0])
+        cost = cal.bin_totals().sum(axis=0) + 0.25 * 32 * H
+        edges = bands.balanced_edges(W, world, cost * np.linspace(1.0, 3.0, len(cost)))   # (skewed: the scene is symmetric)
+        assert len({b - a for a, b in edges}) > 1, edges
+        dev = torch.device("cuda:0")
+
+        def allgather(send, recv, nbytes, stream):
+            s = torch.cuda.ExternalStream(stream, device=dev)
+            s.synchronize()                                   # the band has been packed into the slab
+            mine = torch.as_tensor(bands.DevicePointer(send, (nbytes,), "|u1"), device=dev).cpu()
+            every = torch.empty(world * nbytes, dtype=torch.uint8)
+            dist.all_gather_into_tensor(every, mine)
+            with torch.cuda.stream(s):
+                torch.as_tensor(bands.DevicePointer(recv, (world * nbytes,), "|u1"), device=dev).copy_(every)
+            s.synchronize()
+
+        a = gh.HIPRenderer(W, H, device=0)      # (contexts of the same kind as `cal`: throughput contexts composite with the
+        b = gh.HIPRenderer(W, H, device=0)      #  other kernel, same pixels to f32 association, RGBA8 to a rounding step)
+        a.join_group_custom(rank, world, edges, allgather)
+        b.share_group(a)
+        for r in (a, b):
+            r.render(scene, cams[0])
+        frames = []
+        for k, cam in enumerate(cams):                         # frames back to back, alternating contexts, no host sync
+            r = (a, b)[k % 2]
+            r.set_camera(cam)
+            r.render_async()
+            r.allgather_frame_async()
+            if k >= 2:
+                frames.append((k, r.read_frame()))            # this context's newest frame
+        ok = True
+        for k, got in frames:
+            cal.render(scene, cams[k])
+            ok = ok and np.array_equal(got, cal.readPixels())
+        b.dispose(); a.dispose(); cal.dispose()
+        res = torch.tensor([1 if ok else 0])
+        dist.all_reduce(res, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            open(out, "w").write("ok" if int(res.item()) == 1 else "mismatch")
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_in_library_exchange_with_more_than_one_rank(tmp_path, world):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_exchange_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert open(out).read() == "ok"

@@ -859,6 +859,38 @@ def test_rccl_allgather_inside_the_library_single_rank(gh, scenes):
     r.dispose(); ref.dispose()
 
 
+def test_gathered_frame_is_refused_after_a_list_overflow(gh, scenes):
+    """A frame whose bin lists do not fit publishes no compositor work: the framebuffer keeps the preceding image.  When
+    such a frame was enqueued and gathered without a host sync in between, the gathered frame holds a stale band:
+    gsr_read_frame_rgba8 waits for the render stream, sees the overflow, regrows the lists and refuses the frame
+    (GSR_ERR_OVERFLOW) instead of returning it; gathering again gives the right frame."""
+    cfg = gh.synth.CONFIGS["C1"]
+    rows, data, pos = scenes("C1")
+    W, H = cfg["width"], cfg["height"]
+    ref = gh.HIPRenderer(W, H)
+    ref.set_raw_scene(data, pos)
+    r = gh.HIPRenderer(W, H)
+    r.set_raw_scene(data, pos)
+    r.join_group(gh.new_group_id(), 0, 1, [(0, W)])
+    r.set_camera(_camera(gh, 5, cfg))
+    r.render_async(); r.allgather_frame_async()
+    first = r.read_frame()
+    r.set_list_capacity(1024)                  # far too small for the next frame
+    cam = _camera(gh, 60, cfg)
+    r.set_camera(cam)
+    r.render_async()
+    r.allgather_frame_async()
+    with pytest.raises(gh.GsplatError, match="not composited"):
+        r.read_frame()
+    r.allgather_frame_async()                  # the lists have been regrown and the frame rendered again: gather it
+    got = r.read_frame()
+    ref.set_camera(cam)
+    ref.render_async(); ref.sync()
+    assert np.array_equal(got, ref.readPixels()) and not np.array_equal(got, first)
+    assert r.stats()["overflow_frames"] >= 1
+    r.dispose(); ref.dispose()
+
+
 @pytest.mark.parametrize("order", ["lsd", "bucket", "auto"])
 def test_sort_orders_give_the_same_permutation(gh, oracle, scenes, monkeypatch, order):
     """Two radix orders produce the reference's permutation: LSD (low 8 bits, then high 9: six launches) and bucket order
