@@ -6,7 +6,18 @@
 #include "gsr_internal.h"
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>   // types and constants only: the entry points are resolved with dlsym (gsr_comm_*)
+// RCCL: types and constants only -- the entry points are resolved with dlsym (gsr_comm_*), so the library loads on hosts
+// without RCCL; and it BUILDS without the header too: the handful of declarations the calls need are repeated here
+// (ABI of rccl.h / nccl.h 2.x: an opaque communicator pointer, a 128-byte id, enum values 0 = success, 1 = uint8).
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+typedef struct ncclComm* ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclUint8 = 1 } ncclDataType_t;
+#endif
 
 #include <algorithm>
 #include <cstdarg>

@@ -16,6 +16,7 @@
 #include "gsr_internal.h"
 
 #include <algorithm>
+#include <mutex>
 
 
 namespace gsr {
@@ -203,10 +204,15 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa, uint32
     const int b0 = threadIdx.x * per, b1 = min(b0 + per, nbins);
     // two sums in one pass: the frame's list entries, and the projection's optical-depth figure (slots [4]: opacity byte x
     // tiles / 16), which decides below whether this frame's work items are long
-    UN<2> ent = {{0, 0}}, ent_tot;
+    // (the optical-depth slots are summed as two 16-bit halves: a slot word holds up to 2^32 and there are 64 of them)
+    UN<3> ent = {{0, 0, 0}}, ent_tot;
     for (int b = b0; b < b1; b++) ent.v[0] += bin_total[b];
-    if (have_counts && threadIdx.x < FRAME_SLOTS) ent.v[1] = (uint32_t)slots[(size_t)threadIdx.x * FRAME_SLOT_WORDS + 4];
-    block_exclusive_scan<2>(ent, s_w, &ent_tot);
+    if (have_counts && threadIdx.x < FRAME_SLOTS) {
+        const uint32_t od = (uint32_t)slots[(size_t)threadIdx.x * FRAME_SLOT_WORDS + 4];
+        ent.v[1] = od & 0xffffu; ent.v[2] = od >> 16;
+    }
+    block_exclusive_scan<3>(ent, s_w, &ent_tot);
+    const uint64_t optical = ((uint64_t)ent_tot.v[2] << 16) + ent_tot.v[1];
     // Long work items where the frame saturates (gsr_api.cpp, "Work-item length"): the frame's optical depth
     // tau = sum(opacity x tiles) x 256 / pixels from the projection's slots ([4] holds opacity byte x tiles / 16)
     // frame counters: the projection's visible-splat and tile-overlap sums (scans of two or three streams keep this
@@ -222,7 +228,7 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa, uint32
     // dense enough to saturate: optical depth, and (one frame at a time, where the long items are the frame's tail) splats
     // that cover several tiles each -- small splats take many more entries to saturate a pixel (the C2 generator at
     // 1.6 M splats: tau 394, 3.6 tiles per splat, long items 8 % slower; C3: 5.3 tiles per splat, 23 % faster)
-    const bool dense = (uint64_t)ent_tot.v[1] * (16u * 256u) >= (uint64_t)fa.long_tau * 255u * (uint64_t)fa.npix &&
+    const bool dense = optical * (16u * 256u) >= (uint64_t)fa.long_tau * 255u * (uint64_t)fa.npix &&
                        (uint64_t)ctot.v[1] * 2u >= (uint64_t)fa.long_tiles_x2 * ctot.v[0];
     // How a dense frame is cut (gsr_api.cpp, "Work-item length"):
     //  * speculative segments (fa.spec, needs the arrival masks): the SAME cut as a frame that does not saturate -- plain
@@ -598,16 +604,19 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
     const bool eight = scatter_lds_bytes(sl.w, sl.h, 8) <= SCAT_LDS_TWO_PER_CU;
     // (the finalize step, when it runs as this kernel's extra workgroup, uses FIN_SCRATCH_WORDS of the dynamic LDS)
     const size_t lds = std::max(scatter_lds_bytes(sl.w, sl.h, eight ? 8 : 4), FIN_SCRATCH_WORDS * sizeof(uint32_t));
-    // dynamic LDS above the 64 KiB default needs the attribute raised (4K: 8160 bins -> 146 KiB).  Set per call:
-    // the attribute belongs to the current device's copy of the kernel, and this is off the per-frame fast path
-    // for the common sizes (1080p needs 64 KiB).
-    if (lds > 60 * 1024) {
-        const int want = (int)std::min<size_t>(lds + 1024, 160 * 1024 - 256);
-        const bool fz = n && nbins <= 4096;
-        const void* fn = eight ? (fz ? (const void*)k_bin_scatter<8, true> : (const void*)k_bin_scatter<8, false>)
-                               : (fz ? (const void*)k_bin_scatter<4, true> : (const void*)k_bin_scatter<4, false>);
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess)
-            (void)hipGetLastError();  // the launch below then reports the real failure
+    // dynamic LDS above the default needs the attribute raised (1080p: 64 KiB, 4K: 8160 bins -> 146 KiB).  The attribute
+    // belongs to the current device's copy of each instantiation: raised to the budget once per device for all four.
+    {
+        static std::once_flag once[64];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::call_once(once[dev >= 0 && dev < 64 ? dev : 0], [] {
+            const int want = (int)(SCAT_LDS_BUDGET + 1024);
+            for (const void* fn : {(const void*)k_bin_scatter<8, true>, (const void*)k_bin_scatter<8, false>,
+                                   (const void*)k_bin_scatter<4, true>, (const void*)k_bin_scatter<4, false>})
+                (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, want);
+            (void)hipGetLastError();  // a failure shows up as the launch error
+        });
     }
     // the count pass keeps one counter per bin in LDS and is cut into row slices only beyond 12288 bins (above 4K)
     const int cnt_slices = (nbins + CNT_MAX_BINS - 1) / CNT_MAX_BINS;

@@ -12,6 +12,8 @@
 // must match the reference bit for bit).
 #include "gsr_internal.h"
 
+#include <mutex>
+
 namespace gsr {
 
 constexpr int SORT_THREADS = 256;
@@ -529,10 +531,11 @@ void launch_sort(const SortBuffers& b, uint32_t n, hipStream_t s)
     const size_t lds_lo = scatter_lds_bytes<RADIX_LO_BITS>(b.keys_per_block), lds_hi = scatter_lds_bytes<RADIX_HI_BITS>(b.keys_per_block);
     {   // the last pass needs more than the default 48 KiB of dynamic LDS even at 2048 keys: raise the limit once per
         // device (the attribute belongs to the device's copy of the kernel), to what the largest block size needs
-        static unsigned done_mask = 0;
+        // (contexts on different host threads may arrive here together: one flag per device, set exactly once)
+        static std::once_flag once[64];
         int dev = 0;
         (void)hipGetDevice(&dev);
-        if (dev >= 0 && dev < 32 && !(done_mask & (1u << dev))) {
+        std::call_once(once[dev >= 0 && dev < 64 ? dev : 0], [] {
             (void)hipFuncSetAttribute((const void*)k_scatter<RADIX_LO_BITS, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)scatter_lds_bytes<RADIX_LO_BITS>(SCAT_THREADS * SCAT_MAX_STEPS));
             (void)hipFuncSetAttribute((const void*)k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -540,8 +543,7 @@ void launch_sort(const SortBuffers& b, uint32_t n, hipStream_t s)
             (void)hipFuncSetAttribute((const void*)k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)scatter_lds_bytes<RADIX_HI_BITS>(SCAT_THREADS * SCAT_MAX_STEPS));
             (void)hipGetLastError();   // a failure shows up as the launch error
-            done_mask |= 1u << dev;
-        }
+        });
     }
     if (b.bucket_order) {
         // bucket order: partition by the high 9 bits, then one workgroup per bucket sorts by the low 8 (k_local_sort)

@@ -61,12 +61,14 @@ typedef struct gsr_options {
 
 #define GSR_FLAG_TIMING 1   /* record HIP events around every stage (gsr_get_timings) */
 #define GSR_FLAG_THROUGHPUT 2 /* the caller keeps several frames in flight on this device (one
-                               context per frame): the compositor then cuts a frame into ~1300
-                               work items instead of ~5000 (2048 list entries per item instead of
-                               512 on a 1 M-splat 1080p frame) and launches 6 instead of 7
-                               persistent workgroups per CU, because the other contexts' kernels,
-                               not extra segments of this frame, fill the GPU.  Same pixels within
-                               float rounding (the segments are combined associatively). */
+                               context per frame): the other contexts' kernels, not extra pieces of
+                               this frame, fill the GPU.  The compositor then cuts a frame into ~1300
+                               work items instead of ~5000 and gives every 16x16 tile one wave
+                               (k_blend, 7 four-wave workgroups per CU); without the flag a context
+                               renders one frame at a time and, up to 4096 bins, gives every tile two
+                               waves (k_blend2, 3 eight-wave workgroups per CU), which halves the
+                               serial walk that bounds a lone frame.  Same pixels within float
+                               rounding (pieces are combined associatively). */
 
 /* Per-stage device times of the last completed gsr_render / gsr_sort, measured
  * with HIP events on the context's stream, plus the frame's list sizes. */
