@@ -113,6 +113,20 @@ __device__ __forceinline__ uint32_t xcd_group_remap(uint32_t bid, uint32_t nwg)
     return (bid - in) + (in % 8u) * RUN + in / 8u;
 }
 #endif
+// -DGSR_BOUNDS (diagnostic build, scripts/build_exp.sh bounds "-DGSR_BOUNDS"; tests/test_gpu_bounds.py runs the parity tests'
+// frames on it): every index the kernels derive from device data -- list entries, splat indices, slots, LDS cells -- is
+// checked against the extent of what it indexes; a violation is counted per site in the translation unit's g_bounds[]
+// (gsr_debug_bounds_*), never trapped: a faulting kernel can take the whole node down.  The stand-in for the GPU
+// sanitizers this pool does not offer.  Nothing of it is compiled into the shipped library.
+#ifdef GSR_BOUNDS
+#define GSR_BOUNDS_DECL(name) __device__ unsigned int g_bounds_##name[8];                                             \
+    extern "C" int gsr_debug_bounds_##name(unsigned int* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bounds_##name), sizeof g_bounds_##name) == hipSuccess ? 0 : -1; }
+#define GSR_BOUND(name, site, idx, limit) do { if (!((unsigned long long)(idx) < (unsigned long long)(limit))) atomicAdd(&g_bounds_##name[site], 1u); } while (0)
+#else
+#define GSR_BOUNDS_DECL(name)
+#define GSR_BOUND(name, site, idx, limit) do { } while (0)
+#endif
+
 // Compositor work items: bin | segment << 16.  Segment codes from ITEM_TILE0 on mean "the whole (single-segment) bin, but
 // only its 16x16 tile code - ITEM_TILE0": a heavy bin handed to four workgroups, one 8x8 quadrant per wave (k_blend).
 constexpr uint32_t ITEM_TILE0 = 0xfff0u;

@@ -31,6 +31,7 @@ extern "C" int gsr_debug_bin_stamps(unsigned int* out) { return hipMemcpyFromSym
 #define KSTAMP(slot)
 #endif
 
+GSR_BOUNDS_DECL(bin)   // sites: 0 splat index of a rank, 1 rectangle inside the bin grid, 2 LDS cell of the scatter, 3 table row, 4 count cell
 constexpr int BIN_THREADS = 256;
 constexpr int BIN_STEPS = 8;                                  // 64-rank steps per wave
 constexpr uint32_t BIN_RANKS_PER_BLOCK = BIN_THREADS * BIN_STEPS;  // 2048
@@ -80,6 +81,13 @@ __global__ __launch_bounds__(CNT_THREADS) void k_bin_count(const uint32_t* __res
     }
 #pragma unroll
     for (int st = 0; st < CNT_STEPS; st++) rc[st] = (idx[st] != 0xffffffffu) ? rect_idx[idx[st]] : RECT_NONE;
+#ifdef GSR_BOUNDS
+#pragma unroll
+    for (int st = 0; st < CNT_STEPS; st++) {
+        const BinRect bq = unpack_rect(rc[st]);
+        if (bq.x0 <= bq.x1) { GSR_BOUND(bin, 1, bq.x1, nbxb); GSR_BOUND(bin, 1, bq.y1, g.nby); GSR_BOUND(bin, 1, bq.y0, bq.y1 + 1); }
+    }
+#endif
     if (blockIdx.y == 0) {   // slice 0 also leaves the rectangles in depth order
 #pragma unroll
         for (int st = 0; st < CNT_STEPS; st++) {
@@ -92,7 +100,10 @@ __global__ __launch_bounds__(CNT_THREADS) void k_bin_count(const uint32_t* __res
         const BinRect br = unpack_rect(rc[st]);
         if (br.x0 <= br.x1)
             for (int y = max(br.y0, y_lo); y <= min(br.y1, y_hi - 1); y++)
-                for (int x = br.x0; x <= br.x1; x++) atomicAdd(&s_cnt[(y - y_lo) * nbxb + x], 1u);
+                for (int x = br.x0; x <= br.x1; x++) {
+                    GSR_BOUND(bin, 4, (y - y_lo) * nbxb + x, nb_s);
+                    atomicAdd(&s_cnt[(y - y_lo) * nbxb + x], 1u);
+                }
     }
     __syncthreads();
     for (int b = threadIdx.x; b < nb_s; b += CNT_THREADS) table[(size_t)blockIdx.x * nbins + y_lo * nbxb + b] = s_cnt[b];
@@ -505,6 +516,7 @@ __global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(8,
         for (int b = threadIdx.x; b < nb_s; b += SCAT_THREADS) {
             const int ly = b / sw, lx = b - ly * sw;
             const int gb = (sy0 + ly) * nbxb + sx0 + lx;  // the bin's index in the band
+            GSR_BOUND(bin, 3, blk, gridDim.x);
             base[b] = bin_start[gb] + table[(size_t)blk * nbins + gb];
         }
     } else {
@@ -542,7 +554,10 @@ __global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(8,
         for (int x = b.x0; x <= b.x1; x++) atomicOr(&colm[x], mybit);
         for (int y = b.y0; y <= b.y1; y++) {
             if (b.x0 <= b.x1) atomicOr(&rowm[y], mybit);
-            for (int x = b.x0; x <= b.x1; x++) atomicAdd(&mypair[y * sw + x], one);
+            for (int x = b.x0; x <= b.x1; x++) {
+                GSR_BOUND(bin, 2, y * sw + x, nb_s);
+                atomicAdd(&mypair[y * sw + x], one);
+            }
         }
     }
     __syncthreads();
@@ -584,6 +599,7 @@ __global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(8,
                     else own = m;
                 }
                 dst += lanes_below64(own);
+                GSR_BOUND(bin, 0, myidx, 0xfffffff0u);
                 if (dst < capacity) list[dst] = myidx;
                 else atomicOr(overflow, 1u);
             }

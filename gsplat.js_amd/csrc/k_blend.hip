@@ -38,6 +38,7 @@
 
 namespace gsr {
 
+GSR_BOUNDS_DECL(blend)   // sites: 0 work item's bin, 1 its segment, 2 list position, 3 splat index in the list, 4 item range inside the bin
 constexpr int BLEND_THREADS = 256;
 constexpr int CHUNK = BLEND_THREADS;
 constexpr int BIN_PIXELS = BIN_PX * BIN_PX;
@@ -139,6 +140,8 @@ __device__ __forceinline__ void blend_body(const uint32_t* __restrict__ items,
         const uint32_t seg = tile_item ? 0u : it >> 16;
         const int tile = tile_item ? (int)((it >> 16) - ITEM_TILE0) : wave;
         const uint32_t nseg = seg_start[bin + 1] - seg_start[bin];
+        GSR_BOUND(blend, 0, bin, nbxb * g.nby);
+        GSR_BOUND(blend, 1, seg, nseg);
         const int by = bin / nbxb, bxl = bin - by * nbxb;
         const int binX0 = (g.bx_lo + bxl) * BIN_PX, binY0 = by * BIN_PX;
         const int ox = (tile & 1) * TILE + (tile_item ? (wave & 1) * 8 : 0), oy = (tile >> 1) * TILE + (tile_item ? (wave >> 1) * 8 : 0);
@@ -162,6 +165,8 @@ __device__ __forceinline__ void blend_body(const uint32_t* __restrict__ items,
         // only long items test for saturation while they run, and only where the transmittance is the true one: whole bins
         // and a bin's first segment (later segments start from 1 and find out through the folded prefixes, below)
         const bool sat_item = saturate != 0u && seg == 0u && end - begin > 2u * CHUNK;
+        GSR_BOUND(blend, 4, end, (unsigned long long)bin_end + 1ull);
+        GSR_BOUND(blend, 4, begin, (unsigned long long)end + 1ull);
         // quadrants of mine that can still change (wave-uniform); see the saturation test below.  Quadrants that lie outside
         // the image (the last bin row of 1080p: rows 1080..1087) never could: their pixels are not stored.
         uint32_t alive0 = 0;
@@ -254,6 +259,8 @@ __device__ __forceinline__ void blend_body(const uint32_t* __restrict__ items,
             const uint32_t e = base + slot;
             uint32_t mask = 0;
             if (e < end) {
+                GSR_BOUND(blend, 2, e, capacity);
+                GSR_BOUND(blend, 3, list[e], nsplats);
                 const uint32_t i = min(list[e], nsplats - 1u);
                 const float4* rp = reinterpret_cast<const float4*>(rec + i);
                 const float4 ra = rp[0], rb = rp[1];

@@ -16,6 +16,7 @@
 
 namespace gsr {
 
+GSR_BOUNDS_DECL(sort)   // sites: 0 destination of a radix pass, 1 its LDS position, 2 destination of the bucket sort, 3 key above 65536
 constexpr int SORT_THREADS = 256;
 
 #ifdef GSR_KSTAMPS
@@ -358,6 +359,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter(const uint32_t* __rest
         __builtin_amdgcn_wave_barrier();
         if (valid) {
             const uint32_t p = lstart[digit] + before + rank;
+            GSR_BOUND(sort, 1, p, keys_per_block);
             lkey[p] = key[k];
             lidx[p] = src[k];
         }
@@ -368,6 +370,8 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter(const uint32_t* __rest
     for (uint32_t p = threadIdx.x; p < nlocal; p += SCAT_THREADS) {
         const uint32_t kv = lkey[p];
         const uint32_t dst = gdelta[(kv >> SHIFT) & (BINS - 1)] + p;
+        GSR_BOUND(sort, 0, dst, n);
+        GSR_BOUND(sort, 3, kv, DEPTH_RANGE + 1u);
         if (keys_out) keys_out[dst] = kv;
         idx_out[dst] = lidx[p];
     }
@@ -518,7 +522,10 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint32_t* __
         if (valid && rank == 0) wc[digit] = earlier + (uint32_t)__popcll(m);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
-        if (valid) depth_index[s0 + tot[digit] + earlier + rank] = src[k];
+        if (valid) {
+            GSR_BOUND(sort, 2, tot[digit] + earlier + rank, sz);
+            depth_index[s0 + tot[digit] + earlier + rank] = src[k];
+        }
     }
 }
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc counter_collection.csv files: per kernel, median counter value per dispatch.
-  python scripts/pmc_summary.py [gpurun_out/pmc] [leg]     leg = solo | inflight (scripts/gpu_pmc.sh), default solo"""
+  python scripts/pmc_summary.py [gpurun_out/pmc] [leg]     leg = solo | inflight (scripts/gpu.sh pmc), default solo"""
 import csv
 import glob
 import sys
