@@ -490,7 +490,7 @@ def main():
         b_sort = 52.0 * N
         b_proj = 16.0 * N + 48.0 * V
         b_bin = 8.0 * D
-        # HBM traffic and VALU instruction counts of k_blend come from rocprofv3 --pmc passes (scripts/gpu_pmc.sh ->
+        # HBM traffic and VALU instruction counts of k_blend come from rocprofv3 --pmc passes (scripts/gpu.sh pmc ->
         # profiles/blend_traffic.json).  They describe ONE build of the kernels: the file carries the build id it was
         # measured on, and a library with another id gets null rather than a stale figure.
         traffic = valu = traffic_solo = valu_solo = None

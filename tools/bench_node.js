@@ -3,7 +3,7 @@
 // Frames per second through the JavaScript host -- the reference's own calling convention, renderer.render(scene, camera)
 // (WebGLRenderer.ts:241-296), one synchronous frame after the other -- and with three renderers used round-robin
 // (renderAsync / sync, what bench.py's default measures through ctypes).  The scene is a .splat file (32-byte rows);
-// scripts/gpu_bench_node.sh writes the synthetic C3 scene with the Python generator first.
+// scripts/final_lines.sh writes the synthetic C3 scene with the Python generator first.
 //   node tools/bench_node.js <scene.splat> <W> <H> <fx> [frames] [warmup]
 // prints one JSON line.
 const path = require("path");
