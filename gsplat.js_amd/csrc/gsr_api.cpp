@@ -84,7 +84,10 @@ struct gsr_ctx {
     uint32_t* rect_idx = nullptr; // per splat: packed bin rectangle (k_project_key); bin_rects holds them in depth order
     uint32_t sort_blocks = 0, sort_kpb = 0;
     // binning
-    uint32_t *bin_table = nullptr, *bin_total = nullptr, *bin_start = nullptr, *bin_list = nullptr;
+    uint32_t *bin_table = nullptr, *bin_total = nullptr, *bin_start = nullptr, *bin_start_pre = nullptr, *bin_list = nullptr;
+    uint32_t bin_rounds = 1;          // rounds of 2048 ranks per binning workgroup (alloc_bins; GSR_BIN_ROUNDS)
+    long bin_rounds_env = 0;
+    bool bin_big = true;              // large bin grids: k_bin_scatter_big (GSR_BIN_BIG=0: the 64-register kernel + k_bin_finalize)
     uint32_t *seg_start = nullptr, *items = nullptr;
     unsigned long long* bin_mask = nullptr;   // per-bin arrival masks of the compositor (null: separate k_combine launch)
     uint32_t* bin_sat = nullptr;              // per-bin "saturated in front of segment ..." words, with bin_mask
@@ -232,6 +235,7 @@ constexpr uint32_t BLEND_WG_PER_CU_THROUGHPUT = 7;
 // Two waves per tile (k_blend2, 512-thread workgroups): three workgroups per CU are resident (6 waves per SIMD).
 constexpr uint32_t BLEND_WG_PER_CU_SUB2 = 3;
 constexpr uint32_t SUB2_MAX_BINS = 4096, SEG_LEN_MIN_SUB2 = 1024;
+constexpr uint32_t BIN_BLOCKS_TARGET = 640, BIN_ROUNDS_MAX = 8;
 constexpr uint32_t SEG_LEN_WHOLE_BIN = 0x7fffff00u;
 
 // Sort order.  Up to BUCKET_ORDER_MAX_N splats the radix sort runs high digit first with one workgroup per bucket
@@ -276,7 +280,14 @@ int alloc_bins(gsr_ctx* c)
     if (!c->W) return GSR_OK;
     const BinGrid g = make_grid(c);
     const uint32_t nbins = (uint32_t)((g.bx_hi - g.bx_lo) * g.nby);
-    c->bin_blocks = (c->n + 2047) / 2048;
+    // Ranks per binning workgroup: rounds of 2048.  The count / scan / scatter passes exchange a [workgroup][bin] table; with
+    // one round per workgroup it is 80 MB at 5 M splats and 8160 bins.  Large grids (the k_bin_scatter_big form, > 4096 bins)
+    // take several rounds per workgroup, keeping about BIN_BLOCKS_TARGET workgroups (C4: 4 rounds, 611 workgroups, 20 MB).
+    c->bin_rounds = 1;
+    if (c->bin_big && nbins > 4096)
+        c->bin_rounds = std::min<uint32_t>(BIN_ROUNDS_MAX, std::max<uint32_t>(1u, ((c->n + 2047u) / 2048u + BIN_BLOCKS_TARGET - 1u) / BIN_BLOCKS_TARGET));
+    if (c->bin_big && nbins > 4096 && c->bin_rounds_env > 0) c->bin_rounds = (uint32_t)c->bin_rounds_env;
+    c->bin_blocks = (c->n + 2048u * c->bin_rounds - 1u) / (2048u * c->bin_rounds);
     const size_t table = (size_t)std::max(c->bin_blocks, 1u) * nbins;
     if (table > c->bin_table_elems) {
         if (int r = dev_alloc(c, &c->bin_table, table)) return r;
@@ -286,6 +297,7 @@ int alloc_bins(gsr_ctx* c)
     if (nbins > c->bin_nbins_alloc) {
         if (int r = dev_alloc(c, &c->bin_total, nbins)) return r;
         if (int r = dev_alloc(c, &c->bin_start, nbins + 1)) return r;
+        if (int r = dev_alloc(c, &c->bin_start_pre, nbins + 1)) return r;
         if (int r = dev_alloc(c, &c->seg_start, nbins + 1)) return r;
         if (c->fuse_combine) {
             if (int r = dev_alloc(c, &c->bin_mask, nbins)) return r;
@@ -381,7 +393,7 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
         const BinGrid g = make_grid(c);
         const int nbins = (g.bx_hi - g.bx_lo) * g.nby;
         if (!c->n) HIP_TRY(c, hipMemsetAsync(c->bin_total, 0, sizeof(uint32_t) * nbins, s));
-        BinBuffers bb{c->depth_index, &c->fstate->sorted_count, c->bin_table, c->slots, c->rect_idx, c->bin_rects, c->bin_total, c->bin_start, c->seg_start,
+        BinBuffers bb{c->depth_index, &c->fstate->sorted_count, c->bin_table, c->slots, c->rect_idx, c->bin_rects, c->bin_total, c->bin_start, c->bin_start_pre, c->bin_rounds, c->bin_big ? 1u : 0u, c->seg_start,
                       c->items, c->bin_list, &c->fstate->overflow, &c->fstate->visible, &c->fstate->tile_entries,
                       c->accum, c->mailbox_dev, c->fstate->report, c->bin_capacity, c->max_items, c->seg_len, &c->fstate->seg_len, c->items_by_size, &c->fstate->queue, std::min<uint32_t>(c->max_items, c->blend_grid), c->seg_target_items, c->bin_blocks, c->bin_mask, c->bin_sat,
                       c->seg_len == SEG_LEN_WHOLE_BIN ? 0 : c->long_items >= 0 ? c->long_items : c->saturate ? -1 : 0, SEG_LEN_LONG,
@@ -422,7 +434,7 @@ static std::vector<uint64_t> chain_signature(const gsr_ctx* c)
     P(c->rec); P(c->bbox); P(c->slots); P(c->rect_idx); P(c->bin_table); P(c->bin_rects); P(c->bin_total); P(c->bin_start); P(c->seg_start); P(c->bin_mask); P(c->bin_sat);
     P(c->items); P(c->bin_list); P(c->partial); P(c->fb); P(c->accum); P(c->cam_dev);
     U(c->n); U((uint64_t)c->W); U((uint64_t)c->H); U((uint64_t)g.bx_lo); U((uint64_t)g.bx_hi); U(c->sort_kpb); U(c->sort_blocks);
-    U(c->bin_capacity); U(c->max_items); U(c->seg_len); U(c->seg_target_items); U(c->blend_grid); U(c->bin_blocks);
+    U(c->bin_capacity); U(c->max_items); U(c->seg_len); U(c->seg_target_items); U(c->blend_grid); U(c->bin_blocks); U(c->bin_rounds); U(c->bin_big ? 1u : 0u); P(c->bin_start_pre);
     U((uint64_t)c->opt.flags); U((uint64_t)(c->opt.early_out_eps * 1e9f)); U(c->bucket_order_now ? 1u : 0u); U(c->saturate ? 1u : 0u); U((uint64_t)c->items_by_size); U(c->quad_from); U((uint64_t)(int64_t)c->long_items);
     U((uint64_t)c->spec); U(c->blend_sub);
     return v;
@@ -629,6 +641,8 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
     if (const char* e = getenv("GSR_QUAD_FROM")) c->quad_from = (uint32_t)std::max(0L, atol(e));
     if (const char* e = getenv("GSR_LONG_ITEMS")) c->long_items = atoi(e) != 0 ? 1 : 0; // pins the work-item length policy
     if (const char* e = getenv("GSR_SPEC")) c->spec = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("GSR_BIN_ROUNDS")) c->bin_rounds_env = std::min(64L, std::max(0L, atol(e)));
+    if (const char* e = getenv("GSR_BIN_BIG")) c->bin_big = atoi(e) != 0;
     if (const char* e = getenv("GSR_BLEND_SUB")) c->blend_sub_env = atoi(e) == 2 ? 2 : atoi(e) == 1 ? 1 : 0;
     CREATE_TRY(hipMalloc((void**)&c->accum, 8 * sizeof(uint64_t)));
     CREATE_TRY(hipMemset(c->accum, 0, 8 * sizeof(uint64_t)));
@@ -673,7 +687,7 @@ int gsr_destroy(gsr_ctx* c)
     dev_free(&c->rotv); dev_free(&c->sclv);
     dev_free(&c->depth); dev_free(&c->keys); dev_free(&c->keys_tmp); dev_free(&c->idx_tmp); dev_free(&c->depth_index);
     dev_free(&c->block_hist); dev_free(&c->rec); dev_free(&c->bbox); dev_free(&c->slots); dev_free(&c->rect_idx);
-    dev_free(&c->bin_table); dev_free(&c->bin_total); dev_free(&c->bin_start); dev_free(&c->bin_list);
+    dev_free(&c->bin_table); dev_free(&c->bin_total); dev_free(&c->bin_start); dev_free(&c->bin_start_pre); dev_free(&c->bin_list);
     dev_free(&c->seg_start); dev_free(&c->bin_mask); dev_free(&c->bin_sat); dev_free(&c->items); dev_free(&c->partial); dev_free(&c->bin_rects);
     drop_graph(c);
     dev_free(&c->cam_dev);
@@ -860,7 +874,7 @@ int gsr_scene_limit_box(gsr_ctx* c, const double* box, uint32_t* new_count)
             if (e != hipSuccess) return fail(c, GSR_ERR_HIP, "limitBox failed: %s", hipGetErrorString(e));
         c->n = kept;   // arrays keep their old capacity; per-frame buffers sized for the old count still fit
         c->sort_blocks = (kept + c->sort_kpb - 1) / c->sort_kpb;
-        c->bin_blocks = (kept + 2047) / 2048;
+        c->bin_blocks = (kept + 2048u * c->bin_rounds - 1u) / (2048u * c->bin_rounds);
         // The compaction renumbers the splats, so SH rows (indexed by splat - (bandsIndices[0] + 1)) and the band
         // thresholds no longer belong to them: the SH state is dropped and the scene falls back to its rgba8 colours
         // until gsr_set_scene_sh is called again.  (Scene.limitBox, Scene.ts:307-366, leaves shs_rgb / bandsIndices

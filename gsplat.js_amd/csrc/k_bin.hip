@@ -63,7 +63,7 @@ constexpr int CNT_MAX_BINS = 12288;  // LDS counters per workgroup (48 KiB); lar
 
 __global__ __launch_bounds__(CNT_THREADS) void k_bin_count(const uint32_t* __restrict__ depth_index, const uint32_t* __restrict__ rect_idx,
                                                            const uint32_t* __restrict__ count, BinGrid g, int slice_rows,
-                                                           uint32_t* __restrict__ table, uint32_t* __restrict__ rects)
+                                                           uint32_t rounds, uint32_t* __restrict__ table, uint32_t* __restrict__ rects)
 {
     const uint32_t n = *count;  // ranks the sort produced (all splats, or the band's survivors)
     extern __shared__ uint32_t s_cnt[];  // this slice's bins
@@ -72,7 +72,11 @@ __global__ __launch_bounds__(CNT_THREADS) void k_bin_count(const uint32_t* __res
     const int nb_s = (y_hi - y_lo) * nbxb;
     for (int b = threadIdx.x; b < nb_s; b += CNT_THREADS) s_cnt[b] = 0;
     __syncthreads();
-    const uint32_t begin = blockIdx.x * BIN_RANKS_PER_BLOCK;
+    // a workgroup takes `rounds` rounds of 2048 consecutive ranks into the same counters: one table row per workgroup, so
+    // that a large frame's [workgroup][bin] table stays small (launch_bin)
+    for (uint32_t rd = 0; rd < rounds; rd++) {
+    const uint32_t begin = (blockIdx.x * rounds + rd) * BIN_RANKS_PER_BLOCK;
+    if (begin >= n) break;
     uint32_t idx[CNT_STEPS], rc[CNT_STEPS];
 #pragma unroll
     for (int st = 0; st < CNT_STEPS; st++) {
@@ -105,6 +109,7 @@ __global__ __launch_bounds__(CNT_THREADS) void k_bin_count(const uint32_t* __res
                     atomicAdd(&s_cnt[(y - y_lo) * nbxb + x], 1u);
                 }
     }
+    }   // rounds
     __syncthreads();
     for (int b = threadIdx.x; b < nb_s; b += CNT_THREADS) table[(size_t)blockIdx.x * nbins + y_lo * nbxb + b] = s_cnt[b];
 }
@@ -437,28 +442,55 @@ inline BinSlices make_slices(int nbxb, int nby)
         }
 }
 
-// (8 waves per SIMD = 64 VGPRs: two of these 16-wave workgroups per CU.  The scatter path needs 46; the finalize step,
-// built for one workgroup, wants 104 and spills a little in its one workgroup instead of halving everybody's occupancy.)
-// FUSED (small bin grids): the finalize step runs as an extra workgroup of this kernel and every scatter workgroup scans
-// the bin totals itself -- C3: binning 61.3 -> 56.5 us.  Large grids (4K: 8160 bins) keep the stand-alone finalize
-// kernel and read its bin_start[]: there the 2442 redundant scans cost more than the launch they save (C4: +38 us).
-template <int GROUPS, bool FUSED>
-__global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bin_scatter(const uint32_t* __restrict__ depth_index,
+// bin_start_pre = exclusive scan of the bin totals, for the scatter workgroups of large bin grids (the finalize step, which
+// computes the same starts among much else, runs beside them as the scatter kernel's extra workgroup)
+__global__ __launch_bounds__(FIN_THREADS) void k_bin_starts(const uint32_t* __restrict__ bin_total, int nbins, uint32_t* __restrict__ bin_start_pre)
+{
+    __shared__ uint32_t s_w[1][FIN_WAVES];
+    const int per = (nbins + FIN_THREADS - 1) / FIN_THREADS;
+    const int b0 = threadIdx.x * per, b1 = min(b0 + per, nbins);
+    UN<1> mine = {{0}}, tot;
+    for (int b = b0; b < b1; b++) mine.v[0] += bin_total[b];
+    uint32_t run = block_exclusive_scan<1>(mine, s_w, &tot).v[0];
+    for (int b = b0; b < b1; b++) {
+        bin_start_pre[b] = run;
+        run += bin_total[b];
+    }
+    if (threadIdx.x == 0) bin_start_pre[nbins] = tot.v[0];
+}
+
+// The scatter body.  Two kernels wrap it (below):
+//  * k_bin_scatter<GROUPS, FUSED>, 64 registers = 8 waves per SIMD, two of these 16-wave workgroups per CU.  FUSED (small
+//    bin grids): the finalize step runs as an extra workgroup and every scatter workgroup scans the bin totals itself --
+//    C3: binning 61.3 -> 56.5 us (the finalize step, built for one workgroup, wants 104 registers and spills a little in
+//    its one workgroup instead of halving everybody's occupancy); !FUSED: the stand-alone k_bin_finalize has run and
+//    published bin_start[].
+//  * k_bin_scatter_big<GROUPS> (BIG), the large-grid form (4K: 8160 bins, 146 KiB of LDS, so one workgroup per CU whatever
+//    its registers): 128 registers.  That budget is what lets it (a) run the finalize step as its FIRST workgroup (as the
+//    last of 600+ it would start when the others end) with the bin starts coming from the one-workgroup k_bin_starts in
+//    front -- k_bin_finalize's 28 us leave the chain -- and (b) take several ROUNDS of 2048 ranks per workgroup, base[]
+//    carrying over, so that the [workgroup][bin] table all three binning kernels exchange is 20 MB instead of 80 MB at
+//    5 M splats (more than the lists it helps to build).  Inside the 64-register kernel the same two things spilled 15 and
+//    44 registers and cost more than they saved (C4 binning 477 -> 533 us, profiles/r03_experiments.txt).
+template <int GROUPS, bool FUSED, bool BIG>
+__device__ __forceinline__ void bin_scatter_body(const uint32_t* __restrict__ depth_index,
                                                               const uint32_t* __restrict__ rects,
                                                               const uint32_t* __restrict__ count, BinGrid g, BinSlices sl,
                                                               const uint32_t* __restrict__ table,
                                                               const uint32_t* __restrict__ bin_total /* FUSED */,
                                                               const uint32_t* __restrict__ bin_start /* !FUSED */,
                                                               uint32_t* __restrict__ list, uint32_t capacity,
-                                                              uint32_t* __restrict__ overflow, FinalizeArgs fa)
+                                                              uint32_t* __restrict__ overflow, uint32_t rounds, const FinalizeArgs& fa)
 {
     static_assert(FIN_THREADS == SCAT_THREADS, "the finalize step runs as a workgroup of this kernel");
-    if (FUSED && blockIdx.x == gridDim.x - 1) {   // the extra workgroup: bin starts, work items and frame counters for the compositor
+    static_assert(!(FUSED && BIG), "the large-grid form reads the bin starts from k_bin_starts");
+    constexpr bool EXTRA = FUSED || BIG;   // the finalize step is a workgroup of this launch
+    if (EXTRA && blockIdx.x == (BIG ? 0u : gridDim.x - 1u)) {   // bin starts, work items and frame counters for the compositor
         extern __shared__ uint32_t s_fin[];   // this workgroup's share of the kernel's dynamic LDS (>= FIN_SCRATCH_WORDS, launch_bin)
         if (blockIdx.y == 0) bin_finalize_body(fa, s_fin);
         return;
     }
-    const uint32_t blk = xcd_group_remap(blockIdx.x, gridDim.x - (FUSED ? 1u : 0u));   // neighbouring rank blocks on one XCD (gsr_internal.h)
+    const uint32_t blk = xcd_group_remap(blockIdx.x - (BIG ? 1u : 0u), gridDim.x - (EXTRA ? 1u : 0u));   // neighbouring rank blocks on one XCD (gsr_internal.h)
     constexpr int WAVES_PER_GROUP = SCAT_WAVES / GROUPS;            // 4 or 2
     constexpr int GROUP_STEPS = SCAT_STEPS / GROUPS;                // 8 or 4
     constexpr int PAIR_WORDS = GROUPS / 2;                          // two 16-bit per-group counts / offsets per word
@@ -483,32 +515,6 @@ __global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(8,
     uint32_t* mypair = pair + (size_t)(group >> 1) * cap_s;
     const int myshift = (group & 1) * 16;
     KSTAMP(0);
-
-    for (int b = threadIdx.x; b < PAIR_WORDS * cap_s; b += SCAT_THREADS) pair[b] = 0;
-    for (int b = threadIdx.x; b < SCAT_STEPS * nmask; b += SCAT_THREADS) masks[b] = 0;
-    __syncthreads();
-    KSTAMP(1);
-
-    // this wave's 2 steps of 64 consecutive ranks; rectangles clipped to the sub-grid, in sub-grid coordinates
-    const uint32_t gbegin = blk * BIN_RANKS_PER_BLOCK + group * (GROUP_STEPS * WAVE);
-    uint32_t idx[SCAT_STEPS_PER_WAVE];
-    BinRect br[SCAT_STEPS_PER_WAVE];
-#pragma unroll
-    for (int k = 0; k < SCAT_STEPS_PER_WAVE; k++) {
-        const uint32_t r = gbegin + (sub * SCAT_STEPS_PER_WAVE + k) * WAVE + lane;
-        idx[k] = (r < n) ? depth_index[r] : 0xffffffffu;
-    }
-#pragma unroll
-    for (int k = 0; k < SCAT_STEPS_PER_WAVE; k++) {
-        const uint32_t r = gbegin + (sub * SCAT_STEPS_PER_WAVE + k) * WAVE + lane;
-        BinRect b = unpack_rect((r < n) ? rects[r] : RECT_NONE);
-        if (b.x0 <= b.x1) {
-            b.x0 = max(b.x0, sx0) - sx0; b.x1 = min(b.x1, sx1 - 1) - sx0;
-            b.y0 = max(b.y0, sy0) - sy0; b.y1 = min(b.y1, sy1 - 1) - sy0;
-            if (b.x0 > b.x1 || b.y0 > b.y1) { b.x0 = 1; b.x1 = 0; b.y0 = 1; b.y1 = 0; }
-        }
-        br[k] = b;
-    }
     // the workgroup's first slot in every bin = the bin's start (an exclusive scan of the bin totals, done here by
     // every workgroup: the finalize step that publishes bin_start[] runs beside this kernel, not before it) + the
     // entries earlier workgroups put into the bin (the scanned table).  base[] is not touched by phase 1.
@@ -543,6 +549,35 @@ __global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(8,
         }
     }
     KSTAMP(2);
+    for (uint32_t rd = 0; rd < (BIG ? rounds : 1u); rd++) {
+    const uint32_t rbegin = (BIG ? blk * rounds + rd : blk) * BIN_RANKS_PER_BLOCK;
+    if (BIG && rbegin >= n) break;
+    if (BIG && rd) __syncthreads();   // the previous round's slots are placed: its lane sets and group offsets can go (base[] carries on)
+    for (int b = threadIdx.x; b < PAIR_WORDS * cap_s; b += SCAT_THREADS) pair[b] = 0;
+    for (int b = threadIdx.x; b < SCAT_STEPS * nmask; b += SCAT_THREADS) masks[b] = 0;
+    __syncthreads();
+    KSTAMP(1);
+
+    // this wave's 2 steps of 64 consecutive ranks; rectangles clipped to the sub-grid, in sub-grid coordinates
+    const uint32_t gbegin = rbegin + group * (GROUP_STEPS * WAVE);
+    uint32_t idx[SCAT_STEPS_PER_WAVE];
+    BinRect br[SCAT_STEPS_PER_WAVE];
+#pragma unroll
+    for (int k = 0; k < SCAT_STEPS_PER_WAVE; k++) {
+        const uint32_t r = gbegin + (sub * SCAT_STEPS_PER_WAVE + k) * WAVE + lane;
+        idx[k] = (r < n) ? depth_index[r] : 0xffffffffu;
+    }
+#pragma unroll
+    for (int k = 0; k < SCAT_STEPS_PER_WAVE; k++) {
+        const uint32_t r = gbegin + (sub * SCAT_STEPS_PER_WAVE + k) * WAVE + lane;
+        BinRect b = unpack_rect((r < n) ? rects[r] : RECT_NONE);
+        if (b.x0 <= b.x1) {
+            b.x0 = max(b.x0, sx0) - sx0; b.x1 = min(b.x1, sx1 - 1) - sx0;
+            b.y0 = max(b.y0, sy0) - sy0; b.y1 = min(b.y1, sy1 - 1) - sy0;
+            if (b.x0 > b.x1 || b.y0 > b.y1) { b.x0 = 1; b.x1 = 0; b.y0 = 1; b.y1 = 0; }
+        }
+        br[k] = b;
+    }
     // phase 1: per-group counts, and every lane ORs its bit into the column/row lane sets of its box
     const uint32_t one = 1u << myshift;
     const unsigned long long mybit = 1ull << lane;
@@ -562,16 +597,24 @@ __global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(8,
     }
     __syncthreads();
     KSTAMP(3);
-    // phase 2: counts -> exclusive offsets of the groups inside the workgroup's run (16 bits each, in place)
+    // phase 2: counts -> exclusive offsets of the groups inside the workgroup's run (16 bits each, in place).
+    // BIG: base[] moves on to the next round's start here, and the offsets are stored relative to THAT (negative, 16-bit
+    // two's complement: a round holds 2048 ranks), so that phase 3 needs no second per-bin word
     for (int b = threadIdx.x; b < nb_s; b += SCAT_THREADS) {
-        uint32_t run = 0;
+        uint32_t c[PAIR_WORDS], total = 0;
 #pragma unroll
         for (int wd = 0; wd < PAIR_WORDS; wd++) {
-            const uint32_t c = pair[wd * cap_s + b];
-            const uint32_t lo = run, hi = run + (c & 0xffffu);
-            run = hi + (c >> 16);
-            pair[wd * cap_s + b] = lo | (hi << 16);
+            c[wd] = pair[wd * cap_s + b];
+            total += (c[wd] & 0xffffu) + (c[wd] >> 16);
         }
+        uint32_t run = BIG ? 0u - total : 0u;
+#pragma unroll
+        for (int wd = 0; wd < PAIR_WORDS; wd++) {
+            const uint32_t lo = run, hi = run + (c[wd] & 0xffffu);
+            run = hi + (c[wd] >> 16);
+            pair[wd * cap_s + b] = (lo & 0xffffu) | (hi << 16);
+        }
+        if (BIG) base[b] += total;
     }
     __syncthreads();
     KSTAMP(4);
@@ -589,7 +632,8 @@ __global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(8,
 #pragma unroll
             for (int e = 0; e < GROUP_STEPS; e++) rowm[e] = (e <= st) ? gmask[e * nmask + sl.w + y] : 0ull;
             for (int x = b.x0; x <= b.x1; x++) {
-                uint32_t dst = base[y * sw + x] + ((mypair[y * sw + x] >> myshift) & 0xffffu);
+                const uint32_t off16 = (mypair[y * sw + x] >> myshift) & 0xffffu;
+                uint32_t dst = base[y * sw + x] + (BIG ? (uint32_t)(int32_t)(int16_t)off16 : off16);
                 unsigned long long own = 0ull;
 #pragma unroll
                 for (int e = 0; e < GROUP_STEPS; e++) {
@@ -605,11 +649,31 @@ __global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(8,
             }
         }
     }
+    }   // rounds
 #ifdef GSR_KSTAMPS
     __syncthreads();
     KSTAMP(5);
 #endif
 }
+
+#define GSR_SCATTER_PARAMS                                                                                               \
+    const uint32_t *__restrict__ depth_index, const uint32_t *__restrict__ rects, const uint32_t *__restrict__ count,   \
+        BinGrid g, BinSlices sl, const uint32_t *__restrict__ table, const uint32_t *__restrict__ bin_total,            \
+        const uint32_t *__restrict__ bin_start, uint32_t *__restrict__ list, uint32_t capacity,                         \
+        uint32_t *__restrict__ overflow, uint32_t rounds, FinalizeArgs fa
+#define GSR_SCATTER_ARGS depth_index, rects, count, g, sl, table, bin_total, bin_start, list, capacity, overflow, rounds, fa
+template <int GROUPS, bool FUSED>
+__global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bin_scatter(GSR_SCATTER_PARAMS)
+{
+    bin_scatter_body<GROUPS, FUSED, false>(GSR_SCATTER_ARGS);
+}
+template <int GROUPS>
+__global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_bin_scatter_big(GSR_SCATTER_PARAMS)
+{
+    bin_scatter_body<GROUPS, false, true>(GSR_SCATTER_ARGS);
+}
+#undef GSR_SCATTER_PARAMS
+#undef GSR_SCATTER_ARGS
 
 void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s)
 {
@@ -629,7 +693,8 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
         std::call_once(once[dev >= 0 && dev < 64 ? dev : 0], [] {
             const int want = (int)(SCAT_LDS_BUDGET + 1024);
             for (const void* fn : {(const void*)k_bin_scatter<8, true>, (const void*)k_bin_scatter<8, false>,
-                                   (const void*)k_bin_scatter<4, true>, (const void*)k_bin_scatter<4, false>})
+                                   (const void*)k_bin_scatter<4, true>, (const void*)k_bin_scatter<4, false>,
+                                   (const void*)k_bin_scatter_big<8>, (const void*)k_bin_scatter_big<4>})
                 (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, want);
             (void)hipGetLastError();  // a failure shows up as the launch error
         });
@@ -639,25 +704,29 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
     const int cnt_rows = (g.nby + cnt_slices - 1) / cnt_slices;
     if (n) {
         hipLaunchKernelGGL(k_bin_count, dim3(b.nblocks, (g.nby + cnt_rows - 1) / cnt_rows), dim3(CNT_THREADS),
-                           (size_t)cnt_rows * nbxb * sizeof(uint32_t), s, b.depth_index, b.rect_idx, b.count, g, cnt_rows, b.table, b.rects);
+                           (size_t)cnt_rows * nbxb * sizeof(uint32_t), s, b.depth_index, b.rect_idx, b.count, g, cnt_rows, b.rounds, b.table, b.rects);
         launch_column_scan(b.table, b.bin_total, nbins, b.nblocks, s);
     }
     const FinalizeArgs fa{b.bin_total, nbins, b.seg_len, b.seg_target_items, b.items_by_size, b.seg_len_dev, b.max_items, b.capacity,
                           b.slots, n ? 1u : 0u, b.bin_start, b.seg_start, b.items, b.overflow, b.visible, b.tile_entries, b.accum,
                           b.report, b.queue, b.queue_start, b.mailbox, b.bin_mask, b.bin_sat, b.long_policy, b.seg_len_long, b.long_tau, b.npix, b.quad_from, b.long_tiles_x2,
                           b.spec};
-    const bool fused = n && nbins <= 4096;   // see k_bin_scatter
-    if (!fused) hipLaunchKernelGGL(k_bin_finalize, dim3(1), dim3(FIN_THREADS), FIN_SCRATCH_WORDS * sizeof(uint32_t), s, fa);
+    const bool fused = n && nbins <= 4096;   // see bin_scatter_body
+    const bool big = n && !fused && b.big;   // the large-grid form: finalize as the first workgroup, rounds
+    if (!fused && !big) hipLaunchKernelGGL(k_bin_finalize, dim3(1), dim3(FIN_THREADS), FIN_SCRATCH_WORDS * sizeof(uint32_t), s, fa);
     if (n) {
-        const dim3 grid(b.nblocks + (fused ? 1 : 0), sl.sx * sl.sy), block(SCAT_THREADS);
-#define GSR_LAUNCH_SCATTER(G, F)                                                                                                    \
-    hipLaunchKernelGGL((k_bin_scatter<G, F>), grid, block, lds, s, b.depth_index, (const uint32_t*)b.rects, b.count, g, sl,         \
-                       (const uint32_t*)b.table, (const uint32_t*)b.bin_total, (const uint32_t*)b.bin_start, b.list, b.capacity,    \
-                       b.overflow, fa)
-        if (eight && fused) GSR_LAUNCH_SCATTER(8, true);
-        else if (eight) GSR_LAUNCH_SCATTER(8, false);
-        else if (fused) GSR_LAUNCH_SCATTER(4, true);
-        else GSR_LAUNCH_SCATTER(4, false);
+        if (big) hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(FIN_THREADS), 0, s, (const uint32_t*)b.bin_total, nbins, b.bin_start_pre);
+        const dim3 grid(b.nblocks + ((fused || big) ? 1 : 0), sl.sx * sl.sy), block(SCAT_THREADS);
+#define GSR_LAUNCH_SCATTER(K, STARTS)                                                                                               \
+    hipLaunchKernelGGL((K), grid, block, lds, s, b.depth_index, (const uint32_t*)b.rects, b.count, g, sl,                           \
+                       (const uint32_t*)b.table, (const uint32_t*)b.bin_total, (const uint32_t*)(STARTS), b.list, b.capacity,       \
+                       b.overflow, b.rounds, fa)
+        if (big && eight) GSR_LAUNCH_SCATTER(k_bin_scatter_big<8>, b.bin_start_pre);
+        else if (big) GSR_LAUNCH_SCATTER(k_bin_scatter_big<4>, b.bin_start_pre);
+        else if (eight && fused) GSR_LAUNCH_SCATTER((k_bin_scatter<8, true>), b.bin_start);
+        else if (eight) GSR_LAUNCH_SCATTER((k_bin_scatter<8, false>), b.bin_start);
+        else if (fused) GSR_LAUNCH_SCATTER((k_bin_scatter<4, true>), b.bin_start);
+        else GSR_LAUNCH_SCATTER((k_bin_scatter<4, false>), b.bin_start);
 #undef GSR_LAUNCH_SCATTER
     }
 }

@@ -110,6 +110,9 @@ export class HIPRenderer {
      *  Afterwards render() draws this rank's tile-column band and all-gathers the RGBA8 frame over xGMI inside the
      *  library (RCCL); readPixels() returns the whole frame on every rank. */
     joinGroup(group: { id: Uint8Array; rank: number; world: number; edges: Array<[number, number]> }): void;
+    /** Another renderer of the same rank (frames in flight) joins the group `leader` has joined: one communicator and one
+     *  exchange stream per rank (gsr_comm_share).  Leave (or dispose) it before the leader. */
+    shareGroup(leader: HIPRenderer): void;
     leaveGroup(): void;
     group(): { rank: number; world: number } | null;
     static createGroupId(): Uint8Array;

@@ -422,6 +422,18 @@ napi_value CommInit(napi_env env, napi_callback_info info)
     return rc ? throw_gsr(env, c, rc, "gsr_comm_init") : undefined(env);
 }
 
+// commShare(handle, leaderHandle): this context joins the group the leader has joined (same rank: another frame in flight)
+napi_value CommShare(napi_env env, napi_callback_info info)
+{
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return nullptr;
+    gsr_ctx* c = get_ctx(env, argv[0]);
+    gsr_ctx* leader = get_ctx(env, argv[1]);
+    if (!c || !leader) return nullptr;
+    const int rc = gsr_comm_share(c, leader);
+    return rc ? throw_gsr(env, c, rc, "gsr_comm_share") : undefined(env);
+}
+
 // readFrame(handle, Uint8Array out, width, height): the gathered RGBA8 frame
 napi_value ReadFrame(napi_env env, napi_callback_info info)
 {
@@ -495,7 +507,7 @@ napi_value Init(napi_env env, napi_value exports)
         {"renderAsync", Call0<gsr_render_async>}, {"sync", Call0<gsr_sync>}, {"resetTimings", Call0<gsr_reset_timings>},
         {"readDepthIndex", ReadDepthIndex}, {"readPixels", ReadPixels}, {"getTimings", GetTimings},
         {"deviceInfo", DeviceInfo}, {"sortHost", SortHost}, {"overflowPending", OverflowPending},
-        {"setListCapacity", SetListCapacity}, {"buildId", BuildId}, {"commUniqueId", CommUniqueId}, {"commInit", CommInit},
+        {"setListCapacity", SetListCapacity}, {"buildId", BuildId}, {"commUniqueId", CommUniqueId}, {"commInit", CommInit}, {"commShare", CommShare},
         {"commDestroy", Call0<gsr_comm_destroy>}, {"allgatherFrameAsync", Call0<gsr_allgather_frame_async>}, {"readFrame", ReadFrame},
     };
     for (auto& f : fns) {

@@ -88,6 +88,12 @@ class HIPRenderer {
             this._n.commInit(this._h, g.id, g.rank, g.world, x0, x1);
             group = { rank: g.rank, world: g.world };
         };
+        // A second renderer of the SAME rank (frames in flight with renderAsync) joins through the first one: it shares the
+        // communicator and the exchange stream, so the rank's collectives go out in frame order (gsr_comm_share).
+        this.shareGroup = (leader) => {
+            this._n.commShare(this._h, leader._h);
+            group = Object.assign({}, leader.group());
+        };
         this.leaveGroup = () => { this._n.commDestroy(this._h); group = null; };
         this.group = () => group;
 
