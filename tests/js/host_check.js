@@ -136,7 +136,32 @@ if (mode === "pack") {                     // pack <splat> <outprefix> <W> <H> <
             for (let i = 0; i < want.length; i++) worst = Math.max(worst, Math.abs(got[i] - want[i]));
         }
     }
-    if (ref) fs.writeFileSync(out + ".json", JSON.stringify({ worst: worst, world: +world, group: r.group() }));
+    // a second renderer of this rank shares the group (one communicator and exchange stream per rank): frames in flight with
+    // renderAsync, alternating renderers, each read back before its renderer is used again
+    const r2 = new G.WebGLRenderer({ width: +W, height: +H, device: +world > 1 ? +rank : 0 }, []);
+    r2.shareGroup(r);
+    let worstShared = 0;
+    const pair = [r, r2], posesAsync = [12, 55, 70, 101];
+    const inflight = [null, null];
+    const settle = (slot) => {
+        const got = pair[slot].readPixels();
+        if (ref) {
+            ref.render(scene, orbitCamera(inflight[slot], 120, +fx));
+            const want = ref.readPixels();
+            for (let i = 0; i < want.length; i++) worstShared = Math.max(worstShared, Math.abs(got[i] - want[i]));
+        }
+        inflight[slot] = null;
+    };
+    posesAsync.forEach((pose, k) => {
+        const slot = k % 2;
+        if (inflight[slot] !== null) settle(slot);
+        pair[slot].renderAsync(scene, orbitCamera(pose, 120, +fx));
+        inflight[slot] = pose;
+    });
+    settle(0); settle(1);
+    if (ref) fs.writeFileSync(out + ".json", JSON.stringify({ worst: worst, worstShared: worstShared, world: +world, group: r.group(), group2: r2.group() }));
+    r2.leaveGroup();
+    r2.dispose();
     r.leaveGroup();
     r.dispose();
     if (ref) ref.dispose();

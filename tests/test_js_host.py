@@ -213,6 +213,8 @@ def test_js_render_with_in_library_allgather(tmp_path):
     run("group", f, out, cfg["width"], cfg["height"], cfg["fx"], 0, 1, tmp_path / "comm.id")
     got = json.load(open(out + ".json"))
     assert got["worst"] == 0 and got["world"] == 1 and got["group"] == {"rank": 0, "world": 1}
+    # and with a second renderer sharing the group (renderer.shareGroup: frames in flight of one rank)
+    assert got["worstShared"] == 0 and got["group2"] == {"rank": 0, "world": 1}
 
 
 @pytest.mark.gpu
