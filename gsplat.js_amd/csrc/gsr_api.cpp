@@ -87,7 +87,7 @@ struct gsr_ctx {
     uint32_t *bin_table = nullptr, *bin_total = nullptr, *bin_start = nullptr, *bin_start_pre = nullptr, *bin_list = nullptr;
     uint32_t bin_rounds = 1;          // rounds of 2048 ranks per binning workgroup (alloc_bins; GSR_BIN_ROUNDS)
     long bin_rounds_env = 0;
-    bool bin_big = true;              // large bin grids: k_bin_scatter_big (GSR_BIN_BIG=0: the 64-register kernel + k_bin_finalize)
+    uint32_t bin_big = 2;             // large bin grids: k_bin_scatter_big (GSR_BIN_BIG=0: the 64-register kernel + k_bin_finalize; 1: 2048-rank rounds)
     uint32_t *seg_start = nullptr, *items = nullptr;
     unsigned long long* bin_mask = nullptr;   // per-bin arrival masks of the compositor (null: separate k_combine launch)
     uint32_t* bin_sat = nullptr;              // per-bin "saturated in front of segment ..." words, with bin_mask
@@ -393,7 +393,7 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
         const BinGrid g = make_grid(c);
         const int nbins = (g.bx_hi - g.bx_lo) * g.nby;
         if (!c->n) HIP_TRY(c, hipMemsetAsync(c->bin_total, 0, sizeof(uint32_t) * nbins, s));
-        BinBuffers bb{c->depth_index, &c->fstate->sorted_count, c->bin_table, c->slots, c->rect_idx, c->bin_rects, c->bin_total, c->bin_start, c->bin_start_pre, c->bin_rounds, c->bin_big ? 1u : 0u, c->seg_start,
+        BinBuffers bb{c->depth_index, &c->fstate->sorted_count, c->bin_table, c->slots, c->rect_idx, c->bin_rects, c->bin_total, c->bin_start, c->bin_start_pre, c->bin_rounds, c->bin_big, c->seg_start,
                       c->items, c->bin_list, &c->fstate->overflow, &c->fstate->visible, &c->fstate->tile_entries,
                       c->accum, c->mailbox_dev, c->fstate->report, c->bin_capacity, c->max_items, c->seg_len, &c->fstate->seg_len, c->items_by_size, &c->fstate->queue, std::min<uint32_t>(c->max_items, c->blend_grid), c->seg_target_items, c->bin_blocks, c->bin_mask, c->bin_sat,
                       c->seg_len == SEG_LEN_WHOLE_BIN ? 0 : c->long_items >= 0 ? c->long_items : c->saturate ? -1 : 0, SEG_LEN_LONG,
@@ -434,7 +434,7 @@ static std::vector<uint64_t> chain_signature(const gsr_ctx* c)
     P(c->rec); P(c->bbox); P(c->slots); P(c->rect_idx); P(c->bin_table); P(c->bin_rects); P(c->bin_total); P(c->bin_start); P(c->seg_start); P(c->bin_mask); P(c->bin_sat);
     P(c->items); P(c->bin_list); P(c->partial); P(c->fb); P(c->accum); P(c->cam_dev);
     U(c->n); U((uint64_t)c->W); U((uint64_t)c->H); U((uint64_t)g.bx_lo); U((uint64_t)g.bx_hi); U(c->sort_kpb); U(c->sort_blocks);
-    U(c->bin_capacity); U(c->max_items); U(c->seg_len); U(c->seg_target_items); U(c->blend_grid); U(c->bin_blocks); U(c->bin_rounds); U(c->bin_big ? 1u : 0u); P(c->bin_start_pre);
+    U(c->bin_capacity); U(c->max_items); U(c->seg_len); U(c->seg_target_items); U(c->blend_grid); U(c->bin_blocks); U(c->bin_rounds); U(c->bin_big); P(c->bin_start_pre);
     U((uint64_t)c->opt.flags); U((uint64_t)(c->opt.early_out_eps * 1e9f)); U(c->bucket_order_now ? 1u : 0u); U(c->saturate ? 1u : 0u); U((uint64_t)c->items_by_size); U(c->quad_from); U((uint64_t)(int64_t)c->long_items);
     U((uint64_t)c->spec); U(c->blend_sub);
     return v;
@@ -642,7 +642,7 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
     if (const char* e = getenv("GSR_LONG_ITEMS")) c->long_items = atoi(e) != 0 ? 1 : 0; // pins the work-item length policy
     if (const char* e = getenv("GSR_SPEC")) c->spec = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("GSR_BIN_ROUNDS")) c->bin_rounds_env = std::min(64L, std::max(0L, atol(e)));
-    if (const char* e = getenv("GSR_BIN_BIG")) c->bin_big = atoi(e) != 0;
+    if (const char* e = getenv("GSR_BIN_BIG")) c->bin_big = (uint32_t)std::min(2, std::max(0, atoi(e)));
     if (const char* e = getenv("GSR_BLEND_SUB")) c->blend_sub_env = atoi(e) == 2 ? 2 : atoi(e) == 1 ? 1 : 0;
     CREATE_TRY(hipMalloc((void**)&c->accum, 8 * sizeof(uint64_t)));
     CREATE_TRY(hipMemset(c->accum, 0, 8 * sizeof(uint64_t)));

@@ -177,7 +177,8 @@ struct BinBuffers {
     uint32_t* bin_start;         // nbins + 1
     uint32_t* bin_start_pre;     // nbins + 1: the same starts, computed ahead of the scatter by k_bin_starts (large-grid form)
     uint32_t rounds;             // rounds of 2048 ranks a binning workgroup takes (table rows = ceil(ranks / (2048 * rounds)); > 1 only with big)
-    uint32_t big;                // 1: large bin grids use k_bin_scatter_big (finalize as its first workgroup, rounds); 0: A/B knob
+    uint32_t big;                // large bin grids: 1 = k_bin_scatter_big (finalize as its first workgroup, rounds of 2048 ranks),
+                                 // 2 = the same with rounds of 1024 ranks (half the step loops); 0 = the 64-register kernel (A/B knob)
     uint32_t* seg_start;         // nbins + 1: first compositor work item of each bin; [nbins] = item count
     uint32_t* items;             // max_items: bin | segment << 16
     uint32_t* list;              // capacity entries (splat indices, depth order inside each bin)

@@ -424,9 +424,9 @@ constexpr size_t SCAT_LDS_TWO_PER_CU = 72 * 1024;   // with at most this much, t
 
 struct BinSlices { int32_t sx, sy, w, h; };  // sx x sy sub-grids of w x h bins (the last ones may be smaller)
 
-inline size_t scatter_lds_bytes(int w, int h, int groups)
+inline size_t scatter_lds_bytes(int w, int h, int groups, int steps = SCAT_STEPS)
 {
-    return (size_t)(((1 + groups / 2) * w * h + 1) & ~1) * 4 + (size_t)SCAT_STEPS * (w + h) * 8;
+    return (size_t)(((1 + groups / 2) * w * h + 1) & ~1) * 4 + (size_t)steps * (w + h) * 8;
 }
 
 inline BinSlices make_slices(int nbxb, int nby)
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_bin_starts(const uint32_t* __re
 //    carrying over, so that the [workgroup][bin] table all three binning kernels exchange is 20 MB instead of 80 MB at
 //    5 M splats (more than the lists it helps to build).  Inside the 64-register kernel the same two things spilled 15 and
 //    44 registers and cost more than they saved (C4 binning 477 -> 533 us, profiles/r03_experiments.txt).
-template <int GROUPS, bool FUSED, bool BIG>
+template <int GROUPS, bool FUSED, bool BIG, int SPW /* 64-rank steps per wave and round */>
 __device__ __forceinline__ void bin_scatter_body(const uint32_t* __restrict__ depth_index,
                                                               const uint32_t* __restrict__ rects,
                                                               const uint32_t* __restrict__ count, BinGrid g, BinSlices sl,
@@ -492,7 +492,8 @@ __device__ __forceinline__ void bin_scatter_body(const uint32_t* __restrict__ de
     }
     const uint32_t blk = xcd_group_remap(blockIdx.x - (BIG ? 1u : 0u), gridDim.x - (EXTRA ? 1u : 0u));   // neighbouring rank blocks on one XCD (gsr_internal.h)
     constexpr int WAVES_PER_GROUP = SCAT_WAVES / GROUPS;            // 4 or 2
-    constexpr int GROUP_STEPS = SCAT_STEPS / GROUPS;                // 8 or 4
+    constexpr int STEPS = SCAT_WAVES * SPW;                         // steps of a round: 32 (2048 ranks) or 16 (1024)
+    constexpr int GROUP_STEPS = STEPS / GROUPS;                     // 8 or 4
     constexpr int PAIR_WORDS = GROUPS / 2;                          // two 16-bit per-group counts / offsets per word
     extern __shared__ uint32_t s_mem[];
     const uint32_t n = *count;
@@ -549,27 +550,30 @@ __device__ __forceinline__ void bin_scatter_body(const uint32_t* __restrict__ de
         }
     }
     KSTAMP(2);
-    for (uint32_t rd = 0; rd < (BIG ? rounds : 1u); rd++) {
-    const uint32_t rbegin = (BIG ? blk * rounds + rd : blk) * BIN_RANKS_PER_BLOCK;
+    // (a round of this kernel holds STEPS * 64 ranks; `rounds` counts the count kernel's 2048-rank rounds per workgroup)
+    constexpr uint32_t ROUND_RANKS = (uint32_t)STEPS * WAVE;
+    const uint32_t my_rounds = BIG ? rounds * (BIN_RANKS_PER_BLOCK / ROUND_RANKS) : 1u;
+    for (uint32_t rd = 0; rd < my_rounds; rd++) {
+    const uint32_t rbegin = blk * (BIG ? rounds : 1u) * BIN_RANKS_PER_BLOCK + rd * ROUND_RANKS;
     if (BIG && rbegin >= n) break;
     if (BIG && rd) __syncthreads();   // the previous round's slots are placed: its lane sets and group offsets can go (base[] carries on)
     for (int b = threadIdx.x; b < PAIR_WORDS * cap_s; b += SCAT_THREADS) pair[b] = 0;
-    for (int b = threadIdx.x; b < SCAT_STEPS * nmask; b += SCAT_THREADS) masks[b] = 0;
+    for (int b = threadIdx.x; b < STEPS * nmask; b += SCAT_THREADS) masks[b] = 0;
     __syncthreads();
     KSTAMP(1);
 
     // this wave's 2 steps of 64 consecutive ranks; rectangles clipped to the sub-grid, in sub-grid coordinates
     const uint32_t gbegin = rbegin + group * (GROUP_STEPS * WAVE);
-    uint32_t idx[SCAT_STEPS_PER_WAVE];
-    BinRect br[SCAT_STEPS_PER_WAVE];
+    uint32_t idx[SPW];
+    BinRect br[SPW];
 #pragma unroll
-    for (int k = 0; k < SCAT_STEPS_PER_WAVE; k++) {
-        const uint32_t r = gbegin + (sub * SCAT_STEPS_PER_WAVE + k) * WAVE + lane;
+    for (int k = 0; k < SPW; k++) {
+        const uint32_t r = gbegin + (sub * SPW + k) * WAVE + lane;
         idx[k] = (r < n) ? depth_index[r] : 0xffffffffu;
     }
 #pragma unroll
-    for (int k = 0; k < SCAT_STEPS_PER_WAVE; k++) {
-        const uint32_t r = gbegin + (sub * SCAT_STEPS_PER_WAVE + k) * WAVE + lane;
+    for (int k = 0; k < SPW; k++) {
+        const uint32_t r = gbegin + (sub * SPW + k) * WAVE + lane;
         BinRect b = unpack_rect((r < n) ? rects[r] : RECT_NONE);
         if (b.x0 <= b.x1) {
             b.x0 = max(b.x0, sx0) - sx0; b.x1 = min(b.x1, sx1 - 1) - sx0;
@@ -582,9 +586,9 @@ __device__ __forceinline__ void bin_scatter_body(const uint32_t* __restrict__ de
     const uint32_t one = 1u << myshift;
     const unsigned long long mybit = 1ull << lane;
 #pragma unroll
-    for (int k = 0; k < SCAT_STEPS_PER_WAVE; k++) {
+    for (int k = 0; k < SPW; k++) {
         const BinRect b = br[k];
-        unsigned long long* colm = gmask + (sub * SCAT_STEPS_PER_WAVE + k) * nmask;
+        unsigned long long* colm = gmask + (sub * SPW + k) * nmask;
         unsigned long long* rowm = colm + sl.w;
         for (int x = b.x0; x <= b.x1; x++) atomicOr(&colm[x], mybit);
         for (int y = b.y0; y <= b.y1; y++) {
@@ -623,9 +627,9 @@ __device__ __forceinline__ void bin_scatter_body(const uint32_t* __restrict__ de
     // lower lanes in its own step's set: input order, from ballot-style arithmetic on LDS words that are
     // read-only by now (no ordered atomics, no running counter).  The row sets of a box row are read once per row.
 #pragma unroll
-    for (int k = 0; k < SCAT_STEPS_PER_WAVE; k++) {
+    for (int k = 0; k < SPW; k++) {
         const BinRect b = br[k];
-        const int st = sub * SCAT_STEPS_PER_WAVE + k;
+        const int st = sub * SPW + k;
         const uint32_t myidx = idx[k];
         for (int y = b.y0; y <= b.y1; y++) {
             unsigned long long rowm[GROUP_STEPS];
@@ -665,12 +669,12 @@ __device__ __forceinline__ void bin_scatter_body(const uint32_t* __restrict__ de
 template <int GROUPS, bool FUSED>
 __global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bin_scatter(GSR_SCATTER_PARAMS)
 {
-    bin_scatter_body<GROUPS, FUSED, false>(GSR_SCATTER_ARGS);
+    bin_scatter_body<GROUPS, FUSED, false, SCAT_STEPS_PER_WAVE>(GSR_SCATTER_ARGS);
 }
-template <int GROUPS>
+template <int GROUPS, int SPW>
 __global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_bin_scatter_big(GSR_SCATTER_PARAMS)
 {
-    bin_scatter_body<GROUPS, false, true>(GSR_SCATTER_ARGS);
+    bin_scatter_body<GROUPS, false, true, SPW>(GSR_SCATTER_ARGS);
 }
 #undef GSR_SCATTER_PARAMS
 #undef GSR_SCATTER_ARGS
@@ -683,7 +687,11 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
     // 8 groups of 4 steps where their table still lets two workgroups share a CU, else 4 groups of 8 steps
     const bool eight = scatter_lds_bytes(sl.w, sl.h, 8) <= SCAT_LDS_TWO_PER_CU;
     // (the finalize step, when it runs as this kernel's extra workgroup, uses FIN_SCRATCH_WORDS of the dynamic LDS)
-    const size_t lds = std::max(scatter_lds_bytes(sl.w, sl.h, eight ? 8 : 4), FIN_SCRATCH_WORDS * sizeof(uint32_t));
+    // the large-grid form with 1024-rank rounds (one step per wave): 4 groups of 4 steps -- ~6 instead of ~11 LDS reads per
+    // list entry in the slot phase, the phase the kernel is bound by -- at twice the per-round fixed work (b.big == 2)
+    // (at 1080p the large-grid form loses to the two-workgroups-per-CU kernel: C3 binning 47.3 -> 54.1 us, measured)
+    const bool short_rounds = n && nbins > 4096 && b.big == 2 && !eight;
+    const size_t lds = std::max(scatter_lds_bytes(sl.w, sl.h, eight ? 8 : 4, short_rounds ? SCAT_WAVES : SCAT_STEPS), FIN_SCRATCH_WORDS * sizeof(uint32_t));
     // dynamic LDS above the default needs the attribute raised (1080p: 64 KiB, 4K: 8160 bins -> 146 KiB).  The attribute
     // belongs to the current device's copy of each instantiation: raised to the budget once per device for all four.
     {
@@ -694,7 +702,8 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
             const int want = (int)(SCAT_LDS_BUDGET + 1024);
             for (const void* fn : {(const void*)k_bin_scatter<8, true>, (const void*)k_bin_scatter<8, false>,
                                    (const void*)k_bin_scatter<4, true>, (const void*)k_bin_scatter<4, false>,
-                                   (const void*)k_bin_scatter_big<8>, (const void*)k_bin_scatter_big<4>})
+                                   (const void*)k_bin_scatter_big<8, 2>, (const void*)k_bin_scatter_big<4, 2>,
+                                   (const void*)k_bin_scatter_big<4, 1>})
                 (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, want);
             (void)hipGetLastError();  // a failure shows up as the launch error
         });
@@ -721,8 +730,9 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
     hipLaunchKernelGGL((K), grid, block, lds, s, b.depth_index, (const uint32_t*)b.rects, b.count, g, sl,                           \
                        (const uint32_t*)b.table, (const uint32_t*)b.bin_total, (const uint32_t*)(STARTS), b.list, b.capacity,       \
                        b.overflow, b.rounds, fa)
-        if (big && eight) GSR_LAUNCH_SCATTER(k_bin_scatter_big<8>, b.bin_start_pre);
-        else if (big) GSR_LAUNCH_SCATTER(k_bin_scatter_big<4>, b.bin_start_pre);
+        if (big && eight) GSR_LAUNCH_SCATTER((k_bin_scatter_big<8, 2>), b.bin_start_pre);
+        else if (big && short_rounds) GSR_LAUNCH_SCATTER((k_bin_scatter_big<4, 1>), b.bin_start_pre);
+        else if (big) GSR_LAUNCH_SCATTER((k_bin_scatter_big<4, 2>), b.bin_start_pre);
         else if (eight && fused) GSR_LAUNCH_SCATTER((k_bin_scatter<8, true>), b.bin_start);
         else if (eight) GSR_LAUNCH_SCATTER((k_bin_scatter<8, false>), b.bin_start);
         else if (fused) GSR_LAUNCH_SCATTER((k_bin_scatter<4, true>), b.bin_start);
