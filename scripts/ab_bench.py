@@ -28,11 +28,13 @@ def main():
     ap.add_argument("--frames", type=int, default=40)
     ap.add_argument("--inflight", type=int, default=1)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--res-div", type=int, default=1, help="render at 1/N of the configuration's resolution and focal length (same splats, coarser bin grid)")
     ap.add_argument("--sort-only", action="store_true", help="time gsr_sort (key + min/max + radix) instead of full frames")
     args = ap.parse_args()
     import gsplat_hip as gh
 
-    cfg = gh.synth.CONFIGS[args.config]
+    cfg = dict(gh.synth.CONFIGS[args.config])
+    cfg["width"] //= args.res_div; cfg["height"] //= args.res_div; cfg["fx"] /= args.res_div
     W, H = cfg["width"], cfg["height"]
     scene = gh.Scene()
     scene.setData(gh.synth.config_rows(args.config))
