@@ -87,6 +87,10 @@ struct gsr_ctx {
     uint32_t *bin_table = nullptr, *bin_total = nullptr, *bin_start = nullptr, *bin_start_pre = nullptr, *bin_list = nullptr;
     uint32_t bin_rounds = 1;          // rounds of 2048 ranks per binning workgroup (alloc_bins; GSR_BIN_ROUNDS)
     long bin_rounds_env = 0;
+    int bin_two_level_env = -1;       // GSR_BIN_TWO_LEVEL: 0 / 1 force the one- / two-level binning (alloc_bins); -1: by the bin grid
+    bool bin_two_level = false;
+    uint32_t *cell_list = nullptr, *cell_total = nullptr, *cell_start = nullptr, *chunk_start = nullptr, *chunk_info = nullptr, *cell_table2 = nullptr;
+    uint32_t cell_capacity_alloc = 0, cell_ncells_alloc = 0, cell_grid = 0;
     uint32_t bin_big = 2;             // large bin grids: k_bin_scatter_big (GSR_BIN_BIG=0: the 64-register kernel + k_bin_finalize; 1: 2048-rank rounds)
     uint32_t *seg_start = nullptr, *items = nullptr;
     unsigned long long* bin_mask = nullptr;   // per-bin arrival masks of the compositor (null: separate k_combine launch)
@@ -236,6 +240,7 @@ constexpr uint32_t BLEND_WG_PER_CU_THROUGHPUT = 7;
 constexpr uint32_t BLEND_WG_PER_CU_SUB2 = 3;
 constexpr uint32_t SUB2_MAX_BINS = 4096, SEG_LEN_MIN_SUB2 = 1024;
 constexpr uint32_t BIN_BLOCKS_TARGET = 640, BIN_ROUNDS_MAX = 8;
+constexpr uint32_t TWO_LEVEL_MIN_BINS = 4096, CELL_WG_PER_CU = 4;
 constexpr uint32_t SEG_LEN_WHOLE_BIN = 0x7fffff00u;
 
 // Sort order.  Up to BUCKET_ORDER_MAX_N splats the radix sort runs high digit first with one workgroup per bucket
@@ -283,12 +288,15 @@ int alloc_bins(gsr_ctx* c)
     // Ranks per binning workgroup: rounds of 2048.  The count / scan / scatter passes exchange a [workgroup][bin] table; with
     // one round per workgroup it is 80 MB at 5 M splats and 8160 bins.  Large grids (the k_bin_scatter_big form, > 4096 bins)
     // take several rounds per workgroup, keeping about BIN_BLOCKS_TARGET workgroups (C4: 4 rounds, 611 workgroups, 20 MB).
+    // Two-level binning (k_bin.hip): grids above TWO_LEVEL_MIN_BINS bins whose cells of 4 x 4 bins number at most 4096.
+    const uint32_t ncells = (uint32_t)(((g.bx_hi - g.bx_lo + 3) >> 2) * ((g.nby + 3) >> 2));
+    c->bin_two_level = ncells <= 4096u && (c->bin_two_level_env >= 0 ? c->bin_two_level_env == 1 : nbins > TWO_LEVEL_MIN_BINS);
     c->bin_rounds = 1;
-    if (c->bin_big && nbins > 4096)
+    if (!c->bin_two_level && c->bin_big && nbins > 4096)
         c->bin_rounds = std::min<uint32_t>(BIN_ROUNDS_MAX, std::max<uint32_t>(1u, ((c->n + 2047u) / 2048u + BIN_BLOCKS_TARGET - 1u) / BIN_BLOCKS_TARGET));
-    if (c->bin_big && nbins > 4096 && c->bin_rounds_env > 0) c->bin_rounds = (uint32_t)c->bin_rounds_env;
+    if (!c->bin_two_level && c->bin_big && nbins > 4096 && c->bin_rounds_env > 0) c->bin_rounds = (uint32_t)c->bin_rounds_env;
     c->bin_blocks = (c->n + 2048u * c->bin_rounds - 1u) / (2048u * c->bin_rounds);
-    const size_t table = (size_t)std::max(c->bin_blocks, 1u) * nbins;
+    const size_t table = (size_t)std::max(c->bin_blocks, 1u) * (c->bin_two_level ? ncells + 1u : nbins);
     if (table > c->bin_table_elems) {
         if (int r = dev_alloc(c, &c->bin_table, table)) return r;
         c->bin_table_elems = (uint32_t)table;
@@ -310,6 +318,23 @@ int alloc_bins(gsr_ctx* c)
         c->bin_capacity = std::max<uint32_t>(6u * c->n + (1u << 20), 1u << 22);
         if (int r = dev_alloc(c, &c->bin_list, c->bin_capacity)) return r;
         items_dirty = true;
+    }
+    if (c->bin_two_level) {
+        if (ncells > c->cell_ncells_alloc) {
+            if (int r = dev_alloc(c, &c->cell_total, ncells + 1)) return r;
+            if (int r = dev_alloc(c, &c->cell_start, ncells + 1)) return r;
+            if (int r = dev_alloc(c, &c->chunk_start, ncells + 2)) return r;
+            c->cell_ncells_alloc = ncells;
+            c->cell_capacity_alloc = 0;
+        }
+        if (c->bin_capacity > c->cell_capacity_alloc) {
+            if (int r = dev_alloc(c, &c->cell_list, (size_t)c->bin_capacity * 2)) return r;
+            if (int r = dev_alloc(c, &c->cell_table2, ((size_t)c->bin_capacity / 2048u + ncells + 1u) * 16u)) return r;
+            if (int r = dev_alloc(c, &c->chunk_info, ((size_t)c->bin_capacity / 2048u + ncells + 1u) * 4u)) return r;
+            c->cell_capacity_alloc = c->bin_capacity;
+        }
+        // the level-two kernels stride over the frame's chunks: two 16-wave workgroups per CU, twice over
+        c->cell_grid = (uint32_t)std::max(c->cu_count, 1) * CELL_WG_PER_CU;
     }
     const bool throughput = (c->opt.flags & GSR_FLAG_THROUGHPUT) != 0;
     c->seg_len = c->opt.early_out_eps > 0.0f ? SEG_LEN_WHOLE_BIN : SEG_LEN_MIN;
@@ -400,6 +425,7 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
                       (c->opt.flags & GSR_FLAG_THROUGHPUT) ? LONG_TAU_THROUGHPUT : LONG_TAU_EXACT,
                       (uint32_t)((g.bx_hi - g.bx_lo) * BIN_PX) * (uint32_t)c->H, c->quad_from,
                       (c->opt.flags & GSR_FLAG_THROUGHPUT) ? LONG_TILES_X2_THROUGHPUT : LONG_TILES_X2_EXACT,
+                      c->bin_two_level ? 1u : 0u, c->cell_list, c->cell_total, c->cell_start, c->chunk_start, c->chunk_info, c->cell_table2, c->cell_grid,
                       (uint32_t)c->spec};
         launch_bin(bb, g, c->n, s);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BIN], s));
@@ -437,6 +463,7 @@ static std::vector<uint64_t> chain_signature(const gsr_ctx* c)
     U(c->bin_capacity); U(c->max_items); U(c->seg_len); U(c->seg_target_items); U(c->blend_grid); U(c->bin_blocks); U(c->bin_rounds); U(c->bin_big); P(c->bin_start_pre);
     U((uint64_t)c->opt.flags); U((uint64_t)(c->opt.early_out_eps * 1e9f)); U(c->bucket_order_now ? 1u : 0u); U(c->saturate ? 1u : 0u); U((uint64_t)c->items_by_size); U(c->quad_from); U((uint64_t)(int64_t)c->long_items);
     U((uint64_t)c->spec); U(c->blend_sub);
+    U(c->bin_two_level ? 1u : 0u); P(c->cell_list); P(c->cell_total); P(c->cell_start); P(c->chunk_start); P(c->chunk_info); P(c->cell_table2); U(c->cell_grid);
     return v;
 }
 
@@ -643,6 +670,7 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
     if (const char* e = getenv("GSR_SPEC")) c->spec = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("GSR_BIN_ROUNDS")) c->bin_rounds_env = std::min(64L, std::max(0L, atol(e)));
     if (const char* e = getenv("GSR_BIN_BIG")) c->bin_big = (uint32_t)std::min(2, std::max(0, atoi(e)));
+    if (const char* e = getenv("GSR_BIN_TWO_LEVEL")) c->bin_two_level_env = atoi(e) ? 1 : 0;
     if (const char* e = getenv("GSR_BLEND_SUB")) c->blend_sub_env = atoi(e) == 2 ? 2 : atoi(e) == 1 ? 1 : 0;
     CREATE_TRY(hipMalloc((void**)&c->accum, 8 * sizeof(uint64_t)));
     CREATE_TRY(hipMemset(c->accum, 0, 8 * sizeof(uint64_t)));
@@ -688,6 +716,7 @@ int gsr_destroy(gsr_ctx* c)
     dev_free(&c->depth); dev_free(&c->keys); dev_free(&c->keys_tmp); dev_free(&c->idx_tmp); dev_free(&c->depth_index);
     dev_free(&c->block_hist); dev_free(&c->rec); dev_free(&c->bbox); dev_free(&c->slots); dev_free(&c->rect_idx);
     dev_free(&c->bin_table); dev_free(&c->bin_total); dev_free(&c->bin_start); dev_free(&c->bin_start_pre); dev_free(&c->bin_list);
+    dev_free(&c->cell_list); dev_free(&c->cell_total); dev_free(&c->cell_start); dev_free(&c->chunk_start); dev_free(&c->chunk_info); dev_free(&c->cell_table2);
     dev_free(&c->seg_start); dev_free(&c->bin_mask); dev_free(&c->bin_sat); dev_free(&c->items); dev_free(&c->partial); dev_free(&c->bin_rects);
     drop_graph(c);
     dev_free(&c->cam_dev);

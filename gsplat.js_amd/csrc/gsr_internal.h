@@ -206,6 +206,15 @@ struct BinBuffers {
     uint32_t npix;               // pixels of this context's band (the optical depth is per pixel)
     uint32_t quad_from;          // single-item bins with at least this many entries become four work items, one per 16x16 tile (0: never)
     uint32_t long_tiles_x2;      // long work items also need this many 16x16 tiles per visible splat, times two (0: no such condition)
+    // two-level binning (launch_bin; large bin grids): cells of 4 x 4 bins first, then the cell lists' chunks into the bins
+    uint32_t two_level;          // 1: on (nblocks = workgroups of 2048 ranks, rounds = 1; table holds nblocks x (cells + 1) words)
+    uint32_t* cell_list;         // 2 x capacity words: (splat index, rectangle in bins) per cell-list entry
+    uint32_t* cell_total;        // cells + 1: entries per cell; [cells] = list entries the frame needs
+    uint32_t* cell_start;        // cells + 1
+    uint32_t* chunk_start;       // cells + 2: first chunk of each cell, the frame's chunks, the frame's need
+    uint32_t* chunk_info;        // (capacity / 2048 + cells) x 4: per chunk its cell, first and end entry
+    uint32_t* cell_table2;       // (capacity / 2048 + cells) x 16: per chunk and bin of its cell: entries, then their first slot
+    uint32_t cell_grid;          // workgroups of the level-two kernels (they stride over the frame's chunks)
     uint32_t spec;               // dense frames (long_policy): 1 = speculative segments -- the plain cut, handed out layer by layer, segments
                                  // behind a saturated prefix skipped (needs bin_mask) --, 0 = whole-bin work items of seg_len_long entries
 };

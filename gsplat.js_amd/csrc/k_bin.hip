@@ -47,6 +47,14 @@ __device__ __forceinline__ BinRect unpack_rect(uint32_t p)
     return r;
 }
 
+// the rectangle in cells of 2^shift x 2^shift bins (two-level binning, below); shift 0: in bins
+__device__ __forceinline__ BinRect unpack_rect(uint32_t p, int shift)
+{
+    BinRect r = unpack_rect(p);
+    if (r.x0 <= r.x1) { r.x0 >>= shift; r.x1 >>= shift; r.y0 >>= shift; r.y1 >>= shift; }
+    return r;
+}
+
 __device__ __forceinline__ uint32_t lanes_below64(uint64_t mask)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -63,14 +71,18 @@ constexpr int CNT_MAX_BINS = 12288;  // LDS counters per workgroup (48 KiB); lar
 
 __global__ __launch_bounds__(CNT_THREADS) void k_bin_count(const uint32_t* __restrict__ depth_index, const uint32_t* __restrict__ rect_idx,
                                                            const uint32_t* __restrict__ count, BinGrid g, int slice_rows,
-                                                           uint32_t rounds, uint32_t* __restrict__ table, uint32_t* __restrict__ rects)
+                                                           uint32_t rounds, uint32_t* __restrict__ table, uint32_t* __restrict__ rects, int shift)
 {
     const uint32_t n = *count;  // ranks the sort produced (all splats, or the band's survivors)
     extern __shared__ uint32_t s_cnt[];  // this slice's bins
     const int nbxb = g.bx_hi - g.bx_lo, nbins = nbxb * g.nby;
     const int y_lo = blockIdx.y * slice_rows, y_hi = min(y_lo + slice_rows, g.nby);  // bin rows of this slice
     const int nb_s = (y_hi - y_lo) * nbxb;
-    for (int b = threadIdx.x; b < nb_s; b += CNT_THREADS) s_cnt[b] = 0;
+    // a cell pass (shift > 0: `g` is the grid of cells, the rectangles are in bins) also sums the rectangles' areas in BINS:
+    // one more column of the table, whose total is the number of list entries the frame needs (launch_bin, two levels)
+    const int stride = nbins + (shift ? 1 : 0);
+    uint32_t area = 0;
+    for (int b = threadIdx.x; b < nb_s + (shift ? 1 : 0); b += CNT_THREADS) s_cnt[b] = 0;
     __syncthreads();
     // a workgroup takes `rounds` rounds of 2048 consecutive ranks into the same counters: one table row per workgroup, so
     // that a large frame's [workgroup][bin] table stays small (launch_bin)
@@ -88,7 +100,7 @@ __global__ __launch_bounds__(CNT_THREADS) void k_bin_count(const uint32_t* __res
 #ifdef GSR_BOUNDS
 #pragma unroll
     for (int st = 0; st < CNT_STEPS; st++) {
-        const BinRect bq = unpack_rect(rc[st]);
+        const BinRect bq = unpack_rect(rc[st], shift);
         if (bq.x0 <= bq.x1) { GSR_BOUND(bin, 1, bq.x1, nbxb); GSR_BOUND(bin, 1, bq.y1, g.nby); GSR_BOUND(bin, 1, bq.y0, bq.y1 + 1); }
     }
 #endif
@@ -101,7 +113,11 @@ __global__ __launch_bounds__(CNT_THREADS) void k_bin_count(const uint32_t* __res
     }
 #pragma unroll
     for (int st = 0; st < CNT_STEPS; st++) {
-        const BinRect br = unpack_rect(rc[st]);
+        const BinRect br = unpack_rect(rc[st], shift);
+        if (shift) {
+            const BinRect fine = unpack_rect(rc[st]);
+            if (fine.x0 <= fine.x1) area += (uint32_t)((fine.x1 - fine.x0 + 1) * (fine.y1 - fine.y0 + 1));
+        }
         if (br.x0 <= br.x1)
             for (int y = max(br.y0, y_lo); y <= min(br.y1, y_hi - 1); y++)
                 for (int x = br.x0; x <= br.x1; x++) {
@@ -110,8 +126,13 @@ __global__ __launch_bounds__(CNT_THREADS) void k_bin_count(const uint32_t* __res
                 }
     }
     }   // rounds
+    if (shift) {
+#pragma unroll
+        for (int off = WAVE / 2; off; off >>= 1) area += __shfl_xor(area, off);
+        if ((threadIdx.x & (WAVE - 1)) == 0) atomicAdd(&s_cnt[nb_s], area);
+    }
     __syncthreads();
-    for (int b = threadIdx.x; b < nb_s; b += CNT_THREADS) table[(size_t)blockIdx.x * nbins + y_lo * nbxb + b] = s_cnt[b];
+    for (int b = threadIdx.x; b < nb_s + (shift ? 1 : 0); b += CNT_THREADS) table[(size_t)blockIdx.x * stride + y_lo * nbxb + b] = s_cnt[b];
 }
 
 // (the scan of table[block][bin] down the blocks, and bin_total[], is launch_column_scan of k_sort.hip)
@@ -459,6 +480,60 @@ __global__ __launch_bounds__(FIN_THREADS) void k_bin_starts(const uint32_t* __re
     if (threadIdx.x == 0) bin_start_pre[nbins] = tot.v[0];
 }
 
+
+// ---------------------------------------------------------------------------
+// Two-level binning (large bin grids: launch_bin).  Level one is the pass below over a grid of CELLS of 4 x 4 bins: a
+// splat enters every cell its rectangle touches -- 1.7 cells instead of 5.2 bins per splat on C4, with tables of 510
+// instead of 8160 columns -- and the cell lists keep the depth order; an entry carries the splat's rectangle in bins.
+// Level two cuts every cell list into chunks of CELL_CHUNK entries and places each entry in the 16 bins of its cell:
+// per 64 entries and bin one ballot and a lane count -- no LDS lane sets, no atomics, no loops of different lengths
+// in one wave (k_cell_count, k_cell_scan, k_cell_scatter2).  The lists are the ones the one-level pass builds, entry
+// for entry.
+// ---------------------------------------------------------------------------
+constexpr int CELL_SHIFT = 2;
+constexpr int CELL_SIDE = 1 << CELL_SHIFT;                 // bins along a cell's side
+constexpr int CELL_FINE = CELL_SIDE * CELL_SIDE;           // bins of a cell
+constexpr uint32_t CELL_CHUNK = 2048;                      // cell-list entries per level-two pass of a workgroup
+struct CellArgs {
+    uint32_t* cell_start;    // ncells + 1: first cell-list entry of every cell
+    uint32_t* chunk_start;   // ncells + 2: first chunk of every cell; [ncells] = the frame's chunks; [ncells + 1] = list entries the frame needs
+    uint4* chunk_info;       // per chunk: (cell, first entry, end entry, -) -- what a level-two workgroup needs to know about its chunk
+    int shift;               // CELL_SHIFT in the cell pass, 0 otherwise
+};
+
+// The extra workgroup of the cell pass: starts of the cells and of their chunks.  cell_total[ncells] is the total of the
+// count pass's area column = the list entries the frame needs: a frame that does not fit gets no chunks (level two then
+// reports the need and the frame is rendered again after the regrowth, as in the one-level path).
+__device__ __forceinline__ void cell_finalize_body(const uint32_t* __restrict__ cell_total, int ncells, uint32_t capacity, const CellArgs& ca)
+{
+    __shared__ uint32_t s_w[2][FIN_WAVES];
+    const int per = (ncells + FIN_THREADS - 1) / FIN_THREADS;
+    const int b0 = threadIdx.x * per, b1 = min(b0 + per, ncells);
+    UN<2> mine = {{0, 0}}, tot;
+    for (int b = b0; b < b1; b++) {
+        const uint32_t c = cell_total[b];
+        mine.v[0] += c;
+        mine.v[1] += (c + CELL_CHUNK - 1u) / CELL_CHUNK;
+    }
+    const UN<2> ex = block_exclusive_scan<2>(mine, s_w, &tot);
+    const uint32_t need = cell_total[ncells];
+    uint32_t e = ex.v[0], k = ex.v[1];
+    for (int b = b0; b < b1; b++) {
+        const uint32_t c = cell_total[b];
+        ca.cell_start[b] = e;
+        ca.chunk_start[b] = k;
+        if (need <= capacity)
+            for (uint32_t o = 0; o < c; o += CELL_CHUNK) ca.chunk_info[k++] = make_uint4((uint32_t)b, e + o, e + min(o + CELL_CHUNK, c), 0u);
+        else k += (c + CELL_CHUNK - 1u) / CELL_CHUNK;
+        e += c;
+    }
+    if (threadIdx.x == 0) {
+        ca.cell_start[ncells] = tot.v[0];
+        ca.chunk_start[ncells] = need <= capacity ? tot.v[1] : 0u;
+        ca.chunk_start[ncells + 1] = need;
+    }
+}
+
 // The scatter body.  Two kernels wrap it (below):
 //  * k_bin_scatter<GROUPS, FUSED>, 64 registers = 8 waves per SIMD, two of these 16-wave workgroups per CU.  FUSED (small
 //    bin grids): the finalize step runs as an extra workgroup and every scatter workgroup scans the bin totals itself --
@@ -472,7 +547,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_bin_starts(const uint32_t* __re
 //    carrying over, so that the [workgroup][bin] table all three binning kernels exchange is 20 MB instead of 80 MB at
 //    5 M splats (more than the lists it helps to build).  Inside the 64-register kernel the same two things spilled 15 and
 //    44 registers and cost more than they saved (C4 binning 477 -> 533 us, profiles/r03_experiments.txt).
-template <int GROUPS, bool FUSED, bool BIG, int SPW /* 64-rank steps per wave and round */>
+template <int GROUPS, bool FUSED, bool BIG, int SPW /* 64-rank steps per wave and round */, bool CELLS = false>
 __device__ __forceinline__ void bin_scatter_body(const uint32_t* __restrict__ depth_index,
                                                               const uint32_t* __restrict__ rects,
                                                               const uint32_t* __restrict__ count, BinGrid g, BinSlices sl,
@@ -480,16 +555,21 @@ __device__ __forceinline__ void bin_scatter_body(const uint32_t* __restrict__ de
                                                               const uint32_t* __restrict__ bin_total /* FUSED */,
                                                               const uint32_t* __restrict__ bin_start /* !FUSED */,
                                                               uint32_t* __restrict__ list, uint32_t capacity,
-                                                              uint32_t* __restrict__ overflow, uint32_t rounds, const FinalizeArgs& fa)
+                                                              uint32_t* __restrict__ overflow, uint32_t rounds, const FinalizeArgs& fa,
+                                                              const CellArgs& ca)
 {
     static_assert(FIN_THREADS == SCAT_THREADS, "the finalize step runs as a workgroup of this kernel");
     static_assert(!(FUSED && BIG), "the large-grid form reads the bin starts from k_bin_starts");
+    static_assert(!CELLS || FUSED, "the cell pass of the two-level binning is the fused form");
     constexpr bool EXTRA = FUSED || BIG;   // the finalize step is a workgroup of this launch
     if (EXTRA && blockIdx.x == (BIG ? 0u : gridDim.x - 1u)) {   // bin starts, work items and frame counters for the compositor
         extern __shared__ uint32_t s_fin[];   // this workgroup's share of the kernel's dynamic LDS (>= FIN_SCRATCH_WORDS, launch_bin)
-        if (blockIdx.y == 0) bin_finalize_body(fa, s_fin);
+        if (CELLS) cell_finalize_body(bin_total, (g.bx_hi - g.bx_lo) * g.nby, capacity, ca);   // (the cell pass: cell and chunk starts for level two)
+        else if (blockIdx.y == 0) bin_finalize_body(fa, s_fin);
         return;
     }
+    const int shift = CELLS ? ca.shift : 0;
+    const int table_stride = (g.bx_hi - g.bx_lo) * g.nby + (CELLS ? 1 : 0);   // (the cell pass's table has the area column, k_bin_count)
     const uint32_t blk = xcd_group_remap(blockIdx.x - (BIG ? 1u : 0u), gridDim.x - (EXTRA ? 1u : 0u));   // neighbouring rank blocks on one XCD (gsr_internal.h)
     constexpr int WAVES_PER_GROUP = SCAT_WAVES / GROUPS;            // 4 or 2
     constexpr int STEPS = SCAT_WAVES * SPW;                         // steps of a round: 32 (2048 ranks) or 16 (1024)
@@ -524,7 +604,7 @@ __device__ __forceinline__ void bin_scatter_body(const uint32_t* __restrict__ de
             const int ly = b / sw, lx = b - ly * sw;
             const int gb = (sy0 + ly) * nbxb + sx0 + lx;  // the bin's index in the band
             GSR_BOUND(bin, 3, blk, gridDim.x);
-            base[b] = bin_start[gb] + table[(size_t)blk * nbins + gb];
+            base[b] = bin_start[gb] + table[(size_t)blk * table_stride + gb];
         }
     } else {
         __shared__ uint32_t s_ws[SCAT_WAVES];
@@ -545,7 +625,7 @@ __device__ __forceinline__ void bin_scatter_body(const uint32_t* __restrict__ de
         for (int gb = gb0; gb < gb1; gb++) {
             const int gy = gb / nbxb, gx = gb - gy * nbxb;
             const uint32_t c = bin_total[gb];
-            if (gx >= sx0 && gx < sx1 && gy >= sy0 && gy < sy1) base[(gy - sy0) * sw + (gx - sx0)] = run + table[(size_t)blk * nbins + gb];
+            if (gx >= sx0 && gx < sx1 && gy >= sy0 && gy < sy1) base[(gy - sy0) * sw + (gx - sx0)] = run + table[(size_t)blk * table_stride + gb];
             run += c;
         }
     }
@@ -566,6 +646,7 @@ __device__ __forceinline__ void bin_scatter_body(const uint32_t* __restrict__ de
     const uint32_t gbegin = rbegin + group * (GROUP_STEPS * WAVE);
     uint32_t idx[SPW];
     BinRect br[SPW];
+    uint32_t raw[CELLS ? SPW : 1];   // the cell pass hands the rectangle (in bins) on to level two
 #pragma unroll
     for (int k = 0; k < SPW; k++) {
         const uint32_t r = gbegin + (sub * SPW + k) * WAVE + lane;
@@ -574,7 +655,9 @@ __device__ __forceinline__ void bin_scatter_body(const uint32_t* __restrict__ de
 #pragma unroll
     for (int k = 0; k < SPW; k++) {
         const uint32_t r = gbegin + (sub * SPW + k) * WAVE + lane;
-        BinRect b = unpack_rect((r < n) ? rects[r] : RECT_NONE);
+        const uint32_t packed = (r < n) ? rects[r] : RECT_NONE;
+        if (CELLS) raw[k] = packed;
+        BinRect b = unpack_rect(packed, shift);
         if (b.x0 <= b.x1) {
             b.x0 = max(b.x0, sx0) - sx0; b.x1 = min(b.x1, sx1 - 1) - sx0;
             b.y0 = max(b.y0, sy0) - sy0; b.y1 = min(b.y1, sy1 - 1) - sy0;
@@ -648,8 +731,9 @@ __device__ __forceinline__ void bin_scatter_body(const uint32_t* __restrict__ de
                 }
                 dst += lanes_below64(own);
                 GSR_BOUND(bin, 0, myidx, 0xfffffff0u);
-                if (dst < capacity) list[dst] = myidx;
-                else atomicOr(overflow, 1u);
+                if (dst >= capacity) atomicOr(overflow, 1u);
+                else if (CELLS) reinterpret_cast<uint2*>(list)[dst] = make_uint2(myidx, raw[k]);
+                else list[dst] = myidx;
             }
         }
     }
@@ -664,12 +748,18 @@ __device__ __forceinline__ void bin_scatter_body(const uint32_t* __restrict__ de
     const uint32_t *__restrict__ depth_index, const uint32_t *__restrict__ rects, const uint32_t *__restrict__ count,   \
         BinGrid g, BinSlices sl, const uint32_t *__restrict__ table, const uint32_t *__restrict__ bin_total,            \
         const uint32_t *__restrict__ bin_start, uint32_t *__restrict__ list, uint32_t capacity,                         \
-        uint32_t *__restrict__ overflow, uint32_t rounds, FinalizeArgs fa
-#define GSR_SCATTER_ARGS depth_index, rects, count, g, sl, table, bin_total, bin_start, list, capacity, overflow, rounds, fa
+        uint32_t *__restrict__ overflow, uint32_t rounds, FinalizeArgs fa, CellArgs ca
+#define GSR_SCATTER_ARGS depth_index, rects, count, g, sl, table, bin_total, bin_start, list, capacity, overflow, rounds, fa, ca
 template <int GROUPS, bool FUSED>
 __global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bin_scatter(GSR_SCATTER_PARAMS)
 {
     bin_scatter_body<GROUPS, FUSED, false, SCAT_STEPS_PER_WAVE>(GSR_SCATTER_ARGS);
+}
+// level one of the two-level binning: the same pass over a grid of CELLS, entries = (splat index, rectangle in bins)
+template <int GROUPS>
+__global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_cell_scatter1(GSR_SCATTER_PARAMS)
+{
+    bin_scatter_body<GROUPS, true, false, SCAT_STEPS_PER_WAVE, true>(GSR_SCATTER_ARGS);
 }
 template <int GROUPS, int SPW>
 __global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_bin_scatter_big(GSR_SCATTER_PARAMS)
@@ -678,6 +768,251 @@ __global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(4,
 }
 #undef GSR_SCATTER_PARAMS
 #undef GSR_SCATTER_ARGS
+
+
+// ---- level two ----
+struct CellGeom { int32_t ncx, ncells, nbxb, nby; };   // cells across, cells, bins across / down (of the band)
+
+// chunk -> its cell and its entries [e0, e1) of the cell list (uniform; chunk < chunk_start[ncells])
+__device__ __forceinline__ void chunk_span(uint32_t chunk, const uint4* __restrict__ chunk_info, uint32_t capacity, int& cell, uint32_t& e0, uint32_t& e1)
+{
+    const uint4 ci = chunk_info[chunk];
+    cell = (int)ci.x;
+    e0 = min(ci.y, capacity);
+    e1 = min(ci.z, capacity);
+}
+
+// the bins of the cell at (fx0, fy0) that a rectangle covers: bit ly * 4 + lx
+__device__ __forceinline__ uint32_t cell_mask(uint32_t rect, int fx0, int fy0)
+{
+    const BinRect r = unpack_rect(rect);
+    const int lx0 = max(r.x0 - fx0, 0), lx1 = min(r.x1 - fx0, CELL_SIDE - 1);
+    const int ly0 = max(r.y0 - fy0, 0), ly1 = min(r.y1 - fy0, CELL_SIDE - 1);
+    if (lx0 > lx1 || ly0 > ly1) return 0u;
+    const uint32_t cols = ((2u << lx1) - 1u) & ~((1u << lx0) - 1u);
+    const uint32_t rows = ((2u << ly1) - 1u) & ~((1u << ly0) - 1u);
+    const uint32_t rowexp = (rows & 1u) | ((rows & 2u) << 3) | ((rows & 4u) << 6) | ((rows & 8u) << 9);
+    return cols * rowexp;
+}
+
+// entries of every bin of the cell among this wave's two steps: bin f's count in lane f.  Every lane spreads its mask's
+// 16 bits over the bytes of four words, the words are summed over the wave (row sums with four DPP steps, the four rows
+// through scalar registers), and lane f picks byte f: ~75 instructions instead of 32 ballots and population counts.
+__device__ __forceinline__ uint32_t dpp_row_sum(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);   // row_half_mirror
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true);   // row_mirror
+    return v;   // every lane: the sum over its row of 16
+}
+__device__ __forceinline__ uint32_t cell_wave_counts(uint32_t m0, uint32_t m1, int lane)
+{
+    uint32_t t[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t w = ((((m0 >> (4 * j)) & 15u) * 0x00204081u) & 0x01010101u) + ((((m1 >> (4 * j)) & 15u) * 0x00204081u) & 0x01010101u);
+        const uint32_t r = dpp_row_sum(w);   // <= 32 per byte
+        t[j] = (uint32_t)__builtin_amdgcn_readlane((int)r, 0) + (uint32_t)__builtin_amdgcn_readlane((int)r, 16) +
+               (uint32_t)__builtin_amdgcn_readlane((int)r, 32) + (uint32_t)__builtin_amdgcn_readlane((int)r, 48);   // <= 128 per byte
+    }
+    const int j = lane >> 2;
+    const uint32_t w = j == 0 ? t[0] : j == 1 ? t[1] : j == 2 ? t[2] : t[3];
+    return (w >> ((lane & 3) * 8)) & 0xffu;   // (lanes >= 16: of no use)
+}
+
+// table2[chunk][bin of the cell] = entries the chunk puts into the bin
+__global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_cell_count(const uint2* __restrict__ cell_list, const uint4* __restrict__ chunk_info, const uint32_t* __restrict__ chunk_start,
+                  CellGeom cg, uint32_t capacity, uint32_t* __restrict__ table2)
+{
+    __shared__ uint32_t s_cnt[CELL_FINE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t total_chunks = chunk_start[cg.ncells];
+    for (uint32_t chunk = blockIdx.x; chunk < total_chunks; chunk += gridDim.x) {
+        if (threadIdx.x < CELL_FINE) s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        int cell; uint32_t e0, e1;
+        chunk_span(chunk, chunk_info, capacity, cell, e0, e1);
+        const int fx0 = (cell % cg.ncx) * CELL_SIDE, fy0 = (cell / cg.ncx) * CELL_SIDE;
+        uint32_t m[SCAT_STEPS_PER_WAVE];
+#pragma unroll
+        for (int k = 0; k < SCAT_STEPS_PER_WAVE; k++) {
+            const uint32_t e = e0 + (uint32_t)((wave * SCAT_STEPS_PER_WAVE + k) * WAVE + lane);
+            m[k] = e < e1 ? cell_mask(cell_list[e].y, fx0, fy0) : 0u;
+        }
+        const uint32_t mine = cell_wave_counts(m[0], m[1], lane);
+        if (lane < CELL_FINE && mine) atomicAdd(&s_cnt[lane], mine);
+        __syncthreads();
+        if (threadIdx.x < CELL_FINE) table2[(size_t)chunk * CELL_FINE + threadIdx.x] = s_cnt[threadIdx.x];
+    }
+}
+
+// per cell (one wave): table2 scanned down the cell's chunks for each of its 16 bins; the bins' totals.  Lane = (bin,
+// one of four consecutive chunks).
+__global__ __launch_bounds__(WAVE) void k_cell_scan(uint32_t* __restrict__ table2, const uint32_t* __restrict__ chunk_start, CellGeom cg,
+                                                    uint32_t capacity, uint32_t* __restrict__ bin_total)
+{
+    const int cell = blockIdx.x, lane = threadIdx.x, f = lane & (CELL_FINE - 1), ph = lane >> 4;
+    // a frame that does not fit has no chunks (cell_finalize_body): its need goes into the first bin's total, where the
+    // finalize step finds it
+    const uint32_t need = chunk_start[cg.ncells + 1];
+    const uint32_t c0 = chunk_start[cell], c1 = need <= capacity ? chunk_start[cell + 1] : c0;
+    uint32_t run = 0;
+    for (uint32_t c = c0; c < c1; c += 4) {
+        const bool ok = c + ph < c1;
+        uint32_t* p = table2 + (size_t)(c + ph) * CELL_FINE + f;
+        const uint32_t v = ok ? *p : 0u;
+        uint32_t inc = v;
+        const uint32_t u1 = __shfl_up(inc, 16);
+        if (ph >= 1) inc += u1;
+        const uint32_t u2 = __shfl_up(inc, 32);
+        if (ph >= 2) inc += u2;
+        if (ok) *p = run + inc - v;
+        run += __shfl(inc, 48 + f);
+    }
+    if (cell == 0 && f == 0 && need > capacity) run = need;
+    if (ph == 0) {
+        const int bx = (cell % cg.ncx) * CELL_SIDE + (f & (CELL_SIDE - 1)), by = (cell / cg.ncx) * CELL_SIDE + (f >> CELL_SHIFT);
+        if (bx < cg.nbxb && by < cg.nby) bin_total[by * cg.nbxb + bx] = run;
+    }
+}
+
+// the lists: entry e of a chunk goes to every bin of its mask, at the bin's start (k_bin_starts) + what earlier chunks of
+// the cell put there (table2) + what earlier waves, steps and lanes of this chunk do.  Workgroup 0 is the finalize step.
+__global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_cell_scatter2(const uint2* __restrict__ cell_list, const uint4* __restrict__ chunk_info, const uint32_t* __restrict__ chunk_start,
+                     CellGeom cg, const uint32_t* __restrict__ table2, const uint32_t* __restrict__ bin_start, uint32_t* __restrict__ list,
+                     uint32_t capacity, uint32_t* __restrict__ overflow, FinalizeArgs fa)
+{
+    static_assert(FIN_THREADS == SCAT_THREADS, "the finalize step runs as a workgroup of this kernel");
+    extern __shared__ uint32_t s_fin[];   // FIN_SCRATCH_WORDS
+    if (blockIdx.x == 0) {
+        bin_finalize_body(fa, s_fin);
+        return;
+    }
+    __shared__ uint32_t s_base[CELL_FINE];
+    __shared__ uint32_t s_wcnt[SCAT_WAVES][CELL_FINE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t total_chunks = chunk_start[cg.ncells];
+    for (uint32_t chunk = blockIdx.x - 1u; chunk < total_chunks; chunk += gridDim.x - 1u) {
+        int cell; uint32_t e0, e1;
+        chunk_span(chunk, chunk_info, capacity, cell, e0, e1);
+        const int fx0 = (cell % cg.ncx) * CELL_SIDE, fy0 = (cell / cg.ncx) * CELL_SIDE;
+        if (threadIdx.x < CELL_FINE) {
+            const int bx = fx0 + (int)(threadIdx.x & (CELL_SIDE - 1)), by = fy0 + (int)(threadIdx.x >> CELL_SHIFT);
+            s_base[threadIdx.x] = (bx < cg.nbxb && by < cg.nby) ? bin_start[by * cg.nbxb + bx] + table2[(size_t)chunk * CELL_FINE + threadIdx.x] : 0u;
+        }
+        uint32_t idx[SCAT_STEPS_PER_WAVE], m[SCAT_STEPS_PER_WAVE];
+#pragma unroll
+        for (int k = 0; k < SCAT_STEPS_PER_WAVE; k++) {
+            const uint32_t e = e0 + (uint32_t)((wave * SCAT_STEPS_PER_WAVE + k) * WAVE + lane);
+            const uint2 en = e < e1 ? cell_list[e] : make_uint2(0u, 0u);
+            idx[k] = en.x;
+            m[k] = e < e1 ? cell_mask(en.y, fx0, fy0) : 0u;
+        }
+        const uint32_t mine = cell_wave_counts(m[0], m[1], lane);
+        if (lane < CELL_FINE) s_wcnt[wave][lane] = mine;
+        __syncthreads();
+        // lane f: this wave's first slot in bin f
+        uint32_t wb = 0;
+        if (lane < CELL_FINE) {
+            wb = s_base[lane];
+#pragma unroll
+            for (int w = 0; w < SCAT_WAVES; w++) {
+                const uint32_t c = s_wcnt[w][lane];
+                wb += w < wave ? c : 0u;
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < CELL_FINE; f++) {
+            uint32_t sb = (uint32_t)__builtin_amdgcn_readlane((int)wb, f);
+#pragma unroll
+            for (int k = 0; k < SCAT_STEPS_PER_WAVE; k++) {
+                const bool hit = ((m[k] >> f) & 1u) != 0u;
+                const uint64_t b = __ballot(hit);
+                if (b == 0ull) continue;
+                if (hit) {
+                    // (inside the list by construction: a frame whose need exceeds the capacity has no chunks)
+                    const uint32_t dst = min(sb + lanes_below64(b), capacity - 1u);
+                    GSR_BOUND(bin, 0, idx[k], 0xfffffff0u);
+                    GSR_BOUND(bin, 2, sb + lanes_below64(b), capacity);
+                    list[dst] = idx[k];
+                }
+                sb += (uint32_t)__popcll(b);
+            }
+        }
+        __syncthreads();   // s_base / s_wcnt are rewritten for the next chunk
+    }
+}
+
+static void set_scatter_lds_attribute()
+{
+    // dynamic LDS above the default needs the attribute raised (1080p: 64 KiB, 4K: 8160 bins -> 146 KiB).  The attribute
+    // belongs to the current device's copy of each instantiation: raised to the budget once per device for all of them.
+    static std::once_flag once[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::call_once(once[dev >= 0 && dev < 64 ? dev : 0], [] {
+        const int want = (int)(SCAT_LDS_BUDGET + 1024);
+        for (const void* fn : {(const void*)k_bin_scatter<8, true>, (const void*)k_bin_scatter<8, false>,
+                               (const void*)k_bin_scatter<4, true>, (const void*)k_bin_scatter<4, false>,
+                               (const void*)k_bin_scatter_big<8, 2>, (const void*)k_bin_scatter_big<4, 2>,
+                               (const void*)k_bin_scatter_big<4, 1>, (const void*)k_cell_scatter1<8>, (const void*)k_cell_scatter1<4>})
+            (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, want);
+        (void)hipGetLastError();  // a failure shows up as the launch error
+    });
+}
+
+static FinalizeArgs make_finalize_args(const BinBuffers& b, int nbins, uint32_t n)
+{
+    return FinalizeArgs{b.bin_total, nbins, b.seg_len, b.seg_target_items, b.items_by_size, b.seg_len_dev, b.max_items, b.capacity,
+                        b.slots, n ? 1u : 0u, b.bin_start, b.seg_start, b.items, b.overflow, b.visible, b.tile_entries, b.accum,
+                        b.report, b.queue, b.queue_start, b.mailbox, b.bin_mask, b.bin_sat, b.long_policy, b.seg_len_long, b.long_tau, b.npix, b.quad_from, b.long_tiles_x2,
+                        b.spec};
+}
+
+// cells across / down a grid of bins
+inline int cells_of(int bins) { return (bins + CELL_SIDE - 1) >> CELL_SHIFT; }
+
+// Two levels (see "Two-level binning" above): count / scan / scatter over the cells, then count / scan / scatter of the
+// cell lists' chunks into the bins; the finalize step is the first workgroup of the last kernel.
+static void launch_bin_two_level(const BinBuffers& b, const BinGrid& g, hipStream_t s)
+{
+    const int nbxb = g.bx_hi - g.bx_lo, nbins = nbxb * g.nby;
+    const int ncx = cells_of(nbxb), ncy = cells_of(g.nby), ncells = ncx * ncy;
+    BinGrid gc = g;
+    gc.nbx = ncx; gc.nby = ncy; gc.bx_lo = 0; gc.bx_hi = ncx;
+    const BinSlices sl = make_slices(ncx, ncy);
+    const bool eight = scatter_lds_bytes(sl.w, sl.h, 8) <= SCAT_LDS_TWO_PER_CU;
+    const size_t lds1 = scatter_lds_bytes(sl.w, sl.h, eight ? 8 : 4);
+    set_scatter_lds_attribute();
+    const FinalizeArgs fa = make_finalize_args(b, nbins, 1u);
+    const CellArgs ca{b.cell_start, b.chunk_start, reinterpret_cast<uint4*>(b.chunk_info), CELL_SHIFT};
+    const uint4* ci = reinterpret_cast<const uint4*>(b.chunk_info);
+    const CellGeom cg{ncx, ncells, nbxb, g.nby};
+    // level one (b.nblocks workgroups of 2048 ranks; the table's last column sums the rectangles' areas in bins)
+    hipLaunchKernelGGL(k_bin_count, dim3(b.nblocks), dim3(CNT_THREADS), (size_t)(ncells + 1) * sizeof(uint32_t), s, b.depth_index, b.rect_idx,
+                       b.count, gc, ncy, 1u, b.table, b.rects, CELL_SHIFT);
+    launch_column_scan(b.table, b.cell_total, ncells + 1, b.nblocks, s);
+    {
+        const dim3 grid(b.nblocks + 1), block(SCAT_THREADS);
+#define GSR_LAUNCH_CELLS(K)                                                                                                          \
+    hipLaunchKernelGGL((K), grid, block, lds1, s, b.depth_index, (const uint32_t*)b.rects, b.count, gc, sl, (const uint32_t*)b.table, \
+                       (const uint32_t*)b.cell_total, (const uint32_t*)nullptr, b.cell_list, b.capacity, b.overflow, 1u, fa, ca)
+        if (eight) GSR_LAUNCH_CELLS(k_cell_scatter1<8>);
+        else GSR_LAUNCH_CELLS(k_cell_scatter1<4>);
+#undef GSR_LAUNCH_CELLS
+    }
+    // level two
+    const uint2* cl = reinterpret_cast<const uint2*>(b.cell_list);
+    hipLaunchKernelGGL(k_cell_count, dim3(b.cell_grid), dim3(SCAT_THREADS), 0, s, cl, ci, (const uint32_t*)b.chunk_start, cg,
+                       b.capacity, b.cell_table2);
+    hipLaunchKernelGGL(k_cell_scan, dim3(ncells), dim3(WAVE), 0, s, b.cell_table2, (const uint32_t*)b.chunk_start, cg, b.capacity, b.bin_total);
+    hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(FIN_THREADS), 0, s, (const uint32_t*)b.bin_total, nbins, b.bin_start_pre);
+    hipLaunchKernelGGL(k_cell_scatter2, dim3(b.cell_grid + 1), dim3(SCAT_THREADS), FIN_SCRATCH_WORDS * sizeof(uint32_t), s, cl, ci,
+                       (const uint32_t*)b.chunk_start, cg, (const uint32_t*)b.cell_table2, (const uint32_t*)b.bin_start_pre, b.list, b.capacity, b.overflow, fa);
+}
 
 void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s)
 {
@@ -692,34 +1027,20 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
     // (at 1080p the large-grid form loses to the two-workgroups-per-CU kernel: C3 binning 47.3 -> 54.1 us, measured)
     const bool short_rounds = n && nbins > 4096 && b.big == 2 && !eight;
     const size_t lds = std::max(scatter_lds_bytes(sl.w, sl.h, eight ? 8 : 4, short_rounds ? SCAT_WAVES : SCAT_STEPS), FIN_SCRATCH_WORDS * sizeof(uint32_t));
-    // dynamic LDS above the default needs the attribute raised (1080p: 64 KiB, 4K: 8160 bins -> 146 KiB).  The attribute
-    // belongs to the current device's copy of each instantiation: raised to the budget once per device for all four.
-    {
-        static std::once_flag once[64];
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        std::call_once(once[dev >= 0 && dev < 64 ? dev : 0], [] {
-            const int want = (int)(SCAT_LDS_BUDGET + 1024);
-            for (const void* fn : {(const void*)k_bin_scatter<8, true>, (const void*)k_bin_scatter<8, false>,
-                                   (const void*)k_bin_scatter<4, true>, (const void*)k_bin_scatter<4, false>,
-                                   (const void*)k_bin_scatter_big<8, 2>, (const void*)k_bin_scatter_big<4, 2>,
-                                   (const void*)k_bin_scatter_big<4, 1>})
-                (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, want);
-            (void)hipGetLastError();  // a failure shows up as the launch error
-        });
+    set_scatter_lds_attribute();
+    if (n && b.two_level) {
+        launch_bin_two_level(b, g, s);
+        return;
     }
     // the count pass keeps one counter per bin in LDS and is cut into row slices only beyond 12288 bins (above 4K)
     const int cnt_slices = (nbins + CNT_MAX_BINS - 1) / CNT_MAX_BINS;
     const int cnt_rows = (g.nby + cnt_slices - 1) / cnt_slices;
     if (n) {
         hipLaunchKernelGGL(k_bin_count, dim3(b.nblocks, (g.nby + cnt_rows - 1) / cnt_rows), dim3(CNT_THREADS),
-                           (size_t)cnt_rows * nbxb * sizeof(uint32_t), s, b.depth_index, b.rect_idx, b.count, g, cnt_rows, b.rounds, b.table, b.rects);
+                           (size_t)cnt_rows * nbxb * sizeof(uint32_t), s, b.depth_index, b.rect_idx, b.count, g, cnt_rows, b.rounds, b.table, b.rects, 0);
         launch_column_scan(b.table, b.bin_total, nbins, b.nblocks, s);
     }
-    const FinalizeArgs fa{b.bin_total, nbins, b.seg_len, b.seg_target_items, b.items_by_size, b.seg_len_dev, b.max_items, b.capacity,
-                          b.slots, n ? 1u : 0u, b.bin_start, b.seg_start, b.items, b.overflow, b.visible, b.tile_entries, b.accum,
-                          b.report, b.queue, b.queue_start, b.mailbox, b.bin_mask, b.bin_sat, b.long_policy, b.seg_len_long, b.long_tau, b.npix, b.quad_from, b.long_tiles_x2,
-                          b.spec};
+    const FinalizeArgs fa = make_finalize_args(b, nbins, n);
     const bool fused = n && nbins <= 4096;   // see bin_scatter_body
     const bool big = n && !fused && b.big;   // the large-grid form: finalize as the first workgroup, rounds
     if (!fused && !big) hipLaunchKernelGGL(k_bin_finalize, dim3(1), dim3(FIN_THREADS), FIN_SCRATCH_WORDS * sizeof(uint32_t), s, fa);
@@ -729,7 +1050,7 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
 #define GSR_LAUNCH_SCATTER(K, STARTS)                                                                                               \
     hipLaunchKernelGGL((K), grid, block, lds, s, b.depth_index, (const uint32_t*)b.rects, b.count, g, sl,                           \
                        (const uint32_t*)b.table, (const uint32_t*)b.bin_total, (const uint32_t*)(STARTS), b.list, b.capacity,       \
-                       b.overflow, b.rounds, fa)
+                       b.overflow, b.rounds, fa, CellArgs{nullptr, nullptr, nullptr, 0})
         if (big && eight) GSR_LAUNCH_SCATTER((k_bin_scatter_big<8, 2>), b.bin_start_pre);
         else if (big && short_rounds) GSR_LAUNCH_SCATTER((k_bin_scatter_big<4, 1>), b.bin_start_pre);
         else if (big) GSR_LAUNCH_SCATTER((k_bin_scatter_big<4, 2>), b.bin_start_pre);
