@@ -89,7 +89,7 @@ struct gsr_ctx {
     long bin_rounds_env = 0;
     int bin_two_level_env = -1;       // GSR_BIN_TWO_LEVEL: 0 / 1 force the one- / two-level binning (alloc_bins); -1: by the bin grid
     bool bin_two_level = false;
-    uint32_t *cell_list = nullptr, *cell_total = nullptr, *cell_start = nullptr, *chunk_start = nullptr, *chunk_info = nullptr, *cell_table2 = nullptr;
+    uint32_t *cell_list = nullptr, *cell_total = nullptr, *cell_start = nullptr, *chunk_start = nullptr, *chunk_info = nullptr, *cell_table2 = nullptr, *cell_wcnt = nullptr;
     uint32_t cell_capacity_alloc = 0, cell_ncells_alloc = 0, cell_grid = 0;
     uint32_t bin_big = 2;             // large bin grids: k_bin_scatter_big (GSR_BIN_BIG=0: the 64-register kernel + k_bin_finalize; 1: 2048-rank rounds)
     uint32_t *seg_start = nullptr, *items = nullptr;
@@ -105,6 +105,9 @@ struct gsr_ctx {
     int blend_sub_env = 0;
     int spec = 0;                     // GSR_SPEC=1: dense frames as speculative segments (k_bin_finalize) instead of whole-bin work items
     uint32_t* bin_rects = nullptr;
+    uint32_t* rect_tmp = nullptr;     // the rectangles between the two LSD passes (rect_carry)
+    bool rect_carry = true;           // LSD sort order: the packed rectangles travel with the keys (GSR_RECT_CARRY=0: the binning gathers them)
+    bool rects_sorted_now = false;    // this frame's sort left the rectangles in depth order
     float4* partial = nullptr;
     uint32_t bin_blocks = 0, bin_capacity = 0, bin_table_elems = 0, bin_nbins_alloc = 0;
     uint32_t max_items = 0, seg_len = 0, blend_grid = 2048;
@@ -331,6 +334,7 @@ int alloc_bins(gsr_ctx* c)
             if (int r = dev_alloc(c, &c->cell_list, (size_t)c->bin_capacity * 2)) return r;
             if (int r = dev_alloc(c, &c->cell_table2, ((size_t)c->bin_capacity / 2048u + ncells + 1u) * 16u)) return r;
             if (int r = dev_alloc(c, &c->chunk_info, ((size_t)c->bin_capacity / 2048u + ncells + 1u) * 4u)) return r;
+            if (int r = dev_alloc(c, &c->cell_wcnt, ((size_t)c->bin_capacity / 2048u + ncells + 1u) * 64u)) return r;
             c->cell_capacity_alloc = c->bin_capacity;
         }
         // the level-two kernels stride over the frame's chunks: two 16-wave workgroups per CU, twice over
@@ -409,8 +413,10 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
         const bool cull = render && band_is_partial(c);
         SortBuffers sb{c->depth, c->slots, c->fstate->minmax, c->keys, c->keys_tmp, c->idx_tmp, c->depth_index,
                        c->block_hist, c->fstate->digit_total, c->rect_idx, cull ? 1 : 0, &c->fstate->sorted_count, c->sort_kpb, c->sort_blocks,
-                       c->bucket_order_now ? 1 : 0, reinterpret_cast<uint32_t*>(c->mailbox_dev + 1)};
+                       c->bucket_order_now ? 1 : 0, reinterpret_cast<uint32_t*>(c->mailbox_dev + 1),
+                       c->rect_tmp, (render && c->rect_carry && !c->bucket_order_now) ? c->bin_rects : nullptr};
         c->sort_culled = cull;
+        c->rects_sorted_now = sb.rects_out != nullptr;
         launch_sort(sb, c->n, s);
     }
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_SORT], s));
@@ -418,14 +424,14 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
         const BinGrid g = make_grid(c);
         const int nbins = (g.bx_hi - g.bx_lo) * g.nby;
         if (!c->n) HIP_TRY(c, hipMemsetAsync(c->bin_total, 0, sizeof(uint32_t) * nbins, s));
-        BinBuffers bb{c->depth_index, &c->fstate->sorted_count, c->bin_table, c->slots, c->rect_idx, c->bin_rects, c->bin_total, c->bin_start, c->bin_start_pre, c->bin_rounds, c->bin_big, c->seg_start,
+        BinBuffers bb{c->depth_index, &c->fstate->sorted_count, c->bin_table, c->slots, c->rect_idx, c->bin_rects, (c->n && c->rects_sorted_now) ? 1u : 0u, c->bin_total, c->bin_start, c->bin_start_pre, c->bin_rounds, c->bin_big, c->seg_start,
                       c->items, c->bin_list, &c->fstate->overflow, &c->fstate->visible, &c->fstate->tile_entries,
                       c->accum, c->mailbox_dev, c->fstate->report, c->bin_capacity, c->max_items, c->seg_len, &c->fstate->seg_len, c->items_by_size, &c->fstate->queue, std::min<uint32_t>(c->max_items, c->blend_grid), c->seg_target_items, c->bin_blocks, c->bin_mask, c->bin_sat,
                       c->seg_len == SEG_LEN_WHOLE_BIN ? 0 : c->long_items >= 0 ? c->long_items : c->saturate ? -1 : 0, SEG_LEN_LONG,
                       (c->opt.flags & GSR_FLAG_THROUGHPUT) ? LONG_TAU_THROUGHPUT : LONG_TAU_EXACT,
                       (uint32_t)((g.bx_hi - g.bx_lo) * BIN_PX) * (uint32_t)c->H, c->quad_from,
                       (c->opt.flags & GSR_FLAG_THROUGHPUT) ? LONG_TILES_X2_THROUGHPUT : LONG_TILES_X2_EXACT,
-                      c->bin_two_level ? 1u : 0u, c->cell_list, c->cell_total, c->cell_start, c->chunk_start, c->chunk_info, c->cell_table2, c->cell_grid,
+                      c->bin_two_level ? 1u : 0u, c->cell_list, c->cell_total, c->cell_start, c->chunk_start, c->chunk_info, c->cell_wcnt, c->cell_table2, c->cell_grid,
                       (uint32_t)c->spec};
         launch_bin(bb, g, c->n, s);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BIN], s));
@@ -463,7 +469,7 @@ static std::vector<uint64_t> chain_signature(const gsr_ctx* c)
     U(c->bin_capacity); U(c->max_items); U(c->seg_len); U(c->seg_target_items); U(c->blend_grid); U(c->bin_blocks); U(c->bin_rounds); U(c->bin_big); P(c->bin_start_pre);
     U((uint64_t)c->opt.flags); U((uint64_t)(c->opt.early_out_eps * 1e9f)); U(c->bucket_order_now ? 1u : 0u); U(c->saturate ? 1u : 0u); U((uint64_t)c->items_by_size); U(c->quad_from); U((uint64_t)(int64_t)c->long_items);
     U((uint64_t)c->spec); U(c->blend_sub);
-    U(c->bin_two_level ? 1u : 0u); P(c->cell_list); P(c->cell_total); P(c->cell_start); P(c->chunk_start); P(c->chunk_info); P(c->cell_table2); U(c->cell_grid);
+    U(c->bin_two_level ? 1u : 0u); P(c->cell_list); P(c->cell_total); P(c->cell_start); P(c->chunk_start); P(c->chunk_info); P(c->cell_wcnt); P(c->cell_table2); U(c->cell_grid); P(c->rect_tmp); U(c->rect_carry ? 1u : 0u);
     return v;
 }
 
@@ -671,6 +677,7 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
     if (const char* e = getenv("GSR_BIN_ROUNDS")) c->bin_rounds_env = std::min(64L, std::max(0L, atol(e)));
     if (const char* e = getenv("GSR_BIN_BIG")) c->bin_big = (uint32_t)std::min(2, std::max(0, atoi(e)));
     if (const char* e = getenv("GSR_BIN_TWO_LEVEL")) c->bin_two_level_env = atoi(e) ? 1 : 0;
+    if (const char* e = getenv("GSR_RECT_CARRY")) c->rect_carry = atoi(e) != 0;
     if (const char* e = getenv("GSR_BLEND_SUB")) c->blend_sub_env = atoi(e) == 2 ? 2 : atoi(e) == 1 ? 1 : 0;
     CREATE_TRY(hipMalloc((void**)&c->accum, 8 * sizeof(uint64_t)));
     CREATE_TRY(hipMemset(c->accum, 0, 8 * sizeof(uint64_t)));
@@ -716,8 +723,8 @@ int gsr_destroy(gsr_ctx* c)
     dev_free(&c->depth); dev_free(&c->keys); dev_free(&c->keys_tmp); dev_free(&c->idx_tmp); dev_free(&c->depth_index);
     dev_free(&c->block_hist); dev_free(&c->rec); dev_free(&c->bbox); dev_free(&c->slots); dev_free(&c->rect_idx);
     dev_free(&c->bin_table); dev_free(&c->bin_total); dev_free(&c->bin_start); dev_free(&c->bin_start_pre); dev_free(&c->bin_list);
-    dev_free(&c->cell_list); dev_free(&c->cell_total); dev_free(&c->cell_start); dev_free(&c->chunk_start); dev_free(&c->chunk_info); dev_free(&c->cell_table2);
-    dev_free(&c->seg_start); dev_free(&c->bin_mask); dev_free(&c->bin_sat); dev_free(&c->items); dev_free(&c->partial); dev_free(&c->bin_rects);
+    dev_free(&c->cell_list); dev_free(&c->cell_total); dev_free(&c->cell_start); dev_free(&c->chunk_start); dev_free(&c->chunk_info); dev_free(&c->cell_wcnt); dev_free(&c->cell_table2);
+    dev_free(&c->seg_start); dev_free(&c->bin_mask); dev_free(&c->bin_sat); dev_free(&c->items); dev_free(&c->partial); dev_free(&c->bin_rects); dev_free(&c->rect_tmp);
     drop_graph(c);
     dev_free(&c->cam_dev);
     dev_free(&c->fstate); dev_free(&c->accum); dev_free(&c->fb); dev_free(&c->fb8);
@@ -749,7 +756,7 @@ int alloc_scene(gsr_ctx* c, uint32_t n, bool with_rows)
         (r = dev_alloc(c, &c->rgba, n)) || (r = dev_alloc(c, &c->depth, n)) || (r = dev_alloc(c, &c->keys, n)) ||
         (r = dev_alloc(c, &c->keys_tmp, n)) || (r = dev_alloc(c, &c->idx_tmp, n)) ||
         (r = dev_alloc(c, &c->depth_index, n)) || (r = dev_alloc(c, &c->rec, n)) || (r = dev_alloc(c, &c->bbox, n)) ||
-        (r = dev_alloc(c, &c->bin_rects, n)) || (r = dev_alloc(c, &c->rect_idx, n)))
+        (r = dev_alloc(c, &c->bin_rects, n)) || (r = dev_alloc(c, &c->rect_idx, n)) || (r = dev_alloc(c, &c->rect_tmp, n)))
         return r;
     if (with_rows && ((r = dev_alloc(c, &c->rotv, n)) || (r = dev_alloc(c, &c->sclv, n)))) return r;
     // keys per radix workgroup: the scatter stores runs of keys_per_block / 2^bits keys, so larger scenes take larger
@@ -1250,6 +1257,24 @@ int gsr_read_bin_totals(gsr_ctx* c, uint32_t* out, int32_t* nbx, int32_t* nby)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (nbx) *nbx = w;
     if (nby) *nby = g.nby;
+    return GSR_OK;
+}
+
+int gsr_read_bin_lists(gsr_ctx* c, uint32_t* starts, uint32_t* list, uint64_t list_words)
+{
+    if (!c || !starts) return c ? fail(c, GSR_ERR_ARG, "starts is NULL") : GSR_ERR_ARG;
+    if (!c->have_frame) return fail(c, GSR_ERR_ARG, "no frame has been rendered yet");
+    const BinGrid g = make_grid(c);
+    const size_t nbins = (size_t)(g.bx_hi - g.bx_lo) * g.nby;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(starts, c->bin_start, (nbins + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint64_t total = starts[nbins];
+    if (list) {
+        if (total > list_words || total > c->bin_capacity) return fail(c, GSR_ERR_ARG, "the frame's lists hold %llu entries", (unsigned long long)total);
+        HIP_TRY(c, hipMemcpyAsync(list, c->bin_list, total * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
     return GSR_OK;
 }
 

@@ -156,6 +156,8 @@ struct SortBuffers {
     uint32_t nblocks;
     int bucket_order;          // 1: high digit first + one workgroup per bucket (4 launches); 0: LSD (6 launches); see k_sort.hip
     uint32_t* max_bucket;      // out: keys in the frame's largest high-digit bucket (host-mapped word)
+    uint32_t* rect_tmp;        // LSD order with rects_out: the rectangles after the first pass
+    uint32_t* rects_out;       // LSD order: out: the packed bin rectangles in depth order (null: not carried; the binning gathers them)
 };
 void launch_sort(const SortBuffers& b, uint32_t n, hipStream_t s);
 // column scan (k_sort.hip), shared with the binning
@@ -173,6 +175,7 @@ struct BinBuffers {
     const int32_t* slots;        // FRAME_SLOTS partial (visible splats, 16x16 tile overlaps) sums of k_project_key
     const uint32_t* rect_idx;    // n: packed bin rectangle of every splat (k_project_key)
     uint32_t* rects;             // n: the same in depth order (count pass -> scatter pass)
+    uint32_t rects_sorted;       // 1: the sort has left them there already (SortBuffers::rects_out)
     uint32_t* bin_total;         // nbins (zeroed by the caller when n == 0)
     uint32_t* bin_start;         // nbins + 1
     uint32_t* bin_start_pre;     // nbins + 1: the same starts, computed ahead of the scatter by k_bin_starts (large-grid form)
@@ -213,6 +216,7 @@ struct BinBuffers {
     uint32_t* cell_start;        // cells + 1
     uint32_t* chunk_start;       // cells + 2: first chunk of each cell, the frame's chunks, the frame's need
     uint32_t* chunk_info;        // (capacity / 2048 + cells) x 4: per chunk its cell, first and end entry
+    uint32_t* cell_wcnt;         // (capacity / 2048 + cells) x 64 words: per chunk, bin and wave of k_cell_scatter2 one byte: the wave's entries
     uint32_t* cell_table2;       // (capacity / 2048 + cells) x 16: per chunk and bin of its cell: entries, then their first slot
     uint32_t cell_grid;          // workgroups of the level-two kernels (they stride over the frame's chunks)
     uint32_t spec;               // dense frames (long_policy): 1 = speculative segments -- the plain cut, handed out layer by layer, segments

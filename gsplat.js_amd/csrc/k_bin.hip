@@ -71,7 +71,7 @@ constexpr int CNT_MAX_BINS = 12288;  // LDS counters per workgroup (48 KiB); lar
 
 __global__ __launch_bounds__(CNT_THREADS) void k_bin_count(const uint32_t* __restrict__ depth_index, const uint32_t* __restrict__ rect_idx,
                                                            const uint32_t* __restrict__ count, BinGrid g, int slice_rows,
-                                                           uint32_t rounds, uint32_t* __restrict__ table, uint32_t* __restrict__ rects, int shift)
+                                                           uint32_t rounds, uint32_t* __restrict__ table, uint32_t* __restrict__ rects, int shift, int sorted)
 {
     const uint32_t n = *count;  // ranks the sort produced (all splats, or the band's survivors)
     extern __shared__ uint32_t s_cnt[];  // this slice's bins
@@ -90,13 +90,21 @@ __global__ __launch_bounds__(CNT_THREADS) void k_bin_count(const uint32_t* __res
     const uint32_t begin = (blockIdx.x * rounds + rd) * BIN_RANKS_PER_BLOCK;
     if (begin >= n) break;
     uint32_t idx[CNT_STEPS], rc[CNT_STEPS];
+    if (sorted) {   // (uniform) the sort carried the rectangles into depth order: no gather
 #pragma unroll
-    for (int st = 0; st < CNT_STEPS; st++) {
-        const uint32_t r = begin + st * CNT_THREADS + threadIdx.x;
-        idx[st] = (r < n) ? depth_index[r] : 0xffffffffu;
+        for (int st = 0; st < CNT_STEPS; st++) {
+            const uint32_t r = begin + st * CNT_THREADS + threadIdx.x;
+            rc[st] = (r < n) ? rects[r] : RECT_NONE;
+        }
+    } else {
+#pragma unroll
+        for (int st = 0; st < CNT_STEPS; st++) {
+            const uint32_t r = begin + st * CNT_THREADS + threadIdx.x;
+            idx[st] = (r < n) ? depth_index[r] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int st = 0; st < CNT_STEPS; st++) rc[st] = (idx[st] != 0xffffffffu) ? rect_idx[idx[st]] : RECT_NONE;
     }
-#pragma unroll
-    for (int st = 0; st < CNT_STEPS; st++) rc[st] = (idx[st] != 0xffffffffu) ? rect_idx[idx[st]] : RECT_NONE;
 #ifdef GSR_BOUNDS
 #pragma unroll
     for (int st = 0; st < CNT_STEPS; st++) {
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(CNT_THREADS) void k_bin_count(const uint32_t* __res
         if (bq.x0 <= bq.x1) { GSR_BOUND(bin, 1, bq.x1, nbxb); GSR_BOUND(bin, 1, bq.y1, g.nby); GSR_BOUND(bin, 1, bq.y0, bq.y1 + 1); }
     }
 #endif
-    if (blockIdx.y == 0) {   // slice 0 also leaves the rectangles in depth order
+    if (blockIdx.y == 0 && !sorted) {   // slice 0 also leaves the rectangles in depth order
 #pragma unroll
         for (int st = 0; st < CNT_STEPS; st++) {
             const uint32_t r = begin + st * CNT_THREADS + threadIdx.x;
@@ -782,8 +790,8 @@ __device__ __forceinline__ void chunk_span(uint32_t chunk, const uint4* __restri
     e1 = min(ci.z, capacity);
 }
 
-// the bins of the cell at (fx0, fy0) that a rectangle covers: bit ly * 4 + lx
-__device__ __forceinline__ uint32_t cell_mask(uint32_t rect, int fx0, int fy0)
+// the columns (bits 0..3) and rows (bits 4..7) of the cell at (fx0, fy0) that a rectangle covers; 0: none
+__device__ __forceinline__ uint32_t cell_cols_rows(uint32_t rect, int fx0, int fy0)
 {
     const BinRect r = unpack_rect(rect);
     const int lx0 = max(r.x0 - fx0, 0), lx1 = min(r.x1 - fx0, CELL_SIDE - 1);
@@ -791,6 +799,12 @@ __device__ __forceinline__ uint32_t cell_mask(uint32_t rect, int fx0, int fy0)
     if (lx0 > lx1 || ly0 > ly1) return 0u;
     const uint32_t cols = ((2u << lx1) - 1u) & ~((1u << lx0) - 1u);
     const uint32_t rows = ((2u << ly1) - 1u) & ~((1u << ly0) - 1u);
+    return cols | (rows << CELL_SIDE);
+}
+// ... as one bit per bin: bit ly * 4 + lx
+__device__ __forceinline__ uint32_t cell_mask(uint32_t cr)
+{
+    const uint32_t cols = cr & 15u, rows = cr >> CELL_SIDE;
     const uint32_t rowexp = (rows & 1u) | ((rows & 2u) << 3) | ((rows & 4u) << 6) | ((rows & 8u) << 9);
     return cols * rowexp;
 }
@@ -821,10 +835,11 @@ __device__ __forceinline__ uint32_t cell_wave_counts(uint32_t m0, uint32_t m1, i
     return (w >> ((lane & 3) * 8)) & 0xffu;   // (lanes >= 16: of no use)
 }
 
-// table2[chunk][bin of the cell] = entries the chunk puts into the bin
+// table2[chunk][bin of the cell] = entries the chunk puts into the bin; wcnt[chunk][bin][wave] = those of each wave's 128
+// entries (one byte each), which is what a wave of k_cell_scatter2 needs to know about the waves in front of it
 __global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_cell_count(const uint2* __restrict__ cell_list, const uint4* __restrict__ chunk_info, const uint32_t* __restrict__ chunk_start,
-                  CellGeom cg, uint32_t capacity, uint32_t* __restrict__ table2)
+                  CellGeom cg, uint32_t capacity, uint32_t* __restrict__ table2, uint8_t* __restrict__ wcnt)
 {
     __shared__ uint32_t s_cnt[CELL_FINE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -839,10 +854,13 @@ void k_cell_count(const uint2* __restrict__ cell_list, const uint4* __restrict__
 #pragma unroll
         for (int k = 0; k < SCAT_STEPS_PER_WAVE; k++) {
             const uint32_t e = e0 + (uint32_t)((wave * SCAT_STEPS_PER_WAVE + k) * WAVE + lane);
-            m[k] = e < e1 ? cell_mask(cell_list[e].y, fx0, fy0) : 0u;
+            m[k] = e < e1 ? cell_mask(cell_cols_rows(cell_list[e].y, fx0, fy0)) : 0u;
         }
         const uint32_t mine = cell_wave_counts(m[0], m[1], lane);
-        if (lane < CELL_FINE && mine) atomicAdd(&s_cnt[lane], mine);
+        if (lane < CELL_FINE) {
+            wcnt[(size_t)chunk * (CELL_FINE * SCAT_WAVES) + lane * SCAT_WAVES + wave] = (uint8_t)mine;   // (<= 128)
+            if (mine) atomicAdd(&s_cnt[lane], mine);
+        }
         __syncthreads();
         if (threadIdx.x < CELL_FINE) table2[(size_t)chunk * CELL_FINE + threadIdx.x] = s_cnt[threadIdx.x];
     }
@@ -878,50 +896,72 @@ __global__ __launch_bounds__(WAVE) void k_cell_scan(uint32_t* __restrict__ table
     }
 }
 
+// One store instruction of k_cell_scatter2: the lanes of set `b` write `val` to list[sb + (set lanes below)].  The set is
+// the AND of two scalar lane sets, so it becomes the exec mask as it is -- no per-lane test, three vector instructions.
+__device__ __forceinline__ void store_set(uint64_t b, uint32_t sb, uint32_t val, uint32_t* __restrict__ list)
+{
+    uint32_t t;
+    uint64_t sv;
+    asm volatile("s_and_saveexec_b64 %[sv], %[b]\n\t"
+                 "v_mbcnt_lo_u32_b32 %[t], %[blo], 0\n\t"
+                 "v_mbcnt_hi_u32_b32 %[t], %[bhi], %[t]\n\t"
+                 "v_add_lshl_u32 %[t], %[t], %[sb], 2\n\t"
+                 "global_store_dword %[t], %[val], %[base]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [t] "=&v"(t), [sv] "=&s"(sv)
+                 : [b] "s"(b), [blo] "s"((uint32_t)b), [bhi] "s"((uint32_t)(b >> 32)), [sb] "s"(sb), [val] "v"(val), [base] "s"(list)
+                 : "memory", "scc");
+}
+
 // the lists: entry e of a chunk goes to every bin of its mask, at the bin's start (k_bin_starts) + what earlier chunks of
-// the cell put there (table2) + what earlier waves, steps and lanes of this chunk do.  Workgroup 0 is the finalize step.
+// the cell put there (table2) + what earlier waves (wcnt), steps and lanes of this chunk do.  An entry's mask is columns x
+// rows, so the set of lanes of a step that cover bin (x, y) is colset[x] & rowset[y]: eight ballots per step and scalar
+// ANDs give all sixteen sets.  No LDS, no barrier.  Workgroup 0 is the finalize step.
 __global__ __launch_bounds__(SCAT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_cell_scatter2(const uint2* __restrict__ cell_list, const uint4* __restrict__ chunk_info, const uint32_t* __restrict__ chunk_start,
-                     CellGeom cg, const uint32_t* __restrict__ table2, const uint32_t* __restrict__ bin_start, uint32_t* __restrict__ list,
-                     uint32_t capacity, uint32_t* __restrict__ overflow, FinalizeArgs fa)
+                     CellGeom cg, const uint32_t* __restrict__ table2, const uint8_t* __restrict__ wcnt, const uint32_t* __restrict__ bin_start,
+                     uint32_t* __restrict__ list, uint32_t capacity, FinalizeArgs fa)
 {
     static_assert(FIN_THREADS == SCAT_THREADS, "the finalize step runs as a workgroup of this kernel");
+    static_assert(SCAT_WAVES == 16, "a bin's per-wave counts are one 16-byte load");
     extern __shared__ uint32_t s_fin[];   // FIN_SCRATCH_WORDS
     if (blockIdx.x == 0) {
         bin_finalize_body(fa, s_fin);
         return;
     }
-    __shared__ uint32_t s_base[CELL_FINE];
-    __shared__ uint32_t s_wcnt[SCAT_WAVES][CELL_FINE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t total_chunks = chunk_start[cg.ncells];
     for (uint32_t chunk = blockIdx.x - 1u; chunk < total_chunks; chunk += gridDim.x - 1u) {
         int cell; uint32_t e0, e1;
         chunk_span(chunk, chunk_info, capacity, cell, e0, e1);
         const int fx0 = (cell % cg.ncx) * CELL_SIDE, fy0 = (cell / cg.ncx) * CELL_SIDE;
-        if (threadIdx.x < CELL_FINE) {
-            const int bx = fx0 + (int)(threadIdx.x & (CELL_SIDE - 1)), by = fy0 + (int)(threadIdx.x >> CELL_SHIFT);
-            s_base[threadIdx.x] = (bx < cg.nbxb && by < cg.nby) ? bin_start[by * cg.nbxb + bx] + table2[(size_t)chunk * CELL_FINE + threadIdx.x] : 0u;
+        // lane f < 16: this wave's first slot in bin f
+        uint32_t wb = 0;
+        if (lane < CELL_FINE) {
+            const int bx = fx0 + (lane & (CELL_SIDE - 1)), by = fy0 + (lane >> CELL_SHIFT);
+            const uint4 wc = *reinterpret_cast<const uint4*>(wcnt + (size_t)chunk * (CELL_FINE * SCAT_WAVES) + lane * SCAT_WAVES);
+            const uint32_t w4[4] = {wc.x, wc.y, wc.z, wc.w};
+            if (bx < cg.nbxb && by < cg.nby) wb = bin_start[by * cg.nbxb + bx] + table2[(size_t)chunk * CELL_FINE + lane];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {   // bytes of the waves in front of mine
+                const int nb = min(max(wave - 4 * j, 0), 4);
+                const uint32_t keep = nb == 4 ? 0xffffffffu : (1u << (8 * nb)) - 1u;
+                wb = __builtin_amdgcn_sad_u8(w4[j] & keep, 0u, wb);
+            }
         }
-        uint32_t idx[SCAT_STEPS_PER_WAVE], m[SCAT_STEPS_PER_WAVE];
+        uint32_t idx[SCAT_STEPS_PER_WAVE];
+        uint64_t colset[SCAT_STEPS_PER_WAVE][CELL_SIDE], rowset[SCAT_STEPS_PER_WAVE][CELL_SIDE];
 #pragma unroll
         for (int k = 0; k < SCAT_STEPS_PER_WAVE; k++) {
             const uint32_t e = e0 + (uint32_t)((wave * SCAT_STEPS_PER_WAVE + k) * WAVE + lane);
-            const uint2 en = e < e1 ? cell_list[e] : make_uint2(0u, 0u);
+            const uint2 en = e < e1 ? cell_list[e] : make_uint2(0u, RECT_NONE);
             idx[k] = en.x;
-            m[k] = e < e1 ? cell_mask(en.y, fx0, fy0) : 0u;
-        }
-        const uint32_t mine = cell_wave_counts(m[0], m[1], lane);
-        if (lane < CELL_FINE) s_wcnt[wave][lane] = mine;
-        __syncthreads();
-        // lane f: this wave's first slot in bin f
-        uint32_t wb = 0;
-        if (lane < CELL_FINE) {
-            wb = s_base[lane];
+            GSR_BOUND(bin, 0, idx[k], 0xfffffff0u);
+            const uint32_t cr = e < e1 ? cell_cols_rows(en.y, fx0, fy0) : 0u;
 #pragma unroll
-            for (int w = 0; w < SCAT_WAVES; w++) {
-                const uint32_t c = s_wcnt[w][lane];
-                wb += w < wave ? c : 0u;
+            for (int x = 0; x < CELL_SIDE; x++) {
+                colset[k][x] = __ballot((cr >> x) & 1u);
+                rowset[k][x] = __ballot((cr >> (CELL_SIDE + x)) & 1u);
             }
         }
 #pragma unroll
@@ -929,20 +969,14 @@ void k_cell_scatter2(const uint2* __restrict__ cell_list, const uint4* __restric
             uint32_t sb = (uint32_t)__builtin_amdgcn_readlane((int)wb, f);
 #pragma unroll
             for (int k = 0; k < SCAT_STEPS_PER_WAVE; k++) {
-                const bool hit = ((m[k] >> f) & 1u) != 0u;
-                const uint64_t b = __ballot(hit);
+                const uint64_t b = colset[k][f & (CELL_SIDE - 1)] & rowset[k][f >> CELL_SHIFT];
                 if (b == 0ull) continue;
-                if (hit) {
-                    // (inside the list by construction: a frame whose need exceeds the capacity has no chunks)
-                    const uint32_t dst = min(sb + lanes_below64(b), capacity - 1u);
-                    GSR_BOUND(bin, 0, idx[k], 0xfffffff0u);
-                    GSR_BOUND(bin, 2, sb + lanes_below64(b), capacity);
-                    list[dst] = idx[k];
-                }
+                // (inside the list by construction: a frame whose need exceeds the capacity has no chunks)
+                GSR_BOUND(bin, 2, sb + (uint32_t)__popcll(b) - 1u, capacity);
+                store_set(b, sb, idx[k], list);
                 sb += (uint32_t)__popcll(b);
             }
         }
-        __syncthreads();   // s_base / s_wcnt are rewritten for the next chunk
     }
 }
 
@@ -993,7 +1027,7 @@ static void launch_bin_two_level(const BinBuffers& b, const BinGrid& g, hipStrea
     const CellGeom cg{ncx, ncells, nbxb, g.nby};
     // level one (b.nblocks workgroups of 2048 ranks; the table's last column sums the rectangles' areas in bins)
     hipLaunchKernelGGL(k_bin_count, dim3(b.nblocks), dim3(CNT_THREADS), (size_t)(ncells + 1) * sizeof(uint32_t), s, b.depth_index, b.rect_idx,
-                       b.count, gc, ncy, 1u, b.table, b.rects, CELL_SHIFT);
+                       b.count, gc, ncy, 1u, b.table, b.rects, CELL_SHIFT, (int)b.rects_sorted);
     launch_column_scan(b.table, b.cell_total, ncells + 1, b.nblocks, s);
     {
         const dim3 grid(b.nblocks + 1), block(SCAT_THREADS);
@@ -1007,11 +1041,12 @@ static void launch_bin_two_level(const BinBuffers& b, const BinGrid& g, hipStrea
     // level two
     const uint2* cl = reinterpret_cast<const uint2*>(b.cell_list);
     hipLaunchKernelGGL(k_cell_count, dim3(b.cell_grid), dim3(SCAT_THREADS), 0, s, cl, ci, (const uint32_t*)b.chunk_start, cg,
-                       b.capacity, b.cell_table2);
+                       b.capacity, b.cell_table2, reinterpret_cast<uint8_t*>(b.cell_wcnt));
     hipLaunchKernelGGL(k_cell_scan, dim3(ncells), dim3(WAVE), 0, s, b.cell_table2, (const uint32_t*)b.chunk_start, cg, b.capacity, b.bin_total);
     hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(FIN_THREADS), 0, s, (const uint32_t*)b.bin_total, nbins, b.bin_start_pre);
     hipLaunchKernelGGL(k_cell_scatter2, dim3(b.cell_grid + 1), dim3(SCAT_THREADS), FIN_SCRATCH_WORDS * sizeof(uint32_t), s, cl, ci,
-                       (const uint32_t*)b.chunk_start, cg, (const uint32_t*)b.cell_table2, (const uint32_t*)b.bin_start_pre, b.list, b.capacity, b.overflow, fa);
+                       (const uint32_t*)b.chunk_start, cg, (const uint32_t*)b.cell_table2, reinterpret_cast<const uint8_t*>(b.cell_wcnt),
+                       (const uint32_t*)b.bin_start_pre, b.list, b.capacity, fa);
 }
 
 void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s)
@@ -1037,7 +1072,7 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
     const int cnt_rows = (g.nby + cnt_slices - 1) / cnt_slices;
     if (n) {
         hipLaunchKernelGGL(k_bin_count, dim3(b.nblocks, (g.nby + cnt_rows - 1) / cnt_rows), dim3(CNT_THREADS),
-                           (size_t)cnt_rows * nbxb * sizeof(uint32_t), s, b.depth_index, b.rect_idx, b.count, g, cnt_rows, b.rounds, b.table, b.rects, 0);
+                           (size_t)cnt_rows * nbxb * sizeof(uint32_t), s, b.depth_index, b.rect_idx, b.count, g, cnt_rows, b.rounds, b.table, b.rects, 0, (int)b.rects_sorted);
         launch_column_scan(b.table, b.bin_total, nbins, b.nblocks, s);
     }
     const FinalizeArgs fa = make_finalize_args(b, nbins, n);

@@ -243,14 +243,18 @@ constexpr size_t scatter_lds_bytes(uint32_t keys_per_block)
     return (size_t)(SCAT_WAVES * (1 << BITS) + 2 * (1 << BITS) + 3 * ((1 << BITS) / WAVE) + 2 * keys_per_block) * sizeof(uint32_t);
 }
 
-template <int BITS, int SHIFT, bool FIRST>
+// PAY: one more word per key travels with it (the splat's packed bin rectangle, from rect order to depth order in the two
+// LSD passes: the binning then reads it in rank order instead of gathering 4 bytes per rank through depthIndex -- 5 M
+// random reads, 60 of k_bin_count's 79 us on C4).  It takes the index image's place in LDS once that has been streamed out.
+template <int BITS, int SHIFT, bool FIRST, bool PAY = false>
 __global__ __launch_bounds__(SCAT_THREADS) void k_scatter(const uint32_t* __restrict__ keys_in,
                                                           const uint32_t* __restrict__ idx_in, uint32_t n_in,
                                                           uint32_t* __restrict__ count,
                                                           uint32_t keys_per_block, const uint32_t* __restrict__ base,
                                                           const uint32_t* __restrict__ total,
                                                           uint32_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out,
-                                                          uint32_t* __restrict__ max_bucket)
+                                                          uint32_t* __restrict__ max_bucket,
+                                                          const uint32_t* __restrict__ pay_in = nullptr, uint32_t* __restrict__ pay_out = nullptr)
 {
     constexpr int BINS = 1 << BITS;
     static_assert(BINS <= SCAT_THREADS, "one digit per thread");
@@ -284,12 +288,14 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter(const uint32_t* __rest
 
     // phase 1: load this wave's keys (and, in the last pass, their indices) into registers; count digits per wave
     uint32_t key[SCAT_MAX_STEPS], src[SCAT_MAX_STEPS];
+    uint32_t pay[PAY ? SCAT_MAX_STEPS : 1], pos[PAY ? SCAT_MAX_STEPS : 1];
 #pragma unroll
     for (int k = 0; k < SCAT_MAX_STEPS; k++) {
         const uint32_t i = wbegin + k * WAVE + lane;
         const bool in = (uint32_t)k < steps && i < wend;
         key[k] = in ? keys_in[i] : 0xffffffffu;
         src[k] = FIRST ? i : (in ? idx_in[i] : 0u);
+        if (PAY) pay[k] = in ? pay_in[i] : 0u;
     }
 #pragma unroll
     for (int k = 0; k < SCAT_MAX_STEPS; k++)
@@ -362,6 +368,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter(const uint32_t* __rest
             GSR_BOUND(sort, 1, p, keys_per_block);
             lkey[p] = key[k];
             lidx[p] = src[k];
+            if (PAY) pos[k] = p;
         }
     }
     __syncthreads();
@@ -374,6 +381,16 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter(const uint32_t* __rest
         GSR_BOUND(sort, 3, kv, DEPTH_RANGE + 1u);
         if (keys_out) keys_out[dst] = kv;
         idx_out[dst] = lidx[p];
+    }
+    if (PAY) {
+        __syncthreads();   // the index image has been streamed out
+#pragma unroll
+        for (int k = 0; k < SCAT_MAX_STEPS; k++) {
+            if ((uint32_t)k >= steps) break;
+            if (key[k] != 0xffffffffu) lidx[pos[k]] = pay[k];
+        }
+        __syncthreads();
+        for (uint32_t p = threadIdx.x; p < nlocal; p += SCAT_THREADS) pay_out[gdelta[(lkey[p] >> SHIFT) & (BINS - 1)] + p] = lidx[p];
     }
 #ifdef GSR_KSTAMPS
     __syncthreads();
@@ -549,6 +566,10 @@ void launch_sort(const SortBuffers& b, uint32_t n, hipStream_t s)
                                       (int)scatter_lds_bytes<RADIX_HI_BITS>(SCAT_THREADS * SCAT_MAX_STEPS));
             (void)hipFuncSetAttribute((const void*)k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)scatter_lds_bytes<RADIX_HI_BITS>(SCAT_THREADS * SCAT_MAX_STEPS));
+            (void)hipFuncSetAttribute((const void*)k_scatter<RADIX_LO_BITS, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)scatter_lds_bytes<RADIX_LO_BITS>(SCAT_THREADS * SCAT_MAX_STEPS));
+            (void)hipFuncSetAttribute((const void*)k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)scatter_lds_bytes<RADIX_HI_BITS>(SCAT_THREADS * SCAT_MAX_STEPS));
             (void)hipGetLastError();   // a failure shows up as the launch error
         });
     }
@@ -559,7 +580,7 @@ void launch_sort(const SortBuffers& b, uint32_t n, hipStream_t s)
         launch_column_scan(b.block_hist, total_hi, RADIX_HI_BINS, b.nblocks, s);
         hipLaunchKernelGGL((k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, true>), grid, dim3(SCAT_THREADS), lds_hi, s, (const uint32_t*)b.keys,
                            (const uint32_t*)nullptr, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
-                           (const uint32_t*)total_hi, b.keys_tmp, b.idx_tmp, (uint32_t*)nullptr);
+                           (const uint32_t*)total_hi, b.keys_tmp, b.idx_tmp, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
         hipLaunchKernelGGL(k_local_sort, dim3(local_sort_grid(n)), dim3(LOCAL_THREADS), 0, s, (const uint32_t*)b.keys_tmp,
                            (const uint32_t*)b.idx_tmp, (const uint32_t*)total_hi, b.depth_index, b.max_bucket);
         return;
@@ -567,15 +588,26 @@ void launch_sort(const SortBuffers& b, uint32_t n, hipStream_t s)
     hipLaunchKernelGGL(k_quantise_hist, grid, block, 0, s, b.depth, b.slots, b.minmax, n, b.keys_per_block,
                        b.rect, b.cull, b.keys, b.block_hist, 0, RADIX_LO_BINS);
     launch_column_scan(b.block_hist, total_lo, RADIX_LO_BINS, b.nblocks, s);
-    hipLaunchKernelGGL((k_scatter<RADIX_LO_BITS, 0, true>), grid, dim3(SCAT_THREADS), lds_lo, s, (const uint32_t*)b.keys,
-                       (const uint32_t*)nullptr, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
-                       (const uint32_t*)total_lo, b.keys_tmp, b.idx_tmp, (uint32_t*)nullptr);
+    const bool carry = b.rects_out != nullptr;   // the packed rectangles travel with the keys (k_scatter, PAY)
+    if (carry)
+        hipLaunchKernelGGL((k_scatter<RADIX_LO_BITS, 0, true, true>), grid, dim3(SCAT_THREADS), lds_lo, s, (const uint32_t*)b.keys,
+                           (const uint32_t*)nullptr, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
+                           (const uint32_t*)total_lo, b.keys_tmp, b.idx_tmp, (uint32_t*)nullptr, b.rect, b.rect_tmp);
+    else
+        hipLaunchKernelGGL((k_scatter<RADIX_LO_BITS, 0, true>), grid, dim3(SCAT_THREADS), lds_lo, s, (const uint32_t*)b.keys,
+                           (const uint32_t*)nullptr, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
+                           (const uint32_t*)total_lo, b.keys_tmp, b.idx_tmp, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
     hipLaunchKernelGGL(k_hist_hi, grid, block, 0, s, (const uint32_t*)b.keys_tmp, (const uint32_t*)b.count, b.keys_per_block,
                        b.block_hist);
     launch_column_scan(b.block_hist, total_hi, RADIX_HI_BINS, b.nblocks, s);
-    hipLaunchKernelGGL((k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, false>), grid, dim3(SCAT_THREADS), lds_hi, s, (const uint32_t*)b.keys_tmp,
-                       (const uint32_t*)b.idx_tmp, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
-                       (const uint32_t*)total_hi, (uint32_t*)nullptr, b.depth_index, b.max_bucket);
+    if (carry)
+        hipLaunchKernelGGL((k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, false, true>), grid, dim3(SCAT_THREADS), lds_hi, s, (const uint32_t*)b.keys_tmp,
+                           (const uint32_t*)b.idx_tmp, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
+                           (const uint32_t*)total_hi, (uint32_t*)nullptr, b.depth_index, b.max_bucket, (const uint32_t*)b.rect_tmp, b.rects_out);
+    else
+        hipLaunchKernelGGL((k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, false>), grid, dim3(SCAT_THREADS), lds_hi, s, (const uint32_t*)b.keys_tmp,
+                           (const uint32_t*)b.idx_tmp, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
+                           (const uint32_t*)total_hi, (uint32_t*)nullptr, b.depth_index, b.max_bucket, (const uint32_t*)nullptr, (uint32_t*)nullptr);
 }
 
 }  // namespace gsr

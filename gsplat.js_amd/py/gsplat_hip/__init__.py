@@ -59,7 +59,7 @@ EXPORTS = [
     "gsr_set_scene_rows", "gsr_scene_translate", "gsr_scene_rotate", "gsr_scene_scale", "gsr_scene_limit_box", "gsr_read_scene", "gsr_set_band", "gsr_set_camera",
     "gsr_sort", "gsr_render", "gsr_render_async", "gsr_sync", "gsr_read_depth_index", "gsr_read_pixels_rgba32f",
     "gsr_read_pixels_rgba8", "gsr_get_timings", "gsr_reset_timings", "gsr_set_timing_interval", "gsr_read_keys", "gsr_read_records",
-    "gsr_read_bin_totals", "gsr_convert_rgba8_async", "gsr_framebuffer8_device_ptr",
+    "gsr_read_bin_totals", "gsr_read_bin_lists", "gsr_convert_rgba8_async", "gsr_framebuffer8_device_ptr",
     "gsr_pack_band_rgba8_async", "gsr_unpack_slabs_rgba8_async",
     "gsr_framebuffer_device_ptr", "gsr_stream_handle", "gsr_stream_order", "gsr_device_info", "gsplat_sort_host",
     "gsr_overflow_pending", "gsr_set_list_capacity", "gsr_scene_count", "gsr_build_id",
@@ -132,6 +132,7 @@ def load_library(path=None):
     L.gsr_read_keys.argtypes = [vp, vp, vp]
     L.gsr_read_records.argtypes = [vp, vp, vp]
     L.gsr_read_bin_totals.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+    L.gsr_read_bin_lists.argtypes = [vp, vp, vp, ctypes.c_uint64]
     L.gsr_convert_rgba8_async.argtypes = [vp]
     L.gsr_read_work_items.argtypes = [vp, vp]
     L.gsr_stream_order.argtypes = [vp, vp, ctypes.c_int32]
@@ -496,6 +497,15 @@ class HIPRenderer:
         nbx, nby = ctypes.c_int32(0), ctypes.c_int32(0)
         self._check(self._L.gsr_read_bin_totals(self._ctx, out.ctypes.data, ctypes.byref(nbx), ctypes.byref(nby)))
         return out[:nbx.value * nby.value].reshape(nby.value, nbx.value)
+
+    def bin_lists(self):
+        """The last frame's bin lists: (starts [bins + 1], list [entries]) -- splat indices, front to back inside each 32x32 bin."""
+        nbins = self.bin_totals().size
+        starts = np.zeros(nbins + 1, dtype=np.uint32)
+        self._check(self._L.gsr_read_bin_lists(self._ctx, starts.ctypes.data, None, 0))
+        lst = np.zeros(max(int(starts[-1]), 1), dtype=np.uint32)
+        self._check(self._L.gsr_read_bin_lists(self._ctx, starts.ctypes.data, lst.ctypes.data, lst.size))
+        return starts, lst[:int(starts[-1])]
 
     def work_items(self):
         """How the last frame's bin lists were cut for the compositor: entries per segment, work items, whether the segments

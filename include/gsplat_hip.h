@@ -184,6 +184,11 @@ int gsr_read_work_items(gsr_ctx *ctx, uint32_t *out /* 5 */);
 /* ---- multi-GPU helpers ---- */
 /* Entries per 32x32 bin of the last rendered frame, row-major over the context's band (cost model for balanced bands). */
 int gsr_read_bin_totals(gsr_ctx *ctx, uint32_t *out /* nbx*nby */, int32_t *nbx, int32_t *nby);
+/* The last rendered frame's bin lists (diagnostic; what the compositor walks: the reference has no counterpart, its GPU
+ * rasteriser visits every splat for every pixel, WebGLRenderer.ts:282-296): starts[b] .. starts[b + 1] delimit bin b's
+ * entries in `list` (splat indices, front to back), bins row-major over the context's band, starts[nbx * nby] = entries of
+ * the frame.  `list` may be NULL (starts only); GSR_ERR_ARG when it holds fewer than that many words. */
+int gsr_read_bin_lists(gsr_ctx *ctx, uint32_t *starts /* nbx*nby + 1 */, uint32_t *list, uint64_t list_words);
 /* Enqueue the f32 -> RGBA8 conversion of the framebuffer on the context's stream (result: gsr_framebuffer8_device_ptr). */
 int gsr_convert_rgba8_async(gsr_ctx *ctx);
 void *gsr_framebuffer8_device_ptr(gsr_ctx *ctx); /* uint8[h][w][4] on the device */

@@ -60,7 +60,14 @@ def test_no_index_leaves_its_array(monkeypatch):
     monkeypatch.setenv("GSR_SORT_ORDER", "lsd")
     render("C2", (7,)).dispose()                                       # the six-launch radix order
     monkeypatch.delenv("GSR_SORT_ORDER")
-    render("C1", (9,), size=(3840, 2160)).dispose()                    # 8160 bins: the large-grid binning kernels
+    render("C1", (9,), size=(3840, 2160)).dispose()                    # 8160 bins: two-level binning (cells, then chunks)
+    render("C2", (9,), size=(3840, 2160)).dispose()                    # ... with cell lists of several chunks
+    monkeypatch.setenv("GSR_SORT_ORDER", "lsd")
+    render("C2", (31,), size=(3840, 2160)).dispose()                   # ... and the rectangles carried through the radix passes
+    monkeypatch.delenv("GSR_SORT_ORDER")
+    monkeypatch.setenv("GSR_BIN_TWO_LEVEL", "0")
+    render("C1", (9,), size=(3840, 2160)).dispose()                    # the one-level large-grid kernels
+    monkeypatch.delenv("GSR_BIN_TWO_LEVEL")
     r = render("C1", (21,))
     r.set_list_capacity(1024)                                          # overflow: no work published, then regrowth
     r.set_camera(gh.orbit_camera(50, 120, r.width, r.height, gh.synth.CONFIGS["C1"]["fx"]))
@@ -70,4 +77,4 @@ def test_no_index_leaves_its_array(monkeypatch):
     got = _counters(L)
     bad = {(name, SITES[name][k] if k < len(SITES[name]) else k): v for name, vals in got.items() for k, v in enumerate(vals) if v}
     assert not bad, bad
-    assert frames >= 15
+    assert frames >= 18

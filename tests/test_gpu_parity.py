@@ -1026,6 +1026,85 @@ def test_band_contexts_with_multi_segment_bins_equal_the_full_frame(gh, monkeypa
             r.dispose()
 
 
+def _lists_of(gh, size, scene, cams, env, monkeypatch, band=None):
+    for k in ("GSR_BIN_TWO_LEVEL", "GSR_RECT_CARRY", "GSR_SORT_ORDER"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    r = gh.HIPRenderer(size[0], size[1], band=band) if band else gh.HIPRenderer(size[0], size[1])
+    for k in env:
+        monkeypatch.delenv(k)
+    out = []
+    for cam in cams:
+        r.render(scene, cam)
+        starts, lst = r.bin_lists()
+        out.append((starts, lst, r.lastDepthIndex(), r.readPixelsFloat(), r.stats()["overflow_frames"]))
+    r.dispose()
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["640x480", "1000x712 lsd", "4k", "4k band", "4k lsd gather"])
+def test_two_level_binning_builds_the_one_level_lists(gh, monkeypatch, case):
+    """Large bin grids are binned in two levels (k_bin.hip: cells of 4 x 4 bins with the lane-set pass, then every cell
+    list's chunks into the cell's 16 bins with ballots), and in the LSD sort order the packed rectangles travel with the
+    keys instead of being gathered through depthIndex.  Both must leave exactly the lists of the one-level pass --
+    every bin's start and every entry, i.e. the depth order inside every bin (what the front-to-back blend of
+    WebGLRenderer.ts:139-142,282-285 needs) -- and with them the same image bit for bit.  Forced on at small sizes
+    (partial cells at the right and bottom edges: 640x480 = 20 x 15 bins, 1000x712 = 32 x 23), natural at 4K, in a band
+    context (columns relative to the band), with the rectangles gathered and carried."""
+    W, H = {"640x480": (640, 480), "1000x712 lsd": (1000, 712)}.get(case, (3840, 2160))
+    n = 60000 if W < 3840 else 400000
+    scene = gh.Scene()
+    scene.setData(gh.synth.synth_rows(n, 77, sigma=1.2, s_lo=0.004, s_hi=0.09))
+    cams = [gh.orbit_camera(k, 120, W, H, 1132.0 * W / 1920.0) for k in (4, 41, 97)]
+    band = (1184, 2848) if case == "4k band" else None
+    lsd = {"GSR_SORT_ORDER": "lsd"} if "lsd" in case else {}
+    want = _lists_of(gh, (W, H), scene, cams, dict(lsd, GSR_BIN_TWO_LEVEL="0", GSR_RECT_CARRY="0"), monkeypatch, band)
+    got = _lists_of(gh, (W, H), scene, cams, dict(lsd, GSR_BIN_TWO_LEVEL="1", GSR_RECT_CARRY="0" if "gather" in case else "1"), monkeypatch, band)
+    for (ws, wl, wd, wi, _), (gs, gl, gd, gi, _) in zip(want, got):
+        assert np.array_equal(wd, gd)
+        assert np.array_equal(ws, gs), "bin starts"
+        assert ws[-1] > 4 * ws.size and np.array_equal(wl, gl), "list entries"
+        assert np.array_equal(wi, gi)
+        # a bin's entries are a subsequence of depthIndex: ranks ascending inside every bin
+        rank = np.empty(wd.size, dtype=np.int64)
+        rank[wd] = np.arange(wd.size)
+        rk = rank[gl]
+        first_of_bin = np.zeros(rk.size + 1, dtype=bool)
+        first_of_bin[gs] = True
+        assert np.all((np.diff(rk) > 0) | first_of_bin[1:rk.size])
+
+
+@pytest.mark.gpu
+def test_two_level_binning_overflow_is_repaired_in_one_regrowth(gh, monkeypatch):
+    """A frame whose lists do not fit must report how many entries it needs in ONE pass (the host regrows once and
+    renders the frame again; a second overflow is an error): the two-level pass knows the need before it has built a
+    single list -- the count pass over the cells also sums the rectangles' areas in bins -- and, when the cell lists
+    themselves would not fit, gives the frame no chunks at all."""
+    W, H = 3840, 2160
+    scene = gh.Scene()
+    scene.setData(gh.synth.synth_rows(300000, 78, sigma=1.2, s_lo=0.004, s_hi=0.09))
+    cam = gh.orbit_camera(11, 120, W, H, 2264.0)
+    ref = gh.HIPRenderer(W, H)
+    ref.render(scene, cam)
+    want = ref.readPixelsFloat()
+    entries = ref.stats()["bin_entries"]
+    ws, wl = ref.bin_lists()
+    ref.dispose()
+    for cap in (entries - 1, entries // 2, 4096):     # just too small; smaller than the lists; smaller than the cell lists
+        r = gh.HIPRenderer(W, H)
+        r.render(scene, gh.orbit_camera(60, 120, W, H, 2264.0))
+        r.set_list_capacity(int(cap))
+        r.render(scene, cam)                            # overflow -> regrow -> the same frame again
+        st = r.stats()
+        assert st["overflow_frames"] == 1 and st["dropped_frames"] == 0, (cap, st)
+        gs, gl = r.bin_lists()
+        assert np.array_equal(gs, ws) and np.array_equal(gl, wl)
+        assert np.array_equal(r.readPixelsFloat(), want)
+        r.dispose()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("long_items", ["0", "1"])
 def test_saturated_quadrants_are_skipped_without_changing_a_bit(gh, monkeypatch, long_items):
