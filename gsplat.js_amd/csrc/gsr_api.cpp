@@ -106,7 +106,9 @@ struct gsr_ctx {
     int spec = 0;                     // GSR_SPEC=1: dense frames as speculative segments (k_bin_finalize) instead of whole-bin work items
     uint32_t* bin_rects = nullptr;
     uint32_t* rect_tmp = nullptr;     // the rectangles between the two LSD passes (rect_carry)
-    bool rect_carry = true;           // LSD sort order: the packed rectangles travel with the keys (GSR_RECT_CARRY=0: the binning gathers them)
+    bool rect_carry = true;           // LSD sort order (large scenes): the packed rectangles travel with the keys (GSR_RECT_CARRY=0: the binning gathers them)
+    bool rect_carry_bucket = false;   // ... also in the bucket order (GSR_RECT_CARRY=2; measured: what k_bin_count saves, the two sort kernels
+                                      // pay -- C3 sort 35.0 -> 41.8 us, binning 47.6 -> 41.3 us -- so not by default)
     bool rects_sorted_now = false;    // this frame's sort left the rectangles in depth order
     float4* partial = nullptr;
     uint32_t bin_blocks = 0, bin_capacity = 0, bin_table_elems = 0, bin_nbins_alloc = 0;
@@ -414,7 +416,7 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
         SortBuffers sb{c->depth, c->slots, c->fstate->minmax, c->keys, c->keys_tmp, c->idx_tmp, c->depth_index,
                        c->block_hist, c->fstate->digit_total, c->rect_idx, cull ? 1 : 0, &c->fstate->sorted_count, c->sort_kpb, c->sort_blocks,
                        c->bucket_order_now ? 1 : 0, reinterpret_cast<uint32_t*>(c->mailbox_dev + 1),
-                       c->rect_tmp, (render && c->rect_carry && !c->bucket_order_now) ? c->bin_rects : nullptr};
+                       c->rect_tmp, (render && c->rect_carry && (c->rect_carry_bucket || !c->bucket_order_now)) ? c->bin_rects : nullptr};
         c->sort_culled = cull;
         c->rects_sorted_now = sb.rects_out != nullptr;
         launch_sort(sb, c->n, s);
@@ -469,7 +471,7 @@ static std::vector<uint64_t> chain_signature(const gsr_ctx* c)
     U(c->bin_capacity); U(c->max_items); U(c->seg_len); U(c->seg_target_items); U(c->blend_grid); U(c->bin_blocks); U(c->bin_rounds); U(c->bin_big); P(c->bin_start_pre);
     U((uint64_t)c->opt.flags); U((uint64_t)(c->opt.early_out_eps * 1e9f)); U(c->bucket_order_now ? 1u : 0u); U(c->saturate ? 1u : 0u); U((uint64_t)c->items_by_size); U(c->quad_from); U((uint64_t)(int64_t)c->long_items);
     U((uint64_t)c->spec); U(c->blend_sub);
-    U(c->bin_two_level ? 1u : 0u); P(c->cell_list); P(c->cell_total); P(c->cell_start); P(c->chunk_start); P(c->chunk_info); P(c->cell_wcnt); P(c->cell_table2); U(c->cell_grid); P(c->rect_tmp); U(c->rect_carry ? 1u : 0u);
+    U(c->bin_two_level ? 1u : 0u); P(c->cell_list); P(c->cell_total); P(c->cell_start); P(c->chunk_start); P(c->chunk_info); P(c->cell_wcnt); P(c->cell_table2); U(c->cell_grid); P(c->rect_tmp); U(c->rect_carry ? (c->rect_carry_bucket ? 1u : 2u) : 0u);
     return v;
 }
 
@@ -677,7 +679,7 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
     if (const char* e = getenv("GSR_BIN_ROUNDS")) c->bin_rounds_env = std::min(64L, std::max(0L, atol(e)));
     if (const char* e = getenv("GSR_BIN_BIG")) c->bin_big = (uint32_t)std::min(2, std::max(0, atoi(e)));
     if (const char* e = getenv("GSR_BIN_TWO_LEVEL")) c->bin_two_level_env = atoi(e) ? 1 : 0;
-    if (const char* e = getenv("GSR_RECT_CARRY")) c->rect_carry = atoi(e) != 0;
+    if (const char* e = getenv("GSR_RECT_CARRY")) { c->rect_carry = atoi(e) != 0; c->rect_carry_bucket = atoi(e) == 2; }
     if (const char* e = getenv("GSR_BLEND_SUB")) c->blend_sub_env = atoi(e) == 2 ? 2 : atoi(e) == 1 ? 1 : 0;
     CREATE_TRY(hipMalloc((void**)&c->accum, 8 * sizeof(uint64_t)));
     CREATE_TRY(hipMemset(c->accum, 0, 8 * sizeof(uint64_t)));

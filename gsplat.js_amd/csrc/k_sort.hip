@@ -421,7 +421,8 @@ inline uint32_t local_sort_grid(uint32_t n) { return (n + LOCAL_CHUNK - 1) / LOC
 
 __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ idx,
                                                               const uint32_t* __restrict__ total_hi,
-                                                              uint32_t* __restrict__ depth_index, uint32_t* __restrict__ max_bucket)
+                                                              uint32_t* __restrict__ depth_index, uint32_t* __restrict__ max_bucket,
+                                                              const uint32_t* __restrict__ pay_in, uint32_t* __restrict__ pay_out)
 {
     constexpr int BINS = RADIX_LO_BINS;
     __shared__ uint32_t cnt[LOCAL_WAVES][BINS];   // per wave: counts of my chunk, then keys of the digit in earlier waves
@@ -471,13 +472,14 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint32_t* __
 
     // my keys (registers), counted per wave
     const uint32_t wbegin = cbeg + wave * (LOCAL_STEPS * WAVE), wend = min(wbegin + LOCAL_STEPS * WAVE, cend);
-    uint32_t key[LOCAL_STEPS], src[LOCAL_STEPS];
+    uint32_t key[LOCAL_STEPS], src[LOCAL_STEPS], pay[LOCAL_STEPS];   // (pay: the packed bin rectangles travel along, k_scatter PAY)
 #pragma unroll
     for (int k = 0; k < LOCAL_STEPS; k++) {
         const uint32_t i = wbegin + k * WAVE + lane;
         const bool in = i < wend;
         key[k] = in ? (keys[s0 + i] & (BINS - 1)) : 0xffffffffu;
         src[k] = in ? idx[s0 + i] : 0u;
+        pay[k] = (in && pay_out) ? pay_in[s0 + i] : 0u;
     }
 #pragma unroll
     for (int k = 0; k < LOCAL_STEPS; k++)
@@ -542,6 +544,7 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint32_t* __
         if (valid) {
             GSR_BOUND(sort, 2, tot[digit] + earlier + rank, sz);
             depth_index[s0 + tot[digit] + earlier + rank] = src[k];
+            if (pay_out) pay_out[s0 + tot[digit] + earlier + rank] = pay[k];
         }
     }
 }
@@ -566,6 +569,8 @@ void launch_sort(const SortBuffers& b, uint32_t n, hipStream_t s)
                                       (int)scatter_lds_bytes<RADIX_HI_BITS>(SCAT_THREADS * SCAT_MAX_STEPS));
             (void)hipFuncSetAttribute((const void*)k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)scatter_lds_bytes<RADIX_HI_BITS>(SCAT_THREADS * SCAT_MAX_STEPS));
+            (void)hipFuncSetAttribute((const void*)k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)scatter_lds_bytes<RADIX_HI_BITS>(SCAT_THREADS * SCAT_MAX_STEPS));
             (void)hipFuncSetAttribute((const void*)k_scatter<RADIX_LO_BITS, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)scatter_lds_bytes<RADIX_LO_BITS>(SCAT_THREADS * SCAT_MAX_STEPS));
             (void)hipFuncSetAttribute((const void*)k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -578,11 +583,16 @@ void launch_sort(const SortBuffers& b, uint32_t n, hipStream_t s)
         hipLaunchKernelGGL(k_quantise_hist, grid, block, 0, s, b.depth, b.slots, b.minmax, n, b.keys_per_block,
                            b.rect, b.cull, b.keys, b.block_hist, RADIX_LO_BITS, RADIX_HI_BINS);
         launch_column_scan(b.block_hist, total_hi, RADIX_HI_BINS, b.nblocks, s);
-        hipLaunchKernelGGL((k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, true>), grid, dim3(SCAT_THREADS), lds_hi, s, (const uint32_t*)b.keys,
-                           (const uint32_t*)nullptr, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
-                           (const uint32_t*)total_hi, b.keys_tmp, b.idx_tmp, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+        if (b.rects_out)
+            hipLaunchKernelGGL((k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, true, true>), grid, dim3(SCAT_THREADS), lds_hi, s, (const uint32_t*)b.keys,
+                               (const uint32_t*)nullptr, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
+                               (const uint32_t*)total_hi, b.keys_tmp, b.idx_tmp, (uint32_t*)nullptr, b.rect, b.rect_tmp);
+        else
+            hipLaunchKernelGGL((k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, true>), grid, dim3(SCAT_THREADS), lds_hi, s, (const uint32_t*)b.keys,
+                               (const uint32_t*)nullptr, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
+                               (const uint32_t*)total_hi, b.keys_tmp, b.idx_tmp, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
         hipLaunchKernelGGL(k_local_sort, dim3(local_sort_grid(n)), dim3(LOCAL_THREADS), 0, s, (const uint32_t*)b.keys_tmp,
-                           (const uint32_t*)b.idx_tmp, (const uint32_t*)total_hi, b.depth_index, b.max_bucket);
+                           (const uint32_t*)b.idx_tmp, (const uint32_t*)total_hi, b.depth_index, b.max_bucket, (const uint32_t*)b.rect_tmp, b.rects_out);
         return;
     }
     hipLaunchKernelGGL(k_quantise_hist, grid, block, 0, s, b.depth, b.slots, b.minmax, n, b.keys_per_block,

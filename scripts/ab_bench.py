@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=1)
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--res-div", type=int, default=1, help="render at 1/N of the configuration's resolution and focal length (same splats, coarser bin grid)")
+    ap.add_argument("--n", type=int, default=0, help="splats (default: the configuration's), same generator parameters")
     ap.add_argument("--sort-only", action="store_true", help="time gsr_sort (key + min/max + radix) instead of full frames")
     args = ap.parse_args()
     import gsplat_hip as gh
@@ -37,7 +38,10 @@ def main():
     cfg["width"] //= args.res_div; cfg["height"] //= args.res_div; cfg["fx"] /= args.res_div
     W, H = cfg["width"], cfg["height"]
     scene = gh.Scene()
-    scene.setData(gh.synth.config_rows(args.config))
+    if args.n:
+        scene.setData(gh.synth.synth_rows(args.n, cfg["seed"], cfg["sigma"], cfg["s_lo"], cfg["s_hi"]))
+    else:
+        scene.setData(gh.synth.config_rows(args.config))
     poses = [gh.orbit_camera(k, 120, W, H, cfg["fx"]).f32() for k in range(120)]
     F = max(1, args.inflight)
 

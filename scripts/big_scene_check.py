@@ -9,13 +9,13 @@ import gsplat_hip as gh
 from oracle import oracle as O
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
-W, H = 1920, 1080
+W, H = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080)
 t0 = time.time()
 rows = gh.synth.synth_rows(n, 77, sigma=1.5, s_lo=0.002, s_hi=0.02)
 r = gh.HIPRenderer(W, H, timing=True)
 r.set_scene_rows(rows)              # device-side Scene.setData
 del rows
-cam = gh.orbit_camera(33, width=W, height=H, fx=1132.0)
+cam = gh.orbit_camera(33, width=W, height=H, fx=1132.0 * W / 1920.0)
 r.set_camera(cam)
 r.render_async(); r.sync()
 st = r.stats()
@@ -29,4 +29,17 @@ assert np.array_equal(di, odi), "permutation differs from the oracle"
 img = r.readPixelsFloat()
 assert np.isfinite(img).all() and img[..., 3].max() <= 1.0 + 1e-6 and img[..., 3].min() >= 0.0
 assert 0 < st["visible"] <= n and st["bin_entries"] >= st["visible"]
-print("ok: depthIndex bit-exact at n=%d, image finite, %.0f s total" % (n, time.time() - t0))
+# the same frame with the rectangles gathered by the binning and (large bin grids) the one-level pass: same lists, same image
+starts, lst = r.bin_lists()
+os.environ["GSR_RECT_CARRY"] = "0"; os.environ["GSR_BIN_TWO_LEVEL"] = "0"
+r2 = gh.HIPRenderer(W, H, timing=True)
+del os.environ["GSR_RECT_CARRY"], os.environ["GSR_BIN_TWO_LEVEL"]
+r2.set_raw_scene(data, pos)
+r2.set_camera(cam)
+r2.render_async(); r2.sync()
+st2 = r2.stats()
+print("one-level, gathered: project %.3f sort %.3f bin %.3f blend %.3f" % (st2["ms_project_key"], st2["ms_sort"], st2["ms_bin"], st2["ms_blend"]))
+s2, l2 = r2.bin_lists()
+assert np.array_equal(starts, s2) and np.array_equal(lst, l2), "bin lists differ"
+assert np.array_equal(img, r2.readPixelsFloat())
+print("ok: depthIndex bit-exact at n=%d, %dx%d, lists and image equal to the one-level / gathered path, %.0f s total" % (n, W, H, time.time() - t0))

@@ -1052,7 +1052,8 @@ def test_two_level_binning_builds_the_one_level_lists(gh, monkeypatch, case):
     every bin's start and every entry, i.e. the depth order inside every bin (what the front-to-back blend of
     WebGLRenderer.ts:139-142,282-285 needs) -- and with them the same image bit for bit.  Forced on at small sizes
     (partial cells at the right and bottom edges: 640x480 = 20 x 15 bins, 1000x712 = 32 x 23), natural at 4K, in a band
-    context (columns relative to the band), with the rectangles gathered and carried."""
+    context (columns relative to the band), with the rectangles gathered and carried (640x480: carried through the bucket
+    order's two kernels as well, GSR_RECT_CARRY=2)."""
     W, H = {"640x480": (640, 480), "1000x712 lsd": (1000, 712)}.get(case, (3840, 2160))
     n = 60000 if W < 3840 else 400000
     scene = gh.Scene()
@@ -1061,7 +1062,7 @@ def test_two_level_binning_builds_the_one_level_lists(gh, monkeypatch, case):
     band = (1184, 2848) if case == "4k band" else None
     lsd = {"GSR_SORT_ORDER": "lsd"} if "lsd" in case else {}
     want = _lists_of(gh, (W, H), scene, cams, dict(lsd, GSR_BIN_TWO_LEVEL="0", GSR_RECT_CARRY="0"), monkeypatch, band)
-    got = _lists_of(gh, (W, H), scene, cams, dict(lsd, GSR_BIN_TWO_LEVEL="1", GSR_RECT_CARRY="0" if "gather" in case else "1"), monkeypatch, band)
+    got = _lists_of(gh, (W, H), scene, cams, dict(lsd, GSR_BIN_TWO_LEVEL="1", GSR_RECT_CARRY="0" if "gather" in case else "2" if case == "640x480" else "1"), monkeypatch, band)
     for (ws, wl, wd, wi, _), (gs, gl, gd, gi, _) in zip(want, got):
         assert np.array_equal(wd, gd)
         assert np.array_equal(ws, gs), "bin starts"
