@@ -341,6 +341,10 @@ int alloc_bins(gsr_ctx* c)
         }
         // the level-two kernels stride over the frame's chunks: two 16-wave workgroups per CU, twice over
         c->cell_grid = (uint32_t)std::max(c->cu_count, 1) * CELL_WG_PER_CU;
+        if (const char* e = getenv("GSR_CELL_GRID")) {   // tuning knob: workgroups of the level-two kernels
+            const long v = atol(e);
+            if (v >= 1) c->cell_grid = (uint32_t)std::min(v, 65535L);
+        }
     }
     const bool throughput = (c->opt.flags & GSR_FLAG_THROUGHPUT) != 0;
     c->seg_len = c->opt.early_out_eps > 0.0f ? SEG_LEN_WHOLE_BIN : SEG_LEN_MIN;
