@@ -295,7 +295,10 @@ int alloc_bins(gsr_ctx* c)
     // take several rounds per workgroup, keeping about BIN_BLOCKS_TARGET workgroups (C4: 4 rounds, 611 workgroups, 20 MB).
     // Two-level binning (k_bin.hip): grids above TWO_LEVEL_MIN_BINS bins whose cells of 4 x 4 bins number at most 4096.
     const uint32_t ncells = (uint32_t)(((g.bx_hi - g.bx_lo + 3) >> 2) * ((g.nby + 3) >> 2));
-    c->bin_two_level = ncells <= 4096u && (c->bin_two_level_env >= 0 ? c->bin_two_level_env == 1 : nbins > TWO_LEVEL_MIN_BINS);
+    // (its level-two stores address the list with 32-bit byte offsets: lists of 2^30 entries or more take the one-level pass)
+    const uint64_t cap_now = c->bin_capacity ? c->bin_capacity : std::max<uint64_t>(6ull * c->n + (1u << 20), 1u << 22);
+    c->bin_two_level = ncells <= 4096u && cap_now < (1ull << 30) &&
+                       (c->bin_two_level_env >= 0 ? c->bin_two_level_env == 1 : nbins > TWO_LEVEL_MIN_BINS);
     c->bin_rounds = 1;
     if (!c->bin_two_level && c->bin_big && nbins > 4096)
         c->bin_rounds = std::min<uint32_t>(BIN_ROUNDS_MAX, std::max<uint32_t>(1u, ((c->n + 2047u) / 2048u + BIN_BLOCKS_TARGET - 1u) / BIN_BLOCKS_TARGET));

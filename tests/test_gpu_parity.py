@@ -1044,7 +1044,7 @@ def _lists_of(gh, size, scene, cams, env, monkeypatch, band=None):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["640x480", "1000x712 lsd", "4k", "4k band", "4k lsd gather"])
+@pytest.mark.parametrize("case", ["640x480", "1000x712 lsd", "4k", "4k band", "4k band lsd", "4k lsd gather"])
 def test_two_level_binning_builds_the_one_level_lists(gh, monkeypatch, case):
     """Large bin grids are binned in two levels (k_bin.hip: cells of 4 x 4 bins with the lane-set pass, then every cell
     list's chunks into the cell's 16 bins with ballots), and in the LSD sort order the packed rectangles travel with the
@@ -1059,7 +1059,7 @@ def test_two_level_binning_builds_the_one_level_lists(gh, monkeypatch, case):
     scene = gh.Scene()
     scene.setData(gh.synth.synth_rows(n, 77, sigma=1.2, s_lo=0.004, s_hi=0.09))
     cams = [gh.orbit_camera(k, 120, W, H, 1132.0 * W / 1920.0) for k in (4, 41, 97)]
-    band = (1184, 2848) if case == "4k band" else None
+    band = (1184, 2848) if "band" in case else None   # (a band context sorts its survivors only: the first pass drops the rest)
     lsd = {"GSR_SORT_ORDER": "lsd"} if "lsd" in case else {}
     want = _lists_of(gh, (W, H), scene, cams, dict(lsd, GSR_BIN_TWO_LEVEL="0", GSR_RECT_CARRY="0"), monkeypatch, band)
     got = _lists_of(gh, (W, H), scene, cams, dict(lsd, GSR_BIN_TWO_LEVEL="1", GSR_RECT_CARRY="0" if "gather" in case else "2" if case == "640x480" else "1"), monkeypatch, band)
