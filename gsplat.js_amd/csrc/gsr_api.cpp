@@ -106,6 +106,7 @@ struct gsr_ctx {
     int spec = 0;                     // GSR_SPEC=1: dense frames as speculative segments (k_bin_finalize) instead of whole-bin work items
     uint32_t* bin_rects = nullptr;
     uint32_t* rect_tmp = nullptr;     // the rectangles between the two LSD passes (rect_carry)
+    uint32_t* sort_chunk_tab = nullptr; // bucket order: k_local_sort's work list
     bool rect_carry = true;           // LSD sort order (large scenes): the packed rectangles travel with the keys (GSR_RECT_CARRY=0: the binning gathers them)
     bool rect_carry_bucket = false;   // ... also in the bucket order (GSR_RECT_CARRY=2; measured: what k_bin_count saves, the two sort kernels
                                       // pay -- C3 sort 35.0 -> 41.8 us, binning 47.6 -> 41.3 us -- so not by default)
@@ -423,7 +424,7 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
         SortBuffers sb{c->depth, c->slots, c->fstate->minmax, c->keys, c->keys_tmp, c->idx_tmp, c->depth_index,
                        c->block_hist, c->fstate->digit_total, c->rect_idx, cull ? 1 : 0, &c->fstate->sorted_count, c->sort_kpb, c->sort_blocks,
                        c->bucket_order_now ? 1 : 0, reinterpret_cast<uint32_t*>(c->mailbox_dev + 1),
-                       c->rect_tmp, (render && c->rect_carry && (c->rect_carry_bucket || !c->bucket_order_now)) ? c->bin_rects : nullptr};
+                       c->sort_chunk_tab, c->rect_tmp, (render && c->rect_carry && (c->rect_carry_bucket || !c->bucket_order_now)) ? c->bin_rects : nullptr};
         c->sort_culled = cull;
         c->rects_sorted_now = sb.rects_out != nullptr;
         launch_sort(sb, c->n, s);
@@ -478,7 +479,7 @@ static std::vector<uint64_t> chain_signature(const gsr_ctx* c)
     U(c->bin_capacity); U(c->max_items); U(c->seg_len); U(c->seg_target_items); U(c->blend_grid); U(c->bin_blocks); U(c->bin_rounds); U(c->bin_big); P(c->bin_start_pre);
     U((uint64_t)c->opt.flags); U((uint64_t)(c->opt.early_out_eps * 1e9f)); U(c->bucket_order_now ? 1u : 0u); U(c->saturate ? 1u : 0u); U((uint64_t)c->items_by_size); U(c->quad_from); U((uint64_t)(int64_t)c->long_items);
     U((uint64_t)c->spec); U(c->blend_sub);
-    U(c->bin_two_level ? 1u : 0u); P(c->cell_list); P(c->cell_total); P(c->cell_start); P(c->chunk_start); P(c->chunk_info); P(c->cell_wcnt); P(c->cell_table2); U(c->cell_grid); P(c->rect_tmp); U(c->rect_carry ? (c->rect_carry_bucket ? 1u : 2u) : 0u);
+    U(c->bin_two_level ? 1u : 0u); P(c->cell_list); P(c->cell_total); P(c->cell_start); P(c->chunk_start); P(c->chunk_info); P(c->cell_wcnt); P(c->cell_table2); U(c->cell_grid); P(c->rect_tmp); P(c->sort_chunk_tab); U(c->rect_carry ? (c->rect_carry_bucket ? 1u : 2u) : 0u);
     return v;
 }
 
@@ -733,7 +734,7 @@ int gsr_destroy(gsr_ctx* c)
     dev_free(&c->block_hist); dev_free(&c->rec); dev_free(&c->bbox); dev_free(&c->slots); dev_free(&c->rect_idx);
     dev_free(&c->bin_table); dev_free(&c->bin_total); dev_free(&c->bin_start); dev_free(&c->bin_start_pre); dev_free(&c->bin_list);
     dev_free(&c->cell_list); dev_free(&c->cell_total); dev_free(&c->cell_start); dev_free(&c->chunk_start); dev_free(&c->chunk_info); dev_free(&c->cell_wcnt); dev_free(&c->cell_table2);
-    dev_free(&c->seg_start); dev_free(&c->bin_mask); dev_free(&c->bin_sat); dev_free(&c->items); dev_free(&c->partial); dev_free(&c->bin_rects); dev_free(&c->rect_tmp);
+    dev_free(&c->seg_start); dev_free(&c->bin_mask); dev_free(&c->bin_sat); dev_free(&c->items); dev_free(&c->partial); dev_free(&c->bin_rects); dev_free(&c->rect_tmp); dev_free(&c->sort_chunk_tab);
     drop_graph(c);
     dev_free(&c->cam_dev);
     dev_free(&c->fstate); dev_free(&c->accum); dev_free(&c->fb); dev_free(&c->fb8);
@@ -765,7 +766,8 @@ int alloc_scene(gsr_ctx* c, uint32_t n, bool with_rows)
         (r = dev_alloc(c, &c->rgba, n)) || (r = dev_alloc(c, &c->depth, n)) || (r = dev_alloc(c, &c->keys, n)) ||
         (r = dev_alloc(c, &c->keys_tmp, n)) || (r = dev_alloc(c, &c->idx_tmp, n)) ||
         (r = dev_alloc(c, &c->depth_index, n)) || (r = dev_alloc(c, &c->rec, n)) || (r = dev_alloc(c, &c->bbox, n)) ||
-        (r = dev_alloc(c, &c->bin_rects, n)) || (r = dev_alloc(c, &c->rect_idx, n)) || (r = dev_alloc(c, &c->rect_tmp, n)))
+        (r = dev_alloc(c, &c->bin_rects, n)) || (r = dev_alloc(c, &c->rect_idx, n)) || (r = dev_alloc(c, &c->rect_tmp, n)) ||
+        (r = dev_alloc(c, &c->sort_chunk_tab, 4 * ((size_t)n / 4096 + 260))))
         return r;
     if (with_rows && ((r = dev_alloc(c, &c->rotv, n)) || (r = dev_alloc(c, &c->sclv, n)))) return r;
     // keys per radix workgroup: the scatter stores runs of keys_per_block / 2^bits keys, so larger scenes take larger

@@ -156,6 +156,7 @@ struct SortBuffers {
     uint32_t nblocks;
     int bucket_order;          // 1: high digit first + one workgroup per bucket (4 launches); 0: LSD (6 launches); see k_sort.hip
     uint32_t* max_bucket;      // out: keys in the frame's largest high-digit bucket (host-mapped word)
+    uint32_t* chunk_tab;       // bucket order: 4 x (1 + n / 4096 + 258) words: k_local_sort's work list (k_scatter's first workgroup writes it)
     uint32_t* rect_tmp;        // LSD order with rects_out: the rectangles after the first pass
     uint32_t* rects_out;       // LSD order: out: the packed bin rectangles in depth order (null: not carried; the binning gathers them)
 };

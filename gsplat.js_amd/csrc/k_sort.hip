@@ -236,6 +236,11 @@ void launch_column_scan(uint32_t* table, uint32_t* total, int ncols, uint32_t nr
 constexpr int SCAT_THREADS = 1024;
 constexpr int SCAT_WAVES = SCAT_THREADS / WAVE;
 constexpr int SCAT_MAX_STEPS = 8;  // keys_per_block <= SCAT_THREADS * SCAT_MAX_STEPS = 8192
+// (the bucket order's second kernel, k_local_sort below: one workgroup per LOCAL_CHUNK keys of a bucket)
+constexpr int LOCAL_THREADS = 1024;
+constexpr int LOCAL_WAVES = LOCAL_THREADS / WAVE;
+constexpr int LOCAL_STEPS = 4;                                    // 64-key steps per wave
+constexpr uint32_t LOCAL_CHUNK = LOCAL_THREADS * LOCAL_STEPS;     // 4096 keys per workgroup
 
 template <int BITS>
 constexpr size_t scatter_lds_bytes(uint32_t keys_per_block)
@@ -254,7 +259,8 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter(const uint32_t* __rest
                                                           const uint32_t* __restrict__ total,
                                                           uint32_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out,
                                                           uint32_t* __restrict__ max_bucket,
-                                                          const uint32_t* __restrict__ pay_in = nullptr, uint32_t* __restrict__ pay_out = nullptr)
+                                                          const uint32_t* __restrict__ pay_in = nullptr, uint32_t* __restrict__ pay_out = nullptr,
+                                                          uint4* __restrict__ chunk_tab = nullptr)
 {
     constexpr int BINS = 1 << BITS;
     static_assert(BINS <= SCAT_THREADS, "one digit per thread");
@@ -343,6 +349,29 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter(const uint32_t* __rest
         lstart[d] = run_h;
         gdelta[d] = run_t + wg_base - run_h;   // may wrap: only gdelta[d] + p is used
     }
+    if (chunk_tab && blockIdx.x == 0) {   // (uniform) bucket order: the work list of k_local_sort -- per LOCAL_CHUNK keys of a bucket
+        // (bucket, chunk inside it, the bucket's first key, its size); entry [0] holds the number of chunks.  Every workgroup of
+        // that kernel used to find its chunk itself: a load of the 512 totals, two scans and two barriers in front of its work.
+        __shared__ uint32_t s_cw[BINS / WAVE];
+        const uint32_t nch = threadIdx.x < BINS ? (tot + LOCAL_CHUNK - 1) / LOCAL_CHUNK : 0u;
+        uint32_t inc = nch;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const uint32_t u = __shfl_up(inc, off);
+            if (lane >= off) inc += u;
+        }
+        if (threadIdx.x < BINS && lane == WAVE - 1) s_cw[wave] = inc;
+        __syncthreads();
+        if (threadIdx.x < BINS) {
+            uint32_t first = inc - nch, run_t = incl_t - tot, all = 0;
+            for (int w = 0; w < BINS / WAVE; w++) {
+                if (w < wave) { first += s_cw[w]; run_t += wsum[w]; }
+                all += s_cw[w];
+            }
+            for (uint32_t ch = 0; ch < nch; ch++) chunk_tab[1 + first + ch] = make_uint4((uint32_t)threadIdx.x, ch, run_t, tot);
+            if (threadIdx.x == 0) chunk_tab[0] = make_uint4(all, 0u, 0u, 0u);
+        }
+    }
     __syncthreads();
     KSTAMP(4);
     // phase 3: local position = digit start + keys of the digit in earlier waves + rank among this wave's earlier keys
@@ -411,17 +440,13 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter(const uint32_t* __rest
 // the scene (depth outliers stretch the key range) is slow this way: every frame reports its largest bucket to the
 // host, which falls back to the LSD order while that exceeds LOCAL_BUCKET_LIMIT (gsr_api.cpp).
 // ---------------------------------------------------------------------------
-constexpr int LOCAL_THREADS = 1024;
-constexpr int LOCAL_WAVES = LOCAL_THREADS / WAVE;
-constexpr int LOCAL_STEPS = 4;                                    // 64-key steps per wave
-constexpr uint32_t LOCAL_CHUNK = LOCAL_THREADS * LOCAL_STEPS;     // 4096 keys per workgroup
 inline uint32_t local_sort_grid(uint32_t n) { return (n + LOCAL_CHUNK - 1) / LOCAL_CHUNK + RADIX_HI_BINS / 2 + 1; }   // >= sum over buckets of ceil(size / chunk)
 // (a 2-D grid -- chunk x bucket, bucket starts handed over by the partition pass, no search -- was measured slower:
 //  3084 mostly empty 1024-thread workgroups cost more to dispatch than the search saves: 13.7 -> 21.0 us on C3)
 
 __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ idx,
-                                                              const uint32_t* __restrict__ total_hi,
-                                                              uint32_t* __restrict__ depth_index, uint32_t* __restrict__ max_bucket,
+                                                              const uint4* __restrict__ chunk_tab,
+                                                              uint32_t* __restrict__ depth_index,
                                                               const uint32_t* __restrict__ pay_in, uint32_t* __restrict__ pay_out)
 {
     constexpr int BINS = RADIX_LO_BINS;
@@ -429,45 +454,14 @@ __global__ __launch_bounds__(LOCAL_THREADS) void k_local_sort(const uint32_t* __
     __shared__ uint32_t tot[BINS];                // digit counts of the bucket behind my chunk, then the digit's first position
     __shared__ uint32_t bef[BINS];                // digit counts of the chunks in front of mine
     __shared__ uint32_t wsum[BINS / WAVE];
-    __shared__ uint32_t s_scan[2][LOCAL_WAVES];
-    __shared__ uint32_t s_max[LOCAL_WAVES];
-    __shared__ uint32_t s_pick[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // which (bucket, chunk) am I?  Buckets in order, ceil(size / LOCAL_CHUNK) workgroups each: an inclusive scan of the
-    // chunk counts over the 512 bucket slots (one per thread on the first 512 threads), then the slot that contains my id
-    const uint32_t t = threadIdx.x < RADIX_HI_BINS ? total_hi[threadIdx.x] : 0u;
-    const uint32_t nch = (t + LOCAL_CHUNK - 1) / LOCAL_CHUNK;
-    uint32_t inc_c = nch, inc_k = t, mx = t;
-#pragma unroll
-    for (int off = 1; off < WAVE; off <<= 1) {
-        const uint32_t a = __shfl_up(inc_c, off), b2 = __shfl_up(inc_k, off);
-        if (lane >= off) { inc_c += a; inc_k += b2; }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
-    if (lane == WAVE - 1) { s_scan[0][wave] = inc_c; s_scan[1][wave] = inc_k; }
-    if (lane == 0) s_max[wave] = mx;
+    // which (bucket, chunk) am I?  The partition pass's first workgroup has listed them (k_scatter, chunk_tab)
+    if (blockIdx.x >= chunk_tab[0].x) return;                 // more workgroups than chunks
+    const uint4 me = chunk_tab[1 + blockIdx.x];
     for (int d = threadIdx.x; d < LOCAL_WAVES * BINS; d += LOCAL_THREADS) (&cnt[0][0])[d] = 0;
     if (threadIdx.x < BINS) { tot[threadIdx.x] = 0; bef[threadIdx.x] = 0; }
-    if (threadIdx.x == 0) s_pick[0] = 0xffffffffu;
     __syncthreads();
-    uint32_t base_c = 0, base_k = 0;
-    for (int w = 0; w < wave; w++) { base_c += s_scan[0][w]; base_k += s_scan[1][w]; }
-    inc_c += base_c; inc_k += base_k;                      // inclusive over all earlier buckets
-    if (threadIdx.x < RADIX_HI_BINS && nch && blockIdx.x >= inc_c - nch && blockIdx.x < inc_c) {
-        s_pick[0] = threadIdx.x;                           // my bucket
-        s_pick[1] = blockIdx.x - (inc_c - nch);            // my chunk inside it
-        s_pick[2] = inc_k - t;                             // first key of the bucket
-        s_pick[3] = t;                                     // its size
-    }
-    __syncthreads();
-    if (blockIdx.x == 0 && max_bucket && threadIdx.x == 0) {   // the frame's largest bucket, for the host's choice of sort order
-        uint32_t m2 = 0;
-        for (int w = 0; w < RADIX_HI_BINS / WAVE; w++) m2 = max(m2, s_max[w]);
-        *max_bucket = m2;                                  // plain store: the word is host-mapped
-    }
-    if (s_pick[0] == 0xffffffffu) return;                  // more workgroups than chunks
-    const uint32_t chunk = s_pick[1], s0 = s_pick[2], sz = s_pick[3];
+    const uint32_t chunk = me.y, s0 = me.z, sz = me.w;
     const uint32_t cbeg = chunk * LOCAL_CHUNK, cend = min(cbeg + LOCAL_CHUNK, sz);
 
     // my keys (registers), counted per wave
@@ -583,16 +577,17 @@ void launch_sort(const SortBuffers& b, uint32_t n, hipStream_t s)
         hipLaunchKernelGGL(k_quantise_hist, grid, block, 0, s, b.depth, b.slots, b.minmax, n, b.keys_per_block,
                            b.rect, b.cull, b.keys, b.block_hist, RADIX_LO_BITS, RADIX_HI_BINS);
         launch_column_scan(b.block_hist, total_hi, RADIX_HI_BINS, b.nblocks, s);
+        uint4* tab = reinterpret_cast<uint4*>(b.chunk_tab);   // k_local_sort's work list, written by the partition pass's first workgroup
         if (b.rects_out)
             hipLaunchKernelGGL((k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, true, true>), grid, dim3(SCAT_THREADS), lds_hi, s, (const uint32_t*)b.keys,
                                (const uint32_t*)nullptr, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
-                               (const uint32_t*)total_hi, b.keys_tmp, b.idx_tmp, (uint32_t*)nullptr, b.rect, b.rect_tmp);
+                               (const uint32_t*)total_hi, b.keys_tmp, b.idx_tmp, b.max_bucket, b.rect, b.rect_tmp, tab);
         else
             hipLaunchKernelGGL((k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, true>), grid, dim3(SCAT_THREADS), lds_hi, s, (const uint32_t*)b.keys,
                                (const uint32_t*)nullptr, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
-                               (const uint32_t*)total_hi, b.keys_tmp, b.idx_tmp, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+                               (const uint32_t*)total_hi, b.keys_tmp, b.idx_tmp, b.max_bucket, (const uint32_t*)nullptr, (uint32_t*)nullptr, tab);
         hipLaunchKernelGGL(k_local_sort, dim3(local_sort_grid(n)), dim3(LOCAL_THREADS), 0, s, (const uint32_t*)b.keys_tmp,
-                           (const uint32_t*)b.idx_tmp, (const uint32_t*)total_hi, b.depth_index, b.max_bucket, (const uint32_t*)b.rect_tmp, b.rects_out);
+                           (const uint32_t*)b.idx_tmp, (const uint4*)tab, b.depth_index, (const uint32_t*)b.rect_tmp, b.rects_out);
         return;
     }
     hipLaunchKernelGGL(k_quantise_hist, grid, block, 0, s, b.depth, b.slots, b.minmax, n, b.keys_per_block,
