@@ -335,10 +335,62 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_project_key(SceneSoA sc, uint3
     }
 }
 
+// The depth key alone (A1, wasm/wasm.cpp:14-31): what gsr_sort -- the reference worker's whole job -- needs of the pass above.
+// KEY_PER_THREAD splats per thread, so that a 1 M-splat scene is 977 workgroups instead of 3907 one-splat-per-thread ones
+// whose dispatch, not their 16 bytes per splat, set the pass's time (12.1 us at 1 M).
+constexpr int KEY_PER_THREAD = 4;
+__global__ __launch_bounds__(PROJ_THREADS) void k_depth_key(SceneSoA sc, uint32_t n, const CamParams* __restrict__ camp,
+                                                            int32_t* __restrict__ depth, int32_t* __restrict__ slots)
+{
+    const CamParams& cam = *camp;
+    __shared__ int32_t s_min[PROJ_THREADS / WAVE], s_max[PROJ_THREADS / WAVE];
+    int32_t dmin = 0x7fffffff, dmax = (int32_t)0x80000000;
+    float x[KEY_PER_THREAD], y[KEY_PER_THREAD], z[KEY_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < KEY_PER_THREAD; k++) {
+        const uint32_t i = (blockIdx.x * KEY_PER_THREAD + k) * PROJ_THREADS + threadIdx.x;
+        const bool in = i < n;
+        x[k] = in ? sc.px[i] : 0.0f; y[k] = in ? sc.py[i] : 0.0f; z[k] = in ? sc.pz[i] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < KEY_PER_THREAD; k++) {
+        const uint32_t i = (blockIdx.x * KEY_PER_THREAD + k) * PROJ_THREADS + threadIdx.x;
+        if (i < n) {
+            // three separate f32 multiplies, left-to-right adds, *4096 in f32, truncate (as in k_project_key)
+            const float f0 = cam.vp2 * x[k];
+            const float f1 = cam.vp6 * y[k];
+            const float f2 = cam.vp10 * z[k];
+            const int32_t d = (int32_t)(((f0 + f1) + f2) * 4096.0f);
+            depth[i] = d;
+            dmin = min(dmin, d); dmax = max(dmax, d);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        dmin = min(dmin, __shfl_xor(dmin, off));
+        dmax = max(dmax, __shfl_xor(dmax, off));
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_min[wave] = dmin; s_max[wave] = dmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t* slot = slots + (size_t)(blockIdx.x & (FRAME_SLOTS - 1)) * FRAME_SLOT_WORDS;
+        int32_t mn = s_min[0], mx = s_max[0];
+        for (int w = 1; w < PROJ_THREADS / WAVE; w++) { mn = min(mn, s_min[w]); mx = max(mx, s_max[w]); }
+        atomicMin(&slot[0], mn);
+        atomicMax(&slot[1], mx);
+    }
+}
+
 void launch_project_key(const SceneSoA& sc, uint32_t n, const CamParams* cam, int do_project, int32_t* depth,
                         int32_t* slots, Record* rec, uint2* bbox, uint32_t* rect, hipStream_t s)
 {
     if (!n) return;
+    if (!do_project) {
+        const uint32_t per = PROJ_THREADS * KEY_PER_THREAD;
+        hipLaunchKernelGGL(k_depth_key, dim3((n + per - 1) / per), dim3(PROJ_THREADS), 0, s, sc, n, cam, depth, slots);
+        return;
+    }
     hipLaunchKernelGGL(k_project_key, dim3((n + PROJ_THREADS - 1) / PROJ_THREADS), dim3(PROJ_THREADS), 0, s, sc, n, cam, do_project, depth,
                        slots, rec, bbox, rect);
 }
