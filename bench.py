@@ -478,7 +478,9 @@ def main():
         solo["sort_only"] = {"ms_key_minmax": t_key, "ms_quantise_radix": t_sort,
                              "sorted_splats_per_sec": N / ((t_key + t_sort) * 1e-3),
                              "GBps": 52.0 * N / ((t_key + t_sort) * 1e-3) / 1e9,
-                             "frac_of_hbm_peak": 52.0 * N / ((t_key + t_sort) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                             "frac_of_hbm_peak": 52.0 * N / ((t_key + t_sort) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "note": "HIP events around the whole device chain of gsr_sort: k_depth_key (camera by value, no k_begin_frame "
+                                     "in front), k_quantise_hist, column scan, the radix kernels"}
         sr.dispose()
 
     if rank == 0:

@@ -107,6 +107,8 @@ struct gsr_ctx {
     uint32_t* bin_rects = nullptr;
     uint32_t* rect_tmp = nullptr;     // the rectangles between the two LSD passes (rect_carry)
     uint32_t* sort_chunk_tab = nullptr; // bucket order: k_local_sort's work list
+    int sort_parity = 0;              // which of the two sort-only slot sets the next sort-only frame uses
+    bool sort_slots_ready = false;
     bool rect_carry = true;           // LSD sort order (large scenes): the packed rectangles travel with the keys (GSR_RECT_CARRY=0: the binning gathers them)
     bool rect_carry_bucket = false;   // ... also in the bucket order (GSR_RECT_CARRY=2; measured: what k_bin_count saves, the two sort kernels
                                       // pay -- C3 sort 35.0 -> 41.8 us, binning 47.6 -> 41.3 us -- so not by default)
@@ -411,17 +413,23 @@ inline bool overflow_pending(const gsr_ctx* c);
 static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
 {
     hipStream_t s = c->stream;
+    int32_t* slots_now = c->slots;
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BEGIN], s));
     if (c->n) {
         SceneSoA sc{c->px, c->py, c->pz, c->cov0, c->cov1, c->cov2, c->rgba, c->sh_r, c->sh_g, c->sh_b, c->shcol};
-        launch_project_key(sc, c->n, c->cam_dev, render ? 1 : 0, c->depth, c->slots, c->rec, c->bbox, c->rect_idx, s);
+        if (render) launch_project_key(sc, c->n, c->cam_dev, 1, c->depth, c->slots, c->rec, c->bbox, c->rect_idx, s);
+        else {   // a sort-only frame: its own slots (sets 1 and 2 in turn; set 0 belongs to the render frames and k_begin_frame)
+            slots_now = c->slots + (size_t)(1 + c->sort_parity) * FRAME_SLOTS * FRAME_SLOT_WORDS;
+            launch_depth_key(sc, c->n, c->cam, c->depth, slots_now, c->slots + (size_t)(2 - c->sort_parity) * FRAME_SLOTS * FRAME_SLOT_WORDS, s);
+            c->sort_parity ^= 1;
+        }
     }
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_PROJECT], s));
     if (c->n) {
         // band mode (a context that composites only part of the screen): sort and bin only the splats whose box
         // touches the band; the full depthIndex is produced on demand (gsr_read_depth_index)
         const bool cull = render && band_is_partial(c);
-        SortBuffers sb{c->depth, c->slots, c->fstate->minmax, c->keys, c->keys_tmp, c->idx_tmp, c->depth_index,
+        SortBuffers sb{c->depth, slots_now, c->fstate->minmax, c->keys, c->keys_tmp, c->idx_tmp, c->depth_index,
                        c->block_hist, c->fstate->digit_total, c->rect_idx, cull ? 1 : 0, &c->fstate->sorted_count, c->sort_kpb, c->sort_blocks,
                        c->bucket_order_now ? 1 : 0, reinterpret_cast<uint32_t*>(c->mailbox_dev + 1),
                        c->sort_chunk_tab, c->rect_tmp, (render && c->rect_carry && (c->rect_carry_bucket || !c->bucket_order_now)) ? c->bin_rects : nullptr};
@@ -518,7 +526,15 @@ int enqueue_frame(gsr_ctx* c, bool render)
     c->cam.sh_on = c->sh_count ? 1 : 0;
     c->cam.band[0] = c->band[0]; c->cam.band[1] = c->band[1]; c->cam.band[2] = c->band[2];
     static_assert(offsetof(FrameState, minmax) == 0 && sizeof(FrameState) % 4 == 0, "k_begin_frame resets the frame words");
-    launch_begin_frame(c->cam, c->cam_dev, reinterpret_cast<uint32_t*>(c->fstate), (uint32_t)(sizeof(FrameState) / 4), c->slots, s);
+    // (a sort-only frame needs none of this: k_depth_key takes the camera by value and owns its slots, and the frame words the
+    //  sort writes -- min / max, digit totals, the survivors' count -- are stored, not accumulated)
+    if (render) launch_begin_frame(c->cam, c->cam_dev, reinterpret_cast<uint32_t*>(c->fstate), (uint32_t)(sizeof(FrameState) / 4), c->slots, s);
+    else if (!c->sort_slots_ready) {   // the first sort-only frame of the context: both of their slot sets
+        for (int k = 1; k <= 2; k++)
+            launch_begin_frame(c->cam, c->cam_dev, reinterpret_cast<uint32_t*>(c->fstate), (uint32_t)(sizeof(FrameState) / 4),
+                               c->slots + (size_t)k * FRAME_SLOTS * FRAME_SLOT_WORDS, s);
+        c->sort_slots_ready = true;
+    }
 
     bool replayed = false;
     if (c->graphs_enabled && render && !timing) {
@@ -674,8 +690,8 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
     }
     CREATE_TRY(hipMalloc((void**)&c->fstate, sizeof(FrameState)));
     CREATE_TRY(hipMalloc((void**)&c->cam_dev, sizeof(CamParams)));
-    CREATE_TRY(hipMalloc((void**)&c->slots, sizeof(int32_t) * FRAME_SLOTS * FRAME_SLOT_WORDS));
-    CREATE_TRY(hipMemset(c->slots, 0, sizeof(int32_t) * FRAME_SLOTS * FRAME_SLOT_WORDS));
+    CREATE_TRY(hipMalloc((void**)&c->slots, sizeof(int32_t) * 3 * FRAME_SLOTS * FRAME_SLOT_WORDS));   // render frames' set, two sets of the sort-only frames
+    CREATE_TRY(hipMemset(c->slots, 0, sizeof(int32_t) * 3 * FRAME_SLOTS * FRAME_SLOT_WORDS));
     if (const char* e = getenv("GSR_NO_GRAPH")) c->graphs_enabled = atoi(e) == 0;
     if (const char* e = getenv("GSR_FUSE_COMBINE")) c->fuse_combine = atoi(e) != 0;   // A/B knob: 0 = separate k_combine launch
     if (const char* e = getenv("GSR_SATURATE")) c->saturate = atoi(e) != 0;           // A/B knob: 0 = no saturation skip

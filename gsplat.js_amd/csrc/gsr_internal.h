@@ -134,6 +134,8 @@ constexpr uint32_t PROJ_THREADS = 256;
 constexpr int FRAME_SLOTS = 64;
 constexpr int FRAME_SLOT_WORDS = 32;   // words per slot (one 128-byte line): [0] min depth, [1] max depth, [2] visible, [3] tiles,
                                        // [4] sum of opacity byte x tiles / 16 (the frame's optical depth, k_bin_finalize)
+// the depth key and the min / max alone (sort-only frames): camera by value, its own frame slots, the next frame's reset
+void launch_depth_key(const SceneSoA& sc, uint32_t n, const CamParams& cam, int32_t* depth, int32_t* slots, int32_t* slots_next, hipStream_t s);
 void launch_project_key(const SceneSoA& sc, uint32_t n, const CamParams* cam_dev, int do_project, int32_t* depth,
                         int32_t* slots /* FRAME_SLOTS * FRAME_SLOT_WORDS, reset by k_begin_frame */, Record* rec, uint2* bbox,
                         uint32_t* rect /* n: packed bin rectangle per splat */, hipStream_t s);

@@ -339,10 +339,18 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_project_key(SceneSoA sc, uint3
 // KEY_PER_THREAD splats per thread, so that a 1 M-splat scene is 977 workgroups instead of 3907 one-splat-per-thread ones
 // whose dispatch, not their 16 bytes per splat, set the pass's time (12.1 us at 1 M).
 constexpr int KEY_PER_THREAD = 4;
-__global__ __launch_bounds__(PROJ_THREADS) void k_depth_key(SceneSoA sc, uint32_t n, const CamParams* __restrict__ camp,
-                                                            int32_t* __restrict__ depth, int32_t* __restrict__ slots)
+// It takes the three matrix entries it needs by value and owns its frame slots: sort-only frames alternate between two sets,
+// and the first workgroup of one frame resets the set of the next (its last readers -- the frame before -- are done: one
+// stream), so that no k_begin_frame launch stands in front of the reference worker's job.
+__global__ __launch_bounds__(PROJ_THREADS) void k_depth_key(SceneSoA sc, uint32_t n, float vp2, float vp6, float vp10,
+                                                            int32_t* __restrict__ depth, int32_t* __restrict__ slots,
+                                                            int32_t* __restrict__ slots_next)
 {
-    const CamParams& cam = *camp;
+    struct { float vp2, vp6, vp10; } cam = {vp2, vp6, vp10};
+    if (blockIdx.x == 0 && threadIdx.x < FRAME_SLOTS) {
+        slots_next[(size_t)threadIdx.x * FRAME_SLOT_WORDS + 0] = 0x7fffffff;
+        slots_next[(size_t)threadIdx.x * FRAME_SLOT_WORDS + 1] = (int32_t)0x80000000;
+    }
     __shared__ int32_t s_min[PROJ_THREADS / WAVE], s_max[PROJ_THREADS / WAVE];
     int32_t dmin = 0x7fffffff, dmax = (int32_t)0x80000000;
     float x[KEY_PER_THREAD], y[KEY_PER_THREAD], z[KEY_PER_THREAD];
@@ -382,15 +390,17 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_depth_key(SceneSoA sc, uint32_
     }
 }
 
+void launch_depth_key(const SceneSoA& sc, uint32_t n, const CamParams& cam, int32_t* depth, int32_t* slots, int32_t* slots_next, hipStream_t s)
+{
+    if (!n) return;
+    const uint32_t per = PROJ_THREADS * KEY_PER_THREAD;
+    hipLaunchKernelGGL(k_depth_key, dim3((n + per - 1) / per), dim3(PROJ_THREADS), 0, s, sc, n, cam.vp2, cam.vp6, cam.vp10, depth, slots, slots_next);
+}
+
 void launch_project_key(const SceneSoA& sc, uint32_t n, const CamParams* cam, int do_project, int32_t* depth,
                         int32_t* slots, Record* rec, uint2* bbox, uint32_t* rect, hipStream_t s)
 {
     if (!n) return;
-    if (!do_project) {
-        const uint32_t per = PROJ_THREADS * KEY_PER_THREAD;
-        hipLaunchKernelGGL(k_depth_key, dim3((n + per - 1) / per), dim3(PROJ_THREADS), 0, s, sc, n, cam, depth, slots);
-        return;
-    }
     hipLaunchKernelGGL(k_project_key, dim3((n + PROJ_THREADS - 1) / PROJ_THREADS), dim3(PROJ_THREADS), 0, s, sc, n, cam, do_project, depth,
                        slots, rec, bbox, rect);
 }
