@@ -15,6 +15,12 @@ for it in range(120):
         if k == 3:
             r.setSize(512 + 32 * (it % 4), 384)
     r.lastDepthIndex()
+    if it % 6 == 0:    # a 4K framebuffer: the two-level binning's buffers come and go with the context too
+        r.setSize(3840, 2160)
+        r.render(scene, gh.orbit_camera(1, width=3840, height=2160, fx=2.0 * cfg["fx"]))
+    if it % 4 == 0:    # sort-only frames (their own frame slots)
+        r.sort(gh.orbit_camera(2, width=r.width, height=r.height, fx=cfg["fx"]))
+        r.sort(gh.orbit_camera(3, width=r.width, height=r.height, fx=cfg["fx"]))
     r.dispose()
     if it % 20 == 19:
         free.append(torch.cuda.mem_get_info()[0])

@@ -7,7 +7,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "gsplat.js_amd", "py")]
 import gsplat_hip as gh
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
-for name in ("C2", "C3", "C1"):
+for name in ("C2", "C3", "C1", "C4"):
     cfg = gh.synth.CONFIGS[name]; W, H = cfg["width"], cfg["height"]
     scene = gh.Scene(); scene.setData(gh.synth.config_rows(name))
     poses = [gh.orbit_camera(k, 120, W, H, cfg["fx"]).f32() for k in range(120)]
@@ -15,10 +15,12 @@ for name in ("C2", "C3", "C1"):
     for r in rs:
         r.render(scene, gh.orbit_camera(0, 120, W, H, cfg["fx"]))
     t0 = time.perf_counter()
-    for k in range(frames):
+    for k in range(frames if name != "C4" else frames // 6):
         r = rs[k % 4]
         r.set_camera_arrays(*poses[(k * 7) % 120], cfg["fx"], cfg["fx"])
         r.render_async()
+        if k % 97 == 96:
+            r.sort(gh.orbit_camera(k % 120, 120, W, H, cfg["fx"]))     # a sort-only frame between the rendered ones
         if k % 500 == 499:
             for x in rs: x.sync()
             print("%s: %d frames, %.1f s" % (name, k + 1, time.perf_counter() - t0), flush=True)
