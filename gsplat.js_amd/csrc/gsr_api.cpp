@@ -108,7 +108,7 @@ struct gsr_ctx {
     uint32_t* rect_tmp = nullptr;     // the rectangles between the two LSD passes (rect_carry)
     uint32_t* sort_chunk_tab = nullptr; // bucket order: k_local_sort's work list
     int sort_parity = 0;              // which of the two sort-only slot sets the next sort-only frame uses
-    bool sort_slots_ready = false;
+    bool slots_need_init = true;      // frame words and the three slot sets: initialised once, by the first frame's enqueue
     bool rect_carry = true;           // LSD sort order (large scenes): the packed rectangles travel with the keys (GSR_RECT_CARRY=0: the binning gathers them)
     bool rect_carry_bucket = false;   // ... also in the bucket order (GSR_RECT_CARRY=2; measured: what k_bin_count saves, the two sort kernels
                                       // pay -- C3 sort 35.0 -> 41.8 us, binning 47.6 -> 41.3 us -- so not by default)
@@ -157,6 +157,9 @@ struct gsr_ctx {
     bool graphs_enabled = true;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
+    bool graph_fresh = false;                 // the graph was captured for the frame being enqueued
+    hipGraphNode_t graph_project = nullptr;   // the captured chain's projection node: its camera argument is rewritten every replay
+    ProjectLaunch proj{};                     // the projection kernel's arguments of the current frame
     std::vector<uint64_t> graph_sig;  // everything the chain's kernel arguments and grids derive from
     bool have_cam = false, have_frame = false, have_sort = false;
 
@@ -417,7 +420,10 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
     if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BEGIN], s));
     if (c->n) {
         SceneSoA sc{c->px, c->py, c->pz, c->cov0, c->cov1, c->cov2, c->rgba, c->sh_r, c->sh_g, c->sh_b, c->shcol};
-        if (render) launch_project_key(sc, c->n, c->cam_dev, 1, c->depth, c->slots, c->rec, c->bbox, c->rect_idx, s);
+        if (render) {
+            c->proj = ProjectLaunch{sc, c->n, c->cam, 1, c->depth, c->slots, c->rec, c->bbox, c->rect_idx, &c->fstate->overflow, {}};
+            launch_project_key(c->proj, s);
+        }
         else {   // a sort-only frame: its own slots (sets 1 and 2 in turn; set 0 belongs to the render frames and k_begin_frame)
             slots_now = c->slots + (size_t)(1 + c->sort_parity) * FRAME_SLOTS * FRAME_SLOT_WORDS;
             launch_depth_key(sc, c->n, c->cam, c->depth, slots_now, c->slots + (size_t)(2 - c->sort_parity) * FRAME_SLOTS * FRAME_SLOT_WORDS, s);
@@ -441,7 +447,10 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
     if (render) {
         const BinGrid g = make_grid(c);
         const int nbins = (g.bx_hi - g.bx_lo) * g.nby;
-        if (!c->n) HIP_TRY(c, hipMemsetAsync(c->bin_total, 0, sizeof(uint32_t) * nbins, s));
+        if (!c->n) {
+            HIP_TRY(c, hipMemsetAsync(c->bin_total, 0, sizeof(uint32_t) * nbins, s));
+            HIP_TRY(c, hipMemsetAsync(&c->fstate->overflow, 0, sizeof(uint32_t), s));   // (k_project_key zeroes it otherwise)
+        }
         BinBuffers bb{c->depth_index, &c->fstate->sorted_count, c->bin_table, c->slots, c->rect_idx, c->bin_rects, (c->n && c->rects_sorted_now) ? 1u : 0u, c->bin_total, c->bin_start, c->bin_start_pre, c->bin_rounds, c->bin_big, c->seg_start,
                       c->items, c->bin_list, &c->fstate->overflow, &c->fstate->visible, &c->fstate->tile_entries,
                       c->accum, c->mailbox_dev, c->fstate->report, c->bin_capacity, c->max_items, c->seg_len, &c->fstate->seg_len, c->items_by_size, &c->fstate->queue, std::min<uint32_t>(c->max_items, c->blend_grid), c->seg_target_items, c->bin_blocks, c->bin_mask, c->bin_sat,
@@ -467,7 +476,7 @@ static void drop_graph(gsr_ctx* c)
 {
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     if (c->graph) (void)hipGraphDestroy(c->graph);
-    c->graph_exec = nullptr; c->graph = nullptr;
+    c->graph_exec = nullptr; c->graph = nullptr; c->graph_project = nullptr;
     c->graph_sig.clear();
 }
 
@@ -525,15 +534,15 @@ int enqueue_frame(gsr_ctx* c, bool render)
     c->bucket_order_now = use_bucket_order(c);
     c->cam.sh_on = c->sh_count ? 1 : 0;
     c->cam.band[0] = c->band[0]; c->cam.band[1] = c->band[1]; c->cam.band[2] = c->band[2];
-    static_assert(offsetof(FrameState, minmax) == 0 && sizeof(FrameState) % 4 == 0, "k_begin_frame resets the frame words");
-    // (a sort-only frame needs none of this: k_depth_key takes the camera by value and owns its slots, and the frame words the
-    //  sort writes -- min / max, digit totals, the survivors' count -- are stored, not accumulated)
-    if (render) launch_begin_frame(c->cam, c->cam_dev, reinterpret_cast<uint32_t*>(c->fstate), (uint32_t)(sizeof(FrameState) / 4), c->slots, s);
-    else if (!c->sort_slots_ready) {   // the first sort-only frame of the context: both of their slot sets
-        for (int k = 1; k <= 2; k++)
+    // No kernel in front of the frame: the camera is an argument of the projection kernel (k_project_key; k_depth_key in a
+    // sort-only frame), the frame slots are left clean by their last reader, the frame words are stored, not accumulated
+    // (the overflow word is zeroed by k_project_key).  The context's first frame initialises all of them, once.
+    static_assert(offsetof(FrameState, minmax) == 0 && sizeof(FrameState) % 4 == 0, "k_begin_frame initialises the frame words");
+    if (c->slots_need_init) {
+        for (int k = 0; k < 3; k++)   // the render frames' slot set and the two of the sort-only frames
             launch_begin_frame(c->cam, c->cam_dev, reinterpret_cast<uint32_t*>(c->fstate), (uint32_t)(sizeof(FrameState) / 4),
                                c->slots + (size_t)k * FRAME_SLOTS * FRAME_SLOT_WORDS, s);
-        c->sort_slots_ready = true;
+        c->slots_need_init = false;
     }
 
     bool replayed = false;
@@ -546,8 +555,22 @@ int enqueue_frame(gsr_ctx* c, bool render)
                 const int r = enqueue_chain(c, true, false);
                 hipGraph_t gph = nullptr;
                 ok = (hipStreamEndCapture(s, &gph) == hipSuccess) && r == GSR_OK && gph;
+                if (ok && c->n) {   // the node whose camera argument changes from frame to frame
+                    size_t nn = 0;
+                    ok = hipGraphGetNodes(gph, nullptr, &nn) == hipSuccess && nn > 0;
+                    std::vector<hipGraphNode_t> nodes(nn);
+                    if (ok) ok = hipGraphGetNodes(gph, nodes.data(), &nn) == hipSuccess;
+                    for (size_t k = 0; ok && k < nn && !c->graph_project; k++) {
+                        hipGraphNodeType ty;
+                        hipKernelNodeParams kp{};
+                        if (hipGraphNodeGetType(nodes[k], &ty) == hipSuccess && ty == hipGraphNodeTypeKernel &&
+                            hipGraphKernelNodeGetParams(nodes[k], &kp) == hipSuccess && kp.func == project_key_kernel())
+                            c->graph_project = nodes[k];
+                    }
+                    ok = ok && c->graph_project != nullptr;
+                }
                 if (ok) ok = hipGraphInstantiate(&c->graph_exec, gph, nullptr, nullptr, 0) == hipSuccess;
-                if (ok) { c->graph = gph; c->graph_sig = std::move(sig); }
+                if (ok) { c->graph = gph; c->graph_sig = std::move(sig); c->graph_fresh = true; }
                 else if (gph) (void)hipGraphDestroy(gph);
             }
             if (!ok) {  // this runtime cannot capture the chain: individual launches from now on
@@ -557,6 +580,19 @@ int enqueue_frame(gsr_ctx* c, bool render)
             }
         }
         if (c->graph_exec) {
+            if (c->graph_project && !c->graph_fresh) {   // (a graph captured for this very frame already holds its camera)
+                c->proj.cam = c->cam;
+                c->proj.bind();
+                hipKernelNodeParams kp{};
+                kp.func = const_cast<void*>(project_key_kernel());
+                kp.gridDim = project_key_grid(c->proj.n);
+                kp.blockDim = dim3(PROJ_THREADS);
+                kp.sharedMemBytes = 0;
+                kp.kernelParams = c->proj.ptrs;
+                kp.extra = nullptr;
+                HIP_TRY(c, hipGraphExecKernelNodeSetParams(c->graph_exec, c->graph_project, &kp));
+            }
+            c->graph_fresh = false;
             HIP_TRY(c, hipGraphLaunch(c->graph_exec, s));
             c->sort_culled = band_is_partial(c);
             replayed = true;
@@ -692,6 +728,7 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
     CREATE_TRY(hipMalloc((void**)&c->cam_dev, sizeof(CamParams)));
     CREATE_TRY(hipMalloc((void**)&c->slots, sizeof(int32_t) * 3 * FRAME_SLOTS * FRAME_SLOT_WORDS));   // render frames' set, two sets of the sort-only frames
     CREATE_TRY(hipMemset(c->slots, 0, sizeof(int32_t) * 3 * FRAME_SLOTS * FRAME_SLOT_WORDS));
+    c->slots_need_init = true;   // (the first frame's enqueue launches the one-time initialisation: the stream exists by then)
     if (const char* e = getenv("GSR_NO_GRAPH")) c->graphs_enabled = atoi(e) == 0;
     if (const char* e = getenv("GSR_FUSE_COMBINE")) c->fuse_combine = atoi(e) != 0;   // A/B knob: 0 = separate k_combine launch
     if (const char* e = getenv("GSR_SATURATE")) c->saturate = atoi(e) != 0;           // A/B knob: 0 = no saturation skip

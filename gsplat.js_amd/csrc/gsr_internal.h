@@ -136,9 +136,21 @@ constexpr int FRAME_SLOT_WORDS = 32;   // words per slot (one 128-byte line): [0
                                        // [4] sum of opacity byte x tiles / 16 (the frame's optical depth, k_bin_finalize)
 // the depth key and the min / max alone (sort-only frames): camera by value, its own frame slots, the next frame's reset
 void launch_depth_key(const SceneSoA& sc, uint32_t n, const CamParams& cam, int32_t* depth, int32_t* slots, int32_t* slots_next, hipStream_t s);
-void launch_project_key(const SceneSoA& sc, uint32_t n, const CamParams* cam_dev, int do_project, int32_t* depth,
-                        int32_t* slots /* FRAME_SLOTS * FRAME_SLOT_WORDS, reset by k_begin_frame */, Record* rec, uint2* bbox,
-                        uint32_t* rect /* n: packed bin rectangle per splat */, hipStream_t s);
+// The projection kernel's launch as a value: its arguments and the pointer array hipLaunchKernel / a graph kernel node take.
+// (One struct for both, so that the graph replay rewrites exactly what a direct launch passes: the camera.)
+struct ProjectLaunch {
+    SceneSoA sc; uint32_t n; CamParams cam; int do_project;   // do_project: 1 = project (render frames)
+    int32_t* depth;
+    int32_t* slots;      // FRAME_SLOTS * FRAME_SLOT_WORDS, clean at the start of the frame (the finalize step resets them)
+    Record* rec; uint2* bbox;
+    uint32_t* rect;      // n: packed bin rectangle per splat
+    uint32_t* overflow;  // the frame's overflow word, zeroed by the kernel
+    void* ptrs[10];
+    void bind();
+};
+const void* project_key_kernel();
+dim3 project_key_grid(uint32_t n);
+void launch_project_key(ProjectLaunch& a, hipStream_t s);
 
 // radix sort of the 17-bit keys; see k_sort.hip
 struct SortBuffers {
@@ -175,7 +187,8 @@ struct BinBuffers {
     const uint32_t* depth_index; // *count entries
     const uint32_t* count;       // ranks to bin (SortBuffers::count)
     uint32_t* table;             // nblocks * nbins  (counts, then per-workgroup offsets inside each bin)
-    const int32_t* slots;        // FRAME_SLOTS partial (visible splats, 16x16 tile overlaps) sums of k_project_key
+    int32_t* slots;              // FRAME_SLOTS partial (visible splats, 16x16 tile overlaps) sums of k_project_key; the finalize step,
+                                 // their last reader in a frame, resets them for the next one
     const uint32_t* rect_idx;    // n: packed bin rectangle of every splat (k_project_key)
     uint32_t* rects;             // n: the same in depth order (count pass -> scatter pass)
     uint32_t rects_sorted;       // 1: the sort has left them there already (SortBuffers::rects_out)

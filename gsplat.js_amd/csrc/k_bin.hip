@@ -215,7 +215,7 @@ struct FinalizeArgs {
     const uint32_t* bin_total; int nbins;
     uint32_t seg_len_min, seg_target_items; int by_size;
     uint32_t* seg_len_out; uint32_t max_items, capacity;
-    const int32_t* slots; uint32_t have_counts;
+    int32_t* slots; uint32_t have_counts;
     uint32_t *bin_start, *seg_start, *items, *overflow;
     uint64_t *visible, *tile_entries, *accum, *report;
     uint32_t* queue; uint32_t queue_start;
@@ -239,7 +239,7 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa, uint32
     uint32_t* __restrict__ bin_start = fa.bin_start;
     uint32_t* __restrict__ seg_start = fa.seg_start;
     uint32_t* __restrict__ items = fa.items;
-    const int32_t* __restrict__ slots = fa.slots;
+    int32_t* __restrict__ slots = fa.slots;
     const uint32_t have_counts = fa.have_counts;
     uint32_t* seg_len_out = fa.seg_len_out; uint32_t* overflow = fa.overflow; uint64_t* visible = fa.visible;
     uint64_t* tile_entries = fa.tile_entries; uint64_t* accum = fa.accum; uint64_t* report = fa.report;
@@ -392,6 +392,13 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa, uint32
         ex += c;
         sx += nf + (part ? 1u : 0u);
         fx += nf;
+    }
+    // This step is the last reader of the frame slots (k_quantise_hist took the depth range earlier in the frame): it leaves
+    // them as the next frame's projection expects them -- min <- INT_MAX, max <- INT_MIN (the values wasm/wasm.cpp:14-15 starts
+    // from), the counters <- 0 -- with its last stores, so that no kernel in front of a frame has to.
+    if (have_counts && threadIdx.x < FRAME_SLOTS) {
+        int32_t* sl = slots + (size_t)threadIdx.x * FRAME_SLOT_WORDS;
+        sl[0] = 0x7fffffff; sl[1] = (int32_t)0x80000000; sl[2] = 0; sl[3] = 0; sl[4] = 0;
     }
     if (threadIdx.x == 0) {
         *queue = queue_start;  // the compositor's workgroups take items 0..grid-1 by index, later ones from here

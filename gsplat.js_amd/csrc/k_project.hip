@@ -135,15 +135,18 @@ __device__ __forceinline__ float eval_sh_texture(const uint32_t* __restrict__ te
 // Writes depth[i] always; rec[i] for splats that survive the culls; bbox[i] always
 // (x0 > x1 marks "nothing to draw").
 // ---------------------------------------------------------------------------
-// The camera lives in device memory (written by k_begin_frame just before the frame) so that the frame's kernel
-// arguments do not change from frame to frame and the whole chain can be replayed as a HIP graph.
-__global__ __launch_bounds__(PROJ_THREADS) void k_project_key(SceneSoA sc, uint32_t n, const CamParams* __restrict__ camp,
+// The camera is a kernel argument (scalar loads from the kernarg segment).  It is the one argument of the frame's chain that
+// changes from frame to frame: when the chain is replayed as a HIP graph, the host rewrites this kernel node's parameters
+// (hipGraphExecKernelNodeSetParams, gsr_api.cpp) -- there is no kernel in front of the frame that would carry the camera to
+// device memory and reset the frame's words.  What such a kernel did is done where it costs nothing: the frame slots are
+// reset by their last reader (the finalize step, k_bin.hip), the overflow word here.
+__global__ __launch_bounds__(PROJ_THREADS) void k_project_key(SceneSoA sc, uint32_t n, CamParams cam,
                                                               int do_project, int32_t* __restrict__ depth,
                                                               int32_t* __restrict__ slots,
                                                               Record* __restrict__ rec, uint2* __restrict__ bbox,
-                                                              uint32_t* __restrict__ rect)
+                                                              uint32_t* __restrict__ rect, uint32_t* __restrict__ overflow)
 {
-    const CamParams& cam = *camp;  // uniform address: scalar loads
+    if (blockIdx.x == 0 && threadIdx.x == 0) *overflow = 0u;   // (raised by the binning kernels later in this frame)
     __shared__ int32_t s_min[4], s_max[4];
     __shared__ uint32_t s_vis[4], s_til[4], s_oti[4];
     int32_t dmin = 0x7fffffff, dmax = (int32_t)0x80000000;
@@ -397,17 +400,25 @@ void launch_depth_key(const SceneSoA& sc, uint32_t n, const CamParams& cam, int3
     hipLaunchKernelGGL(k_depth_key, dim3((n + per - 1) / per), dim3(PROJ_THREADS), 0, s, sc, n, cam.vp2, cam.vp6, cam.vp10, depth, slots, slots_next);
 }
 
-void launch_project_key(const SceneSoA& sc, uint32_t n, const CamParams* cam, int do_project, int32_t* depth,
-                        int32_t* slots, Record* rec, uint2* bbox, uint32_t* rect, hipStream_t s)
+void ProjectLaunch::bind()
 {
-    if (!n) return;
-    hipLaunchKernelGGL(k_project_key, dim3((n + PROJ_THREADS - 1) / PROJ_THREADS), dim3(PROJ_THREADS), 0, s, sc, n, cam, do_project, depth,
-                       slots, rec, bbox, rect);
+    void* p[] = {&sc, &n, &cam, &do_project, &depth, &slots, &rec, &bbox, &rect, &overflow};
+    static_assert(sizeof p == sizeof ptrs, "one pointer per kernel argument");
+    for (size_t k = 0; k < sizeof p / sizeof p[0]; k++) ptrs[k] = p[k];
+}
+const void* project_key_kernel() { return (const void*)k_project_key; }
+dim3 project_key_grid(uint32_t n) { return dim3((n + PROJ_THREADS - 1) / PROJ_THREADS); }
+
+void launch_project_key(ProjectLaunch& a, hipStream_t s)
+{
+    if (!a.n) return;
+    a.bind();
+    (void)hipLaunchKernel(project_key_kernel(), project_key_grid(a.n), dim3(PROJ_THREADS), a.ptrs, 0, s);
 }
 
-// Start of a frame, one small workgroup: the by-value camera goes to its device slot (kernarg -> global) and the
-// frame's device words are reset (minDepth / maxDepth to the values wasm/wasm.cpp:14-15 starts from, everything
-// else to zero).  One launch instead of a copy kernel plus a setter.
+// Initialisation of a context's frame words and of one set of frame slots (minDepth / maxDepth to the values
+// wasm/wasm.cpp:14-15 starts from, everything else to zero); the by-value camera goes to a device slot.  Once per context
+// and slot set: the frames keep their words clean themselves (k_project_key, k_depth_key, the finalize step).
 __global__ void k_begin_frame(CamParams cam, CamParams* __restrict__ dst, uint32_t* __restrict__ frame_words, uint32_t nwords,
                               int32_t* __restrict__ slots)
 {

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=1)
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--res-div", type=int, default=1, help="render at 1/N of the configuration's resolution and focal length (same splats, coarser bin grid)")
+    ap.add_argument("--no-timing", action="store_true", help="contexts without stage events: frames replay the captured graph (frames/s only)")
     ap.add_argument("--n", type=int, default=0, help="splats (default: the configuration's), same generator parameters")
     ap.add_argument("--sort-only", action="store_true", help="time gsr_sort (key + min/max + radix) instead of full frames")
     args = ap.parse_args()
@@ -55,7 +56,7 @@ def main():
         os.environ.update(envs)
         rs = []
         for _ in range(F):
-            r = gh.HIPRenderer(W, H, timing=True, throughput=F > 1, lib_path=lib_of(name))
+            r = gh.HIPRenderer(W, H, timing=not args.no_timing, throughput=F > 1, lib_path=lib_of(name))
             r.render(scene, gh.orbit_camera(0, 120, W, H, cfg["fx"]))
             rs.append(r)
         for k in envs:
@@ -95,7 +96,7 @@ def main():
             st = [r.stats() for r in rs]
             fr = max(1, sum(int(x["frames"]) for x in st))
             for s in stages:
-                res[name][s].append(sum(x["sum_ms_" + s] for x in st) / fr * 1e3)
+                res[name][s].append(0.0 if args.no_timing else sum(x["sum_ms_" + s] for x in st) / fr * 1e3)
             res[name]["fps"].append(args.frames / dt)
     print("%-26s %8s | %s   (us, median of %d rounds x %d frames, %d in flight, %s)" % (
         "variant", "fps", " ".join("%11s" % s for s in stages), args.rounds, args.frames, F, args.config))
