@@ -37,7 +37,8 @@ thread_local std::string g_create_error;
 
 enum Stage { EV_BEGIN = 0, EV_PROJECT, EV_SORT, EV_BIN, EV_BLEND /* after k_blend */, EV_COMBINE /* after k_combine */, EV_COUNT };
 
-struct FrameState {  // small per-frame device words, reset by k_begin_frame (minmax to +max / -max, the rest to zero)
+struct FrameState {  // small per-frame device words; initialised once (k_begin_frame), then every frame STORES them -- only `overflow`
+                     // is accumulated, and zeroed by k_project_key
     int32_t minmax[2];
     uint32_t overflow;
     uint32_t queue;   // compositor work-item counter
@@ -151,7 +152,7 @@ struct gsr_ctx {
     bool frame8_valid = false;
 
     CamParams cam{};
-    CamParams* cam_dev = nullptr;     // the frame's camera in device memory (k_begin_frame)
+    CamParams* cam_dev = nullptr;     // a camera slot in device memory (written by the one-time initialisation only)
     hipEvent_t link_ev[2] = {nullptr, nullptr};  // gsr_stream_order
     // the frame's launch chain replayed as a HIP graph (frames that carry no stage events)
     bool graphs_enabled = true;
