@@ -591,9 +591,15 @@ int enqueue_frame(gsr_ctx* c, bool render)
                 kp.sharedMemBytes = 0;
                 kp.kernelParams = c->proj.ptrs;
                 kp.extra = nullptr;
-                HIP_TRY(c, hipGraphExecKernelNodeSetParams(c->graph_exec, c->graph_project, &kp));
+                if (hipGraphExecKernelNodeSetParams(c->graph_exec, c->graph_project, &kp) != hipSuccess) {
+                    (void)hipGetLastError();   // this runtime cannot rewrite the node: individual launches from now on
+                    drop_graph(c);
+                    c->graphs_enabled = false;
+                }
             }
             c->graph_fresh = false;
+        }
+        if (c->graph_exec) {
             HIP_TRY(c, hipGraphLaunch(c->graph_exec, s));
             c->sort_culled = band_is_partial(c);
             replayed = true;
