@@ -501,9 +501,10 @@ __global__ __launch_bounds__(FIN_THREADS) void k_bin_starts(const uint32_t* __re
 // splat enters every cell its rectangle touches -- 1.7 cells instead of 5.2 bins per splat on C4, with tables of 510
 // instead of 8160 columns -- and the cell lists keep the depth order; an entry carries the splat's rectangle in bins.
 // Level two cuts every cell list into chunks of CELL_CHUNK entries and places each entry in the 16 bins of its cell:
-// per 64 entries and bin one ballot and a lane count -- no LDS lane sets, no atomics, no loops of different lengths
-// in one wave (k_cell_count, k_cell_scan, k_cell_scatter2).  The lists are the ones the one-level pass builds, entry
-// for entry.
+// count (k_cell_count: per chunk and bin, and per wave of the chunk), scan (k_cell_scan: down the chunks of a cell),
+// scatter (k_cell_scatter2: per 64 entries eight ballots -- columns and rows -- whose scalar ANDs are the sixteen bins'
+// lane sets and, as they are, the exec masks of the stores) -- no LDS lane sets, no atomics, no loops of different
+// lengths in one wave.  The lists are the ones the one-level pass builds, entry for entry.
 // ---------------------------------------------------------------------------
 constexpr int CELL_SHIFT = 2;
 constexpr int CELL_SIDE = 1 << CELL_SHIFT;                 // bins along a cell's side
