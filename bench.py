@@ -173,6 +173,78 @@ def other_config(gh, name, device, F, frames=120):
     return out
 
 
+def split_config(gh, torch, dist, name, rank, world, local_rank, F, steps, warmup, custom_collective):
+    """N>1: configuration `name` split over the ranks by tile columns with the library's exchange (RCCL; a host-staged gloo
+    all-gather in the one-GPU rehearsal): BASELINE C5 = C4's scene on N GPUs.  Every rank calls this; the frame rate is the
+    whole job's (barrier, MAX over ranks), like the headline's."""
+    from gsplat_hip import bands
+    cfg = gh.synth.CONFIGS[name]
+    W, H, N = cfg["width"], cfg["height"], cfg["n"]
+    scene = gh.Scene()
+    scene.setData(gh.synth.config_rows(name))
+    dev = torch.device("cuda", local_rank)
+    cal = gh.HIPRenderer(W, H, device=local_rank)
+    cost = np.zeros(-(-W // 32))
+    for k in (0, 60):
+        cal.render(scene, gh.orbit_camera(k, ORBIT_FRAMES, W, H, cfg["fx"]))
+        cost += cal.bin_totals().sum(axis=0) + 0.25 * 32 * H
+    cal.dispose()
+    got = [bands.balanced_edges(W, world, cost)]
+    dist.broadcast_object_list(got, src=0)        # every rank uses rank 0's edges
+    edges = got[0]
+    rs = [gh.HIPRenderer(W, H, device=local_rank, timing=False, throughput=F > 1) for _ in range(F)]
+    if custom_collective:
+        def allgather(send, recv, nbytes, stream):
+            st = torch.cuda.ExternalStream(stream, device=dev)
+            st.synchronize()
+            mine = torch.as_tensor(bands.DevicePointer(send, (nbytes,), "|u1"), device=dev).cpu()
+            every = torch.empty(world * nbytes, dtype=torch.uint8)
+            dist.all_gather_into_tensor(every, mine)
+            with torch.cuda.stream(st):
+                torch.as_tensor(bands.DevicePointer(recv, (world * nbytes,), "|u1"), device=dev).copy_(every)
+            st.synchronize()
+        rs[0].join_group_custom(rank, world, edges, allgather)
+    else:
+        ids = [gh.new_group_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        rs[0].join_group(ids[0], rank, world, edges)
+    for rr in rs[1:]:
+        rr.share_group(rs[0])
+    poses = [gh.orbit_camera(k, ORBIT_FRAMES, W, H, cfg["fx"]).f32() for k in range(ORBIT_FRAMES)]
+    for rr in rs:
+        rr.render(scene, gh.orbit_camera(0, ORBIT_FRAMES, W, H, cfg["fx"]))
+
+    def run(k0, count):
+        for k in range(k0, k0 + count):
+            rr = rs[k % F]
+            rr.set_camera_arrays(*poses[k % ORBIT_FRAMES], cfg["fx"], cfg["fx"])
+            rr.render_async()
+            rr.allgather_frame_async()
+        for rr in rs:
+            rr.sync()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    run(0, warmup)
+    t0 = time.perf_counter()
+    run(warmup, steps)
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    sts = [rr.stats() for rr in rs]
+    out = {"workload": "%s scene split over %d GPUs by tile columns (BASELINE C5): %d synthetic gaussians (seed %d), %dx%d, 120-pose orbit"
+                       % (name, world, N, cfg["seed"], W, H),
+           "frames_per_sec": steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "n_gpus": world, "steps": steps, "warmup": warmup,
+           "frames_in_flight": F, "scaling": "strong", "exchange": "host-staged gloo all-gather (rehearsal)" if custom_collective else
+           "RGBA8 slabs, ncclAllGather issued by the library", "band_edges": [list(e) for e in edges],
+           "overflow_frames_this_rank": sum(int(x["overflow_frames"]) for x in sts)}
+    for rr in reversed(rs):
+        rr.dispose()
+    return out
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,6 +269,9 @@ def main():
                          "a GPU and the slab all-gather is staged through host memory")
     ap.add_argument("--timing-interval", type=int, default=8,
                     help="stage events (HIP) on every k-th frame of the timed region; 1 = every frame")
+    ap.add_argument("--c5-rehearsal", action="store_true",
+                    help="N>1 over gloo: also run the C5 leg (5 M splats at 3840x2160 split over the ranks) with the library's exchange "
+                         "driven through a host-staged gloo all-gather (gsr_comm_init_custom) -- a rehearsal of its control flow on one GPU")
     ap.add_argument("--emulate-rank", default=None, metavar="Q/G",
                     help="single GPU only: render just the band rank Q of G would own (no exchange) -> per-rank device time of a G-GPU run")
     args = ap.parse_args()
@@ -368,6 +443,11 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda:%d" % local_rank)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # N>1: the 4K scene split over the same ranks (BASELINE C5) in the same run; every rank takes part
+    c5 = None
+    if world > 1 and args.config == "C3" and not args.no_other_configs and not args.timed_only and (in_library or args.c5_rehearsal):
+        c5 = split_config(gh, torch, dist, "C4", rank, world, local_rank, F, max(30, args.steps // 4), 9, custom_collective=not in_library)
 
     sts = [rr.stats() for rr in rs]
     overflow_frames = sum(int(x["overflow_frames"]) for x in sts) - overflow_before[0]
@@ -578,6 +658,8 @@ def main():
         }
         if world == 1 and args.config == "C3" and not args.timed_only and not args.no_other_configs and not emu:
             out["other_configs"] = {name: other_config(gh, name, local_rank, F) for name in ("C2", "C4")}
+        if c5 is not None:
+            out["other_configs"] = {"C5": c5}
         if world == 1 and not args.no_cpu_baseline and not args.timed_only:
             out["cpu_baseline"] = cpu_baseline(gh, cfg, scene.data[:8 * N], scene.positions)
         print(json.dumps(out))
