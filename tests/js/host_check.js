@@ -104,6 +104,73 @@ if (mode === "pack") {                     // pack <splat> <outprefix> <W> <H> <
     for (let slot = 0; slot < 3; slot++) check(slot);
     fs.writeFileSync(out + ".json", JSON.stringify({ same, frames }));
     rs.forEach((r) => r.dispose()); ref.dispose();
+} else if (mode === "golden") {
+    // golden <host_golden.json>: this package's classes on the inputs of the fixture that tests/golden/make_golden_host.js
+    // produced by running the reference's own TypeScript; prints the outputs that differ (none expected) and how many were compared
+    const g = JSON.parse(fs.readFileSync(a[0], "utf8"));
+    const f64 = new Float64Array(1), b8 = new Uint8Array(f64.buffer);
+    const un = (h) => { for (let i = 0; i < 8; i++) b8[7 - i] = parseInt(h.substr(2 * i, 2), 16); return f64[0]; };
+    const hex64 = (x) => { f64[0] = x; return Array.from(b8).reverse().map((b) => b.toString(16).padStart(2, "0")).join(""); };
+    const hexBytes = (ta) => Buffer.from(ta.buffer, ta.byteOffset, ta.byteLength).toString("hex");
+    const bytes = (h) => { const b = Buffer.from(h, "hex"), u = new Uint8Array(b.length); u.set(b); return u; };
+    const bad = [];
+    let compared = 0;
+    const same = (what, got, want) => { compared++; if (JSON.stringify(got) !== JSON.stringify(want)) bad.push(what); };
+    g.quaternions.forEach((e, k) => {
+        const q = e.q.map(un), Q = new G.Quaternion(q[0], q[1], q[2], q[3]), N = Q.normalize(), o = e.other.map(un);
+        same("quaternion.normalize " + k, N.flat().map(hex64), e.normalized);
+        same("quaternion.multiply " + k, Q.multiply(new G.Quaternion(o[0], o[1], o[2], o[3])).flat().map(hex64), e.times_other);
+        same("RotationFromQuaternion(normalized) " + k, G.Matrix3.RotationFromQuaternion(N).buffer.map(hex64), e.rotation_of_normalized);
+        same("RotationFromQuaternion(raw) " + k, G.Matrix3.RotationFromQuaternion(Q).buffer.map(hex64), e.rotation_raw);
+    });
+    g.matrix3_products.forEach((e, k) => same("Matrix3.multiply " + k, new G.Matrix3(...e.a.map(un)).multiply(new G.Matrix3(...e.b.map(un))).buffer.map(hex64), e.a_multiply_b));
+    g.matrix4_products.forEach((e, k) => same("Matrix4.multiply " + k, new G.Matrix4(...e.a.map(un)).multiply(new G.Matrix4(...e.b.map(un))).buffer.map(hex64), e.a_multiply_b));
+    g.cameras.forEach((e, k) => {
+        const p = e.position.map(un), q = e.rotation.map(un);
+        const cam = new G.Camera(new G.Vector3(p[0], p[1], p[2]), new G.Quaternion(q[0], q[1], q[2], q[3]), un(e.fx), un(e.fy), un(e.near), un(e.far));
+        cam.update(e.width, e.height);
+        same("Camera.projectionMatrix " + k, cam.projectionMatrix.buffer.map(hex64), e.projectionMatrix);
+        same("Camera.viewMatrix " + k, cam.viewMatrix.buffer.map(hex64), e.viewMatrix);
+        same("Camera.viewProj " + k, cam.viewProj.buffer.map(hex64), e.viewProj);
+    });
+    const snap = (what, sc, w) => {
+        same(what + " vertexCount", sc.vertexCount, w.vertexCount);
+        same(what + " texture", [sc.width, sc.height, sc.data.length], [w.width, w.height, w.data_length]);
+        same(what + " data", hexBytes(new Uint32Array(sc.data.buffer, sc.data.byteOffset, 8 * sc.vertexCount)), w.data);
+        same(what + " positions", hexBytes(sc.positions), w.positions);
+        same(what + " rotations", hexBytes(sc.rotations), w.rotations);
+        same(what + " scales", hexBytes(sc.scales), w.scales);
+    };
+    {
+        const sc = new G.Scene();
+        let events = 0;
+        sc.addEventListener("change", () => { events++; });
+        sc.setData(bytes(g.scene.rows));
+        snap("setData", sc, g.scene.after_setData);
+        same("setData tail", Array.from(sc.data.subarray(8 * sc.vertexCount)).every((x) => x === 0), g.scene.after_setData.data_tail_is_zero);
+        const t = g.scene.translate.t.map(un);
+        sc.translate(new G.Vector3(t[0], t[1], t[2]));
+        snap("translate", sc, g.scene.translate.after);
+        const q = g.scene.rotate.q.map(un);
+        sc.rotate(new G.Quaternion(q[0], q[1], q[2], q[3]));
+        snap("rotate", sc, g.scene.rotate.after);
+        const s = g.scene.scale.s.map(un);
+        sc.scale(new G.Vector3(s[0], s[1], s[2]));
+        snap("scale", sc, g.scene.scale.after);
+        sc.limitBox(...g.scene.limitBox.box.map(un));
+        snap("limitBox", sc, g.scene.limitBox.after);
+        same("change events", events, g.scene.change_events);
+    }
+    {
+        const e = g.scene_sh, sb = bytes(e.shs), shs = new Float32Array(sb.buffer, 0, sb.length / 4), nsh = shs.length / 48;
+        const sc = new G.Scene();
+        sc.bandsIndices = new Int32Array([e.first - 1, 80, 120]);
+        sc.setData(bytes(g.scene.rows), shs);
+        same("sh height", sc.shHeight, e.shHeight);
+        same("sh texture words", sc.shs_rgb.map((t) => t.length), e.texture_words);
+        for (let c = 0; c < 3; c++) same("sh channel " + c, hexBytes(new Uint32Array(sc.shs_rgb[c].buffer, sc.shs_rgb[c].byteOffset, 8 * nsh)), e.shs_rgb[c]);
+    }
+    console.log(JSON.stringify({ compared, mismatches: bad }));
 } else if (mode === "group") {
     // group <splat> <outprefix> <W> <H> <fx> <rank> <world> <idfile>: renderer.render(scene, camera) with the framebuffer
     // all-gather inside the library (RCCL).  Rank 0 writes the communicator id to <idfile>, the others wait for it: the id
