@@ -106,7 +106,62 @@ def cpu_baseline(gh, cfg, data, pos, sample_frames=2, sort_calls=10):
                 js = json.loads(out.stdout.strip().splitlines()[-1])
     except Exception:
         js = None
+    # The one native boundary the reference has: wasm `sort` (wasm/wasm.cpp:8-13, called at Worker.ts:36-43).  Its drop-in
+    # gsplat_sort_host takes HOST pointers, so a call is pageable H2D of 12 N bytes + the device chain + D2H of 4 N bytes:
+    # timed here at three sizes beside the reference's own sort (native build, one pinned core) on the same positions, and
+    # beside the device chain alone (gsr_sort on a resident scene, HIP events) -- the difference is transfers and host calls.
+    sort_host = {}
+    try:
+        L = gh.load_library()
+        for n_ in (10000, 300000, 1000000):
+            if n_ > n:
+                continue
+            p_ = np.ascontiguousarray(pos[:3 * n_], dtype=np.float32)
+            out = np.empty(n_, dtype=np.uint32)
+            vps = [np.ascontiguousarray(c.f32()[2], dtype=np.float32) for c in cams[:8]]
+            for k in range(3):
+                L.gsplat_sort_host(vps[k].ctypes.data, n_, p_.ctypes.data, None, out.ctypes.data, None, None)
+            ts = []
+            for k in range(12):
+                t0 = time.perf_counter()
+                L.gsplat_sort_host(vps[k % 8].ctypes.data, n_, p_.ctypes.data, None, out.ctypes.data, None, None)
+                ts.append(time.perf_counter() - t0)
+            ok = bool(np.array_equal(out, O.sort(vps[11 % 8], p_)[0]))
+            tc = []
+            try:
+                os.sched_setaffinity(0, {usable[len(usable) // 2]})
+            except (AttributeError, OSError):
+                pass
+            try:
+                for k in range(6):
+                    t0 = time.perf_counter()
+                    (O.ref_sort(vps[k], p_, calls=1) if use_ref else O.sort(vps[k], p_))
+                    tc.append((time.perf_counter() - t0) / (2.0 if use_ref else 1.0))
+            finally:
+                try:
+                    os.sched_setaffinity(0, set(usable))
+                except (AttributeError, OSError):
+                    pass
+            r = gh.HIPRenderer(64, 64, timing=True)
+            r.set_raw_scene(data[:8 * n_], p_)
+            for k in range(20):
+                if k == 8:
+                    r.reset_stats()
+                r.set_camera(cams[k % len(cams)])
+                r.sort()
+            st = r.stats()
+            dev_ms = (st["sum_ms_project_key"] + st["sum_ms_sort"]) / max(int(st["frames"]), 1)
+            r.dispose()
+            m = float(np.median(ts)) * 1e3
+            sort_host[str(n_)] = {"sort_host_ms": m, "device_chain_ms": dev_ms, "transfers_and_host_calls_ms": m - dev_ms,
+                                  "h2d_bytes": 12 * n_, "d2h_bytes": 4 * n_, "cpu_reference_sort_ms": float(np.median(tc[1:])) * 1e3,
+                                  "depth_index_equals_oracle": ok}
+    except Exception as e:   # (never fatal for the headline)
+        sort_host = {"error": repr(e)}
     return {
+        "sort_host": sort_host,
+        "sort_host_note": "gsplat_sort_host(viewProj, n, positions, NULL, depthIndex, NULL, NULL) on pageable host arrays, median of 12 calls; "
+                          "cpu_reference_sort_ms = the reference's wasm.cpp built natively, one pinned core, same positions",
         "sort_js_ms": js["ms_median"] if js else None,
         "sort_js_note": "wasm.cpp's loops in plain JavaScript (V8, Math.fround per operation), 1 thread; an upper bound for the wasm worker" if js else None,
         "value": 1.0 / t_frame, "unit": "frames/s", "cores": cores, "kind": "port",
@@ -170,6 +225,110 @@ def other_config(gh, name, device, F, frames=120):
            "overflow_frames": sum(int(x["overflow_frames"]) for x in sts), "dropped_frames": sum(int(x["dropped_frames"]) for x in sts)}
     for rr in rs + [solo]:
         rr.dispose()
+    return out
+
+
+def sh_config(gh, device, F, frames=120):
+    """C3 with degree-3 spherical harmonics on EVERY splat (the fork's raison d'etre: vertex.glsl.ts:57-104,180-204,
+    Scene.ts:108-124): three half textures of 8 words per splat (96 bytes per splat more for the projection kernel to read,
+    inverse(view) and the degree-3 polynomial per visible splat, a float4 colour written per visible splat and read by the
+    compositor's staging instead of the record's rgb8).  Seeded coefficients: the half words are drawn directly (sign,
+    exponent 2^-6..2^-3, mantissa), which is what Scene.setData's packHalf2x16 would have produced from such floats."""
+    name = "C3"
+    cfg = gh.synth.CONFIGS[name]
+    W, H, N = cfg["width"], cfg["height"], cfg["n"]
+    rows = gh.synth.config_rows(name)
+    rng = np.random.default_rng(33)
+    tex = []
+    for _ in range(3):
+        w = rng.integers(0, 1 << 32, size=8 * N, dtype=np.uint64).astype(np.uint32)
+        ex = rng.integers(9, 13, size=8 * N, dtype=np.uint32)
+        ex2 = rng.integers(9, 13, size=8 * N, dtype=np.uint32)
+        w = (w & np.uint32(0x83FF83FF)) | (ex << np.uint32(10)) | (ex2 << np.uint32(26))
+        tex.append(w)
+    bands_idx = np.array([-1, -1, -1], dtype=np.int32)     # every splat: degree 3
+    poses = [gh.orbit_camera(k, ORBIT_FRAMES, W, H, cfg["fx"]).f32() for k in range(ORBIT_FRAMES)]
+    rs = [gh.HIPRenderer(W, H, device=device, throughput=F > 1, timing=True) for _ in range(F)]
+    solo = gh.HIPRenderer(W, H, device=device, timing=True)
+    for rr in rs + [solo]:
+        rr.set_scene_rows(rows)
+        rr.set_sh(tex, bands_idx)
+        rr.set_timing_interval(8)
+        for j in range(SETUP_FRAMES):
+            rr.set_camera_arrays(*poses[j], cfg["fx"], cfg["fx"])
+            rr.render_async()
+        rr.sync()
+        rr.reset_stats()
+
+    def run(ctxs, count):
+        t0 = time.perf_counter()
+        for k in range(count):
+            rr = ctxs[k % len(ctxs)]
+            rr.set_camera_arrays(*poses[k % ORBIT_FRAMES], cfg["fx"], cfg["fx"])
+            rr.render_async()
+        for rr in ctxs:
+            rr.sync()
+        return count / (time.perf_counter() - t0)
+
+    run(rs, 2 * F)
+    fps = run(rs, frames)
+    run([solo], 2)
+    solo.reset_stats()
+    fps1 = run([solo], max(30, frames // 2))
+    s1 = solo.stats()
+    f1 = max(int(s1["frames"]), 1)
+    sf = max(int(s1["sum_frames"]), 1)
+    V = s1["sum_visible"] / sf
+    pk = s1["sum_ms_project_key"] / f1
+    out = {"workload": "C3 with degree-3 SH on every splat: %d synthetic gaussians (seed %d) + 3 x 8 half-packed words per splat (seed 33), %dx%d, 120-pose orbit"
+                       % (N, cfg["seed"], W, H),
+           "frames_per_sec": fps, "frames_in_flight": F,
+           "one_frame_in_flight": {"frames_per_sec": fps1, "ms_per_frame": 1e3 / fps1,
+                                   "stage_ms": {k: s1["sum_ms_" + k] / f1 for k in ("project_key", "sort", "bin", "blend", "total")}},
+           "project_key": {"ms": pk, "algorithmic_bytes": 32.0 * N + 48.0 * V + (96.0 + 16.0) * V,
+                           "GBps": (32.0 * N + 48.0 * V + 112.0 * V) / (pk * 1e-3) / 1e9 if pk else 0,
+                           "note": "the plain kernel's 32 N + 48 V plus 96 B of SH halves read and 16 B of colour written per visible splat"},
+           "counts": {"N": N, "V": V},
+           "overflow_frames": sum(int(x.stats()["overflow_frames"]) for x in rs + [solo])}
+    for rr in rs + [solo]:
+        rr.dispose()
+    return out
+
+
+def scene_build_config(gh, device):
+    """Scene.setData and Scene.rotate (Scene.ts:126-257) as device kernels (gsr_set_scene_rows, gsr_scene_rotate: k_scene.hip,
+    every word bit-identical to the host loops) at C4's 5 M splats, beside the same loops in JavaScript (the package's Scene,
+    Node, one thread) on a bounded sample of 1 M splats."""
+    import shutil
+    import subprocess
+    rows = gh.synth.config_rows("C4")
+    n = rows.size // 32
+    r = gh.HIPRenderer(64, 64, device=device)
+    r.set_scene_rows(rows[:32 * 1000])          # (context and kernels warm)
+    t0 = time.perf_counter()
+    r.set_scene_rows(rows)
+    t_set = time.perf_counter() - t0
+    q = np.array([0.3, -0.2, 0.1, 0.9]); q = q / np.sqrt((q * q).sum())
+    ts = {}
+    for what, fn in (("rotate", lambda: r.scene_rotate(q)), ("translate", lambda: r.scene_translate([0.25, -0.5, 1.0])),
+                     ("scale", lambda: r.scene_scale([1.5, 0.75, 1.25]))):
+        fn(); r.sync()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            fn()
+        r.sync()
+        ts[what] = (time.perf_counter() - t0) / 5 * 1e3
+    r.dispose()
+    out = {"device": {"n": n, "set_scene_rows_ms": t_set * 1e3, "set_scene_rows_note": "includes the pageable upload of 32 B per splat",
+                      "scene_rotate_ms": ts["rotate"], "scene_translate_ms": ts["translate"], "scene_scale_ms": ts["scale"],
+                      "rotate_bytes": (32 + 36) * n * 1.0}}
+    node = shutil.which("node")
+    if node:
+        try:
+            o = subprocess.run([node, os.path.join(ROOT, "tools", "scene_js_baseline.js"), "1000000"], capture_output=True, text=True, timeout=120)
+            out["js_host"] = json.loads(o.stdout.strip().splitlines()[-1])
+        except Exception as e:
+            out["js_host"] = {"error": repr(e)}
     return out
 
 
@@ -263,6 +422,9 @@ def main():
                     help="N>1: framebuffer slab format of the per-frame all-gather (rgba8: what a display consumes)")
     ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="independent frames rendered concurrently on separate contexts/streams (frame k uses context k mod F)")
+    ap.add_argument("--throughput-contexts", action="store_true",
+                    help="contexts of the throughput kind (GSR_FLAG_THROUGHPUT: what the default three-in-flight run uses) even with "
+                         "--frames-in-flight 1: the timed region's own compositor kernel (k_blend) one launch at a time, for profiler runs")
     ap.add_argument("--equal-bands", action="store_true", help="N>1: equal-width bands instead of cost-balanced ones")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="N>1: nccl = RCCL over xGMI (the product path); gloo = rehearsal on a box without peers: ranks may share "
@@ -354,7 +516,7 @@ def main():
     rs = []
     for _ in range(F):   # every context owns its buffers and its stream; frames are independent of each other
         rr = gh.HIPRenderer(W, H, device=local_rank, early_out_eps=args.early_out_eps, band=None if in_library else band,
-                            timing=True, throughput=F > 1)
+                            timing=True, throughput=F > 1 or args.throughput_contexts)
         rs.append(rr)
     if in_library:
         # ONE communicator and ONE exchange stream per rank, shared by its F contexts: the collectives of a rank's frames in
@@ -564,6 +726,27 @@ def main():
                              "note": "HIP events around the whole device chain of gsr_sort: k_depth_key (camera by value, no k_begin_frame "
                                      "in front), k_quantise_hist, column scan, the radix kernels"}
         sr.dispose()
+        # The timed region's own compositor kernel, one launch at a time: a context of the kind the timed region uses
+        # (GSR_FLAG_THROUGHPUT: k_blend, one wave per tile, its cut of the lists), frames issued one after the other, HIP events
+        # on the library's stream.  `roofline` below is this kernel's (the headline and its roofline must be the
+        # same kernel); the one-frame context's k_blend2 keeps its own figures in `one_frame_in_flight`.
+        tr = gh.HIPRenderer(W, H, device=local_rank, early_out_eps=args.early_out_eps, timing=True, throughput=True)
+        for k in range(SETUP_FRAMES):
+            tr.render(scene, gh.orbit_camera(k, ORBIT_FRAMES, W, H, cfg["fx"]))
+        tr.set_timing_interval(1)
+        tr.reset_stats()
+        for k in range(60):
+            v, p, vp = poses[k % ORBIT_FRAMES]
+            tr.set_camera_arrays(v, p, vp, cfg["fx"], cfg["fx"])
+            tr.render_async()
+            tr.sync()
+        s3 = tr.stats()
+        f3 = max(int(s3["frames"]), 1)
+        solo["timed_region_kernels_one_launch_at_a_time"] = {
+            "stage_ms": {k: s3["sum_ms_" + k] / f3 for k in ("project_key", "sort", "bin", "blend", "total")},
+            "work_items": tr.work_items(),
+            "note": "a GSR_FLAG_THROUGHPUT context (the kind the timed region renders on) rendering one frame at a time"}
+        tr.dispose()
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -584,7 +767,7 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 if tj.get("build_id") == gh.build_id():
-                    sel = tj["frames_in_flight" if F > 1 else "one_frame"]
+                    sel = tj["frames_in_flight" if (F > 1 or args.throughput_contexts) else "one_frame"]
                     traffic, valu = sel["hbm_bytes_per_launch"], sel["valu_wave_instructions_per_launch"]
                     traffic_solo = tj["one_frame"]["hbm_bytes_per_launch"]
                     valu_solo = tj["one_frame"]["valu_wave_instructions_per_launch"]
@@ -600,10 +783,21 @@ def main():
         # the duration of the same kernel on the same frames with ONE frame in flight (untimed secondary leg), which is
         # what the committed rocprofv3 --kernel-trace summary of `bench.py --frames-in-flight 1 --timed-only` shows too.
         ach = b_blend / (ms["blend"] * 1e-3) / 1e9 if ms["blend"] > 0 else 0.0
-        blend_ms = solo["stage_ms"]["blend"] if solo else ms["blend"]
+        # the timed region's compositor kernel (k_blend on throughput contexts) in isolation; without the secondary legs
+        # (--timed-only, N>1) the timed region's own event pairs
+        tp = solo["timed_region_kernels_one_launch_at_a_time"] if solo else None
+        blend_ms = tp["stage_ms"]["blend"] if tp else ms["blend"]
         ach_solo = b_blend / (blend_ms * 1e-3) / 1e9 if blend_ms > 0 else 0.0
         sm = solo["stage_ms"] if solo else ms   # per-stage figures: uncontended times when several frames were in flight
-        kernel_name = "k_blend2" if (solo and r_solo_sub == 2) else "k_blend"
+        timed_sub = rs[0].work_items()["waves_per_tile"]
+        kernel_name = "k_blend2" if timed_sub == 2 else "k_blend"
+        if solo:   # the one-frame context's compositor (k_blend2) against the same byte model
+            b2 = solo["stage_ms"]["blend"]
+            solo["roofline"] = {"kernel": "k_blend2" if r_solo_sub == 2 else "k_blend", "avg_launch_ms": b2,
+                                "achieved": b_blend / (b2 * 1e-3) / 1e9 if b2 > 0 else 0.0,
+                                "frac": b_blend / (b2 * 1e-3) / 1e9 / HBM_PEAK_GBS if b2 > 0 else 0.0,
+                                "traffic": traffic_solo,
+                                "valu_frac": (valu_solo / (b2 * 1e-3) / 0.651e12) if (valu_solo and b2 > 0) else None}
         out = {
             "metric": "frames_per_sec", "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
@@ -619,7 +813,7 @@ def main():
             "stage_ms": ms,
             "counts": {"N": N, "V": V, "D_tiles16": D, "bin_entries32": E, "P": band_px},
             "roofline": {"bound": "valu", "kernel": kernel_name, "achieved": ach_solo, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach_solo / HBM_PEAK_GBS, "traffic": traffic_solo if solo else traffic, "traffic_note": traffic_note,
+                         "frac": ach_solo / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": b_blend, "avg_launch_ms": blend_ms,
                          "frames_in_flight_of_this_figure": 1 if solo else F,
                          "timed_region": None if not solo else {
@@ -632,9 +826,9 @@ def main():
             # secondary ceiling: VALU issue.  peak = what tools/valu_cost.hip sustains on this chip for the compositor's
             # own instruction mix (11 VALU of a covered quadrant incl. v_exp_f32 and v_pk_fma_f32, operands in VGPRs,
             # 7 waves/SIMD like k_blend, wall clock): 0.651e12 wave-instr/s (profiles/r02_valu_cost4.txt)
-            "valu": None if not (valu_solo if solo else valu) or not blend_ms else (lambda t_ms, v: {
+            "valu": None if not valu or not blend_ms else (lambda t_ms, v: {
                 "wave_instr_per_launch": v, "launch_ms": t_ms, "achieved_wave_instr_per_s": v / (t_ms * 1e-3),
-                "peak_wave_instr_per_s": 0.651e12, "frac": v / (t_ms * 1e-3) / 0.651e12})(blend_ms, valu_solo if solo else valu),
+                "peak_wave_instr_per_s": 0.651e12, "frac": v / (t_ms * 1e-3) / 0.651e12})(blend_ms, valu),
             "overflow_frames": overflow_frames, "dropped_frames": dropped_frames,
             "build_id": gh.build_id(),
             "stage_roofline": {
@@ -658,6 +852,8 @@ def main():
         }
         if world == 1 and args.config == "C3" and not args.timed_only and not args.no_other_configs and not emu:
             out["other_configs"] = {name: other_config(gh, name, local_rank, F) for name in ("C2", "C4")}
+            out["other_configs"]["C3_sh"] = sh_config(gh, local_rank, F)
+            out["other_configs"]["scene_build"] = scene_build_config(gh, local_rank)
         if c5 is not None:
             out["other_configs"] = {"C5": c5}
         if world == 1 and not args.no_cpu_baseline and not args.timed_only:

@@ -49,7 +49,7 @@ struct FrameState {  // small per-frame device words; initialised once (k_begin_
     uint32_t sorted_count;  // entries of depth_index: n, or the band's survivors (SortBuffers::count)
     uint32_t seg_len;       // the frame's compositor segment length (k_bin_finalize -> k_blend)
     uint32_t n_items;       // and its number of work items (directly behind seg_len: k_blend reads both through one pointer)
-    uint32_t spec;          // and 1 when the frame's segments are speculative (k_bin_finalize)
+    uint32_t spec;          // reserved (0)
 };
 
 }  // namespace
@@ -57,6 +57,7 @@ struct FrameState {  // small per-frame device words; initialised once (k_begin_
 struct gsr_ctx {
     int device = 0;
     int cu_count = 256;               // compute units of the device (the compositor's persistent grid is sized from it)
+    int cu_part = 0;                  // GSR_CU_PARTS: compute units of this context's share (0: the whole device)
     hipStream_t stream = nullptr;
     std::string error;
     gsr_options opt{};
@@ -95,16 +96,13 @@ struct gsr_ctx {
     uint32_t bin_big = 2;             // large bin grids: k_bin_scatter_big (GSR_BIN_BIG=0: the 64-register kernel + k_bin_finalize; 1: 2048-rank rounds)
     uint32_t *seg_start = nullptr, *items = nullptr;
     unsigned long long* bin_mask = nullptr;   // per-bin arrival masks of the compositor (null: separate k_combine launch)
-    uint32_t* bin_sat = nullptr;              // per-bin "saturated in front of segment ..." words, with bin_mask
     int items_by_size = 1;            // work items heaviest first (k_bin_finalize); GSR_ITEMS_BY_SIZE
-    uint32_t quad_from = 0;           // whole-bin items from this many entries go to four workgroups, one per tile (GSR_QUAD_FROM); 0 = off,
-                                      // the default: measured slower (C3 k_blend 184 -> 203 / 215 / 238 us from 4096 / 3072 / 2048 entries)
     bool fuse_combine = true;
     bool saturate = true;             // skip quadrants that can no longer change (GSR_SATURATE=0: composite every entry)
+    uint32_t long_tau_env = 0;        // GSR_LONG_TAU: the per-bin optical depth from which a bin is one work item (0: the built-in thresholds)
     int long_items = -1;              // -1: long work items where the frame's optical depth says so (LONG_TAU), 0 / 1: pinned (GSR_LONG_ITEMS)
     uint32_t blend_sub = 1;           // compositor waves per 16x16 tile: 1 (k_blend) or 2 (k_blend2); alloc_bins, GSR_BLEND_SUB
     int blend_sub_env = 0;
-    int spec = 0;                     // GSR_SPEC=1: dense frames as speculative segments (k_bin_finalize) instead of whole-bin work items
     uint32_t* bin_rects = nullptr;
     uint32_t* rect_tmp = nullptr;     // the rectangles between the two LSD passes (rect_carry)
     uint32_t* sort_chunk_tab = nullptr; // bucket order: k_local_sort's work list
@@ -144,6 +142,8 @@ struct gsr_ctx {
     gsr_allgather_fn comm_fn = nullptr;   // gsr_comm_init_custom: the caller's collective in place of ncclAllGather
     void* comm_fn_user = nullptr;
     bool comm_owned = true;               // false: communicator and exchange stream belong to another context (gsr_comm_share)
+    gsr_ctx* comm_leader = nullptr;       // that context; it lists this one in comm_followers and detaches it when it leaves the group first
+    std::vector<gsr_ctx*> comm_followers;
     int comm_rank = 0, comm_world = 0, slab_w = 0;
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_packed = nullptr, ev_slab_free = nullptr;
@@ -152,6 +152,7 @@ struct gsr_ctx {
     bool frame8_valid = false;
 
     CamParams cam{};
+    CamParams cam_frame{};            // the camera of the last rendered frame
     CamParams* cam_dev = nullptr;     // a camera slot in device memory (written by the one-time initialisation only)
     hipEvent_t link_ev[2] = {nullptr, nullptr};  // gsr_stream_order
     // the frame's launch chain replayed as a HIP graph (frames that carry no stage events)
@@ -184,7 +185,13 @@ int fail(gsr_ctx* c, int code, const char* fmt, ...)
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (c) c->error = buf;
+    if (c) {
+        c->error = buf;
+        // A chain that stopped half way (a failed launch behind k_project_key, a device error) leaves the frame slots and frame
+        // words as that frame had them -- partial min / max, counters -- and nothing would ever clean them: their last reader in a
+        // frame (the finalize step) did not run.  The next frame starts with the one-time initialisation again.
+        if (code == GSR_ERR_HIP) c->slots_need_init = true;
+    }
     else g_create_error = buf;
     return code;
 }
@@ -324,7 +331,6 @@ int alloc_bins(gsr_ctx* c)
         if (int r = dev_alloc(c, &c->seg_start, nbins + 1)) return r;
         if (c->fuse_combine) {
             if (int r = dev_alloc(c, &c->bin_mask, nbins)) return r;
-            if (int r = dev_alloc(c, &c->bin_sat, nbins)) return r;
         }
         c->bin_nbins_alloc = nbins;
         items_dirty = true;
@@ -367,9 +373,8 @@ int alloc_bins(gsr_ctx* c)
     // to SUB2_MAX_BINS bins, with segments of at least 1024 entries.  (Leaving the choice to k_bin_finalize per frame --
     // both kernels launched, the other one returning at once -- cost 4.5 us per frame for the idle launch.)
     c->blend_sub = c->blend_sub_env ? (uint32_t)c->blend_sub_env : (!throughput && nbins <= SUB2_MAX_BINS) ? 2u : 1u;
-    if (c->quad_from) c->blend_sub = 1;   // (tile items give every wave one quadrant: one wave per tile only)
-    if (c->blend_sub == 2 && c->seg_len != SEG_LEN_WHOLE_BIN) c->seg_len = SEG_LEN_MIN_SUB2;
-    c->blend_grid = (c->blend_sub == 2 ? BLEND_WG_PER_CU_SUB2 : throughput ? BLEND_WG_PER_CU_THROUGHPUT : BLEND_WG_PER_CU_EXACT) * (uint32_t)std::max(c->cu_count, 1);
+    if (c->blend_sub >= 2 && c->seg_len != SEG_LEN_WHOLE_BIN) c->seg_len = SEG_LEN_MIN_SUB2;
+    c->blend_grid = (c->blend_sub >= 2 ? BLEND_WG_PER_CU_SUB2 : throughput ? BLEND_WG_PER_CU_THROUGHPUT : BLEND_WG_PER_CU_EXACT) * (uint32_t)std::max(c->cu_count, 1);
     if (const char* e = getenv("GSR_SEG_TARGET")) {  // tuning knob: full segments a frame is cut into at least
         const long v = atol(e);
         if (v >= 1) c->seg_target_items = (uint32_t)v;
@@ -382,10 +387,9 @@ int alloc_bins(gsr_ctx* c)
         const long v = atol(e);
         if (v >= 256 && c->seg_len != SEG_LEN_WHOLE_BIN) c->seg_len = (uint32_t)(v / 256 * 256);
     }
-    // segments (each may need a partial slot): one per bin plus one per seg_len entries; work items: a heavy single-segment
-    // bin is handed out as four (ITEM_TILE0), so up to three more per bin
+    // segments = work items (each may need a partial slot): one per bin plus one per seg_len entries
     const uint32_t want_segs = nbins + c->bin_capacity / c->seg_len + 16;
-    const uint32_t want_items = want_segs + 3u * nbins;
+    const uint32_t want_items = want_segs;
     if (items_dirty || want_items > c->max_items) {
         c->max_items = want_items;
         if (int r = dev_alloc(c, &c->items, c->max_items)) return r;
@@ -422,7 +426,8 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
     if (c->n) {
         SceneSoA sc{c->px, c->py, c->pz, c->cov0, c->cov1, c->cov2, c->rgba, c->sh_r, c->sh_g, c->sh_b, c->shcol};
         if (render) {
-            c->proj = ProjectLaunch{sc, c->n, c->cam, 1, c->depth, c->slots, c->rec, c->bbox, c->rect_idx, &c->fstate->overflow, {}};
+            c->proj = ProjectLaunch{sc, c->n, c->cam, 1, c->depth, c->slots, c->rec, nullptr, c->rect_idx, &c->fstate->overflow, {}};
+            c->cam_frame = c->cam;   // (gsr_read_records projects once more for this camera to get the pixel boxes)
             launch_project_key(c->proj, s);
         }
         else {   // a sort-only frame: its own slots (sets 1 and 2 in turn; set 0 belongs to the render frames and k_begin_frame)
@@ -454,18 +459,17 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
         }
         BinBuffers bb{c->depth_index, &c->fstate->sorted_count, c->bin_table, c->slots, c->rect_idx, c->bin_rects, (c->n && c->rects_sorted_now) ? 1u : 0u, c->bin_total, c->bin_start, c->bin_start_pre, c->bin_rounds, c->bin_big, c->seg_start,
                       c->items, c->bin_list, &c->fstate->overflow, &c->fstate->visible, &c->fstate->tile_entries,
-                      c->accum, c->mailbox_dev, c->fstate->report, c->bin_capacity, c->max_items, c->seg_len, &c->fstate->seg_len, c->items_by_size, &c->fstate->queue, std::min<uint32_t>(c->max_items, c->blend_grid), c->seg_target_items, c->bin_blocks, c->bin_mask, c->bin_sat,
+                      c->accum, c->mailbox_dev, c->fstate->report, c->bin_capacity, c->max_items, c->seg_len, &c->fstate->seg_len, c->items_by_size, &c->fstate->queue, std::min<uint32_t>(c->max_items, c->blend_grid), c->seg_target_items, c->bin_blocks, c->bin_mask,
                       c->seg_len == SEG_LEN_WHOLE_BIN ? 0 : c->long_items >= 0 ? c->long_items : c->saturate ? -1 : 0, SEG_LEN_LONG,
-                      (c->opt.flags & GSR_FLAG_THROUGHPUT) ? LONG_TAU_THROUGHPUT : LONG_TAU_EXACT,
-                      (uint32_t)((g.bx_hi - g.bx_lo) * BIN_PX) * (uint32_t)c->H, c->quad_from,
+                      c->long_tau_env ? c->long_tau_env : (c->opt.flags & GSR_FLAG_THROUGHPUT) ? LONG_TAU_THROUGHPUT : LONG_TAU_EXACT,
+                      (uint32_t)((g.bx_hi - g.bx_lo) * BIN_PX) * (uint32_t)c->H,
                       (c->opt.flags & GSR_FLAG_THROUGHPUT) ? LONG_TILES_X2_THROUGHPUT : LONG_TILES_X2_EXACT,
-                      c->bin_two_level ? 1u : 0u, c->cell_list, c->cell_total, c->cell_start, c->chunk_start, c->chunk_info, c->cell_wcnt, c->cell_table2, c->cell_grid,
-                      (uint32_t)c->spec};
+                      c->bin_two_level ? 1u : 0u, c->cell_list, c->cell_total, c->cell_start, c->chunk_start, c->chunk_info, c->cell_wcnt, c->cell_table2, c->cell_grid};
         launch_bin(bb, g, c->n, s);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BIN], s));
         BlendBuffers bl{c->items, c->seg_start, c->bin_start, c->bin_list, c->rec, c->bbox, c->shcol, c->fb, c->partial,
                         &c->fstate->queue, c->seg_len, &c->fstate->seg_len, std::min<uint32_t>(c->max_items, c->blend_grid), c->bin_capacity,
-                        std::max(c->n, 1u), c->bin_mask, c->bin_sat, c->saturate ? 1u : 0u, c->blend_sub};
+                        std::max(c->n, 1u), c->bin_mask, c->saturate ? 1u : 0u, c->blend_sub};
         launch_blend(bl, g, c->opt.early_out_eps, s, (timing && !c->bin_mask) ? c->ev[EV_BLEND] : nullptr);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_COMBINE], s));
     }
@@ -491,12 +495,12 @@ static std::vector<uint64_t> chain_signature(const gsr_ctx* c)
     auto U = [&v](uint64_t x) { v.push_back(x); };
     P(c->px); P(c->py); P(c->pz); P(c->cov0); P(c->cov1); P(c->cov2); P(c->rgba); P(c->sh_r); P(c->sh_g); P(c->sh_b); P(c->shcol);
     P(c->depth); P(c->keys); P(c->keys_tmp); P(c->idx_tmp); P(c->depth_index); P(c->block_hist); P(c->fstate);
-    P(c->rec); P(c->bbox); P(c->slots); P(c->rect_idx); P(c->bin_table); P(c->bin_rects); P(c->bin_total); P(c->bin_start); P(c->seg_start); P(c->bin_mask); P(c->bin_sat);
+    P(c->rec); P(c->bbox); P(c->slots); P(c->rect_idx); P(c->bin_table); P(c->bin_rects); P(c->bin_total); P(c->bin_start); P(c->seg_start); P(c->bin_mask);
     P(c->items); P(c->bin_list); P(c->partial); P(c->fb); P(c->accum); P(c->cam_dev);
     U(c->n); U((uint64_t)c->W); U((uint64_t)c->H); U((uint64_t)g.bx_lo); U((uint64_t)g.bx_hi); U(c->sort_kpb); U(c->sort_blocks);
     U(c->bin_capacity); U(c->max_items); U(c->seg_len); U(c->seg_target_items); U(c->blend_grid); U(c->bin_blocks); U(c->bin_rounds); U(c->bin_big); P(c->bin_start_pre);
-    U((uint64_t)c->opt.flags); U((uint64_t)(c->opt.early_out_eps * 1e9f)); U(c->bucket_order_now ? 1u : 0u); U(c->saturate ? 1u : 0u); U((uint64_t)c->items_by_size); U(c->quad_from); U((uint64_t)(int64_t)c->long_items);
-    U((uint64_t)c->spec); U(c->blend_sub);
+    U((uint64_t)c->opt.flags); U((uint64_t)(c->opt.early_out_eps * 1e9f)); U(c->bucket_order_now ? 1u : 0u); U(c->saturate ? 1u : 0u); U((uint64_t)c->items_by_size); U((uint64_t)(int64_t)c->long_items); U(c->long_tau_env);
+    U(c->blend_sub);
     U(c->bin_two_level ? 1u : 0u); P(c->cell_list); P(c->cell_total); P(c->cell_start); P(c->chunk_start); P(c->chunk_info); P(c->cell_wcnt); P(c->cell_table2); U(c->cell_grid); P(c->rect_tmp); P(c->sort_chunk_tab); U(c->rect_carry ? (c->rect_carry_bucket ? 1u : 2u) : 0u);
     return v;
 }
@@ -600,7 +604,7 @@ int enqueue_frame(gsr_ctx* c, bool render)
             c->graph_fresh = false;
         }
         if (c->graph_exec) {
-            HIP_TRY(c, hipGraphLaunch(c->graph_exec, s));
+            HIP_TRY(c, hipGraphLaunch(c->graph_exec, s));   // (a failure marks the frame slots for re-initialisation: fail())
             c->sort_culled = band_is_partial(c);
             replayed = true;
         }
@@ -726,10 +730,29 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
         if (e_ != hipSuccess) { fail(c, GSR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); return bail(GSR_ERR_HIP); } \
     } while (0)
     CREATE_TRY(hipSetDevice(c->device));
-    CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    {
+        // Experiment knob (frames in flight): GSR_CU_PARTS=k gives the process's contexts, in turn, one of k
+        // disjoint sets of compute units (hipExtStreamCreateWithCUMask; mask bits are dealt round-robin over the XCDs, so a
+        // contiguous range of bits is an equal share of every XCD): frames in flight then run side by side instead of taking
+        // turns on the whole chip.  Off by default (measured: profiles/r04_experiments.txt).
+        static int next_part = 0;
+        const char* e = getenv("GSR_CU_PARTS");
+        const int parts = e ? atoi(e) : 0;
+        int cus = 0;
+        if (parts >= 2 && parts <= 16 && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus >= parts) {
+            const int part = next_part++ % parts, per = cus / parts;
+            std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
+            for (int k = part * per; k < (part + 1) * per; k++) mask[(size_t)k / 32] |= 1u << (k % 32);
+            CREATE_TRY(hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data()));
+            c->cu_part = per;   // (the compositor's persistent grid is sized for the CUs the stream may use)
+        } else {
+            CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        }
+    }
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0) c->cu_count = cus;
+        if (c->cu_part) c->cu_count = c->cu_part;
     }
     CREATE_TRY(hipMalloc((void**)&c->fstate, sizeof(FrameState)));
     CREATE_TRY(hipMalloc((void**)&c->cam_dev, sizeof(CamParams)));
@@ -741,14 +764,13 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
     if (const char* e = getenv("GSR_SATURATE")) c->saturate = atoi(e) != 0;           // A/B knob: 0 = no saturation skip
     c->items_by_size = (o.flags & GSR_FLAG_THROUGHPUT) ? 0 : 1;
     if (const char* e = getenv("GSR_ITEMS_BY_SIZE")) c->items_by_size = atoi(e) != 0 ? 1 : 0;
-    if (const char* e = getenv("GSR_QUAD_FROM")) c->quad_from = (uint32_t)std::max(0L, atol(e));
     if (const char* e = getenv("GSR_LONG_ITEMS")) c->long_items = atoi(e) != 0 ? 1 : 0; // pins the work-item length policy
-    if (const char* e = getenv("GSR_SPEC")) c->spec = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("GSR_LONG_TAU")) c->long_tau_env = (uint32_t)std::max(0L, atol(e));
     if (const char* e = getenv("GSR_BIN_ROUNDS")) c->bin_rounds_env = std::min(64L, std::max(0L, atol(e)));
     if (const char* e = getenv("GSR_BIN_BIG")) c->bin_big = (uint32_t)std::min(2, std::max(0, atoi(e)));
     if (const char* e = getenv("GSR_BIN_TWO_LEVEL")) c->bin_two_level_env = atoi(e) ? 1 : 0;
     if (const char* e = getenv("GSR_RECT_CARRY")) { c->rect_carry = atoi(e) != 0; c->rect_carry_bucket = atoi(e) == 2; }
-    if (const char* e = getenv("GSR_BLEND_SUB")) c->blend_sub_env = atoi(e) == 2 ? 2 : atoi(e) == 1 ? 1 : 0;
+    if (const char* e = getenv("GSR_BLEND_SUB")) c->blend_sub_env = atoi(e) >= 1 && atoi(e) <= 3 ? atoi(e) : 0;   // (3: the first form of the two-waves-per-tile kernel, for A/B)
     CREATE_TRY(hipMalloc((void**)&c->accum, 8 * sizeof(uint64_t)));
     CREATE_TRY(hipMemset(c->accum, 0, 8 * sizeof(uint64_t)));
     CREATE_TRY(hipHostMalloc((void**)&c->mailbox, 64, hipHostMallocMapped));
@@ -794,7 +816,7 @@ int gsr_destroy(gsr_ctx* c)
     dev_free(&c->block_hist); dev_free(&c->rec); dev_free(&c->bbox); dev_free(&c->slots); dev_free(&c->rect_idx);
     dev_free(&c->bin_table); dev_free(&c->bin_total); dev_free(&c->bin_start); dev_free(&c->bin_start_pre); dev_free(&c->bin_list);
     dev_free(&c->cell_list); dev_free(&c->cell_total); dev_free(&c->cell_start); dev_free(&c->chunk_start); dev_free(&c->chunk_info); dev_free(&c->cell_wcnt); dev_free(&c->cell_table2);
-    dev_free(&c->seg_start); dev_free(&c->bin_mask); dev_free(&c->bin_sat); dev_free(&c->items); dev_free(&c->partial); dev_free(&c->bin_rects); dev_free(&c->rect_tmp); dev_free(&c->sort_chunk_tab);
+    dev_free(&c->seg_start); dev_free(&c->bin_mask); dev_free(&c->items); dev_free(&c->partial); dev_free(&c->bin_rects); dev_free(&c->rect_tmp); dev_free(&c->sort_chunk_tab);
     drop_graph(c);
     dev_free(&c->cam_dev);
     dev_free(&c->fstate); dev_free(&c->accum); dev_free(&c->fb); dev_free(&c->fb8);
@@ -825,7 +847,7 @@ int alloc_scene(gsr_ctx* c, uint32_t n, bool with_rows)
         (r = dev_alloc(c, &c->cov0, n)) || (r = dev_alloc(c, &c->cov1, n)) || (r = dev_alloc(c, &c->cov2, n)) ||
         (r = dev_alloc(c, &c->rgba, n)) || (r = dev_alloc(c, &c->depth, n)) || (r = dev_alloc(c, &c->keys, n)) ||
         (r = dev_alloc(c, &c->keys_tmp, n)) || (r = dev_alloc(c, &c->idx_tmp, n)) ||
-        (r = dev_alloc(c, &c->depth_index, n)) || (r = dev_alloc(c, &c->rec, n)) || (r = dev_alloc(c, &c->bbox, n)) ||
+        (r = dev_alloc(c, &c->depth_index, n)) || (r = dev_alloc(c, &c->rec, n)) ||
         (r = dev_alloc(c, &c->bin_rects, n)) || (r = dev_alloc(c, &c->rect_idx, n)) || (r = dev_alloc(c, &c->rect_tmp, n)) ||
         (r = dev_alloc(c, &c->sort_chunk_tab, 4 * ((size_t)n / 4096 + 260))))
         return r;
@@ -1278,8 +1300,19 @@ int gsr_read_records(gsr_ctx* c, float* rec, int32_t* bbox)
     if (rec) HIP_TRY(c, hipMemcpyAsync(rec, c->rec, (size_t)c->n * 32, hipMemcpyDeviceToHost, c->stream));
     std::vector<uint2> tmp;
     if (bbox) {
+        // the pixel boxes are not part of a frame (no kernel reads them): project once more for the frame's camera, records and
+        // boxes only (k_project_key, do_project == 2: the same arithmetic, so the same records)
         tmp.resize(c->n);
-        HIP_TRY(c, hipMemcpyAsync(tmp.data(), c->bbox, (size_t)c->n * 8, hipMemcpyDeviceToHost, c->stream));
+        if (c->n) {
+            if (int r = dev_alloc(c, &c->bbox, c->n)) return r;
+            SceneSoA sc{c->px, c->py, c->pz, c->cov0, c->cov1, c->cov2, c->rgba, c->sh_r, c->sh_g, c->sh_b, c->shcol};
+            ProjectLaunch again{sc, c->n, c->cam_frame, 2, c->depth, c->slots, c->rec, c->bbox, c->rect_idx, &c->fstate->overflow, {}};
+            launch_project_key(again, c->stream);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipMemcpyAsync(tmp.data(), c->bbox, (size_t)c->n * 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            dev_free(&c->bbox);
+        }
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (bbox)
@@ -1312,7 +1345,7 @@ int gsr_read_work_items(gsr_ctx* c, uint32_t* out)
     HIP_TRY(c, hipMemcpyAsync(out, &c->fstate->seg_len, 12, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const BinGrid g = make_grid(c);
-    out[3] = c->blend_sub;
+    out[3] = std::min(c->blend_sub, 2u);
     out[4] = (uint32_t)((g.bx_hi - g.bx_lo) * g.nby);
     return GSR_OK;
 }
@@ -1471,6 +1504,15 @@ RcclApi& rccl()
 
 void comm_release(gsr_ctx* c)
 {
+    // A leader that leaves the group (or is destroyed) before the contexts that borrowed its communicator and exchange stream:
+    // they are detached first, while both still exist -- afterwards they are plain contexts that have to join again, instead of
+    // holders of a destroyed stream (a garbage-collected host destroys contexts in any order).
+    while (!c->comm_followers.empty()) comm_release(c->comm_followers.back());
+    if (c->comm_leader) {
+        auto& fl = c->comm_leader->comm_followers;
+        fl.erase(std::remove(fl.begin(), fl.end(), c), fl.end());
+        c->comm_leader = nullptr;
+    }
     if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
     if (c->comm && c->comm_owned && rccl().ok) (void)rccl().CommDestroy(c->comm);
     c->comm = nullptr;
@@ -1523,10 +1565,12 @@ static int comm_setup(gsr_ctx* c, const char* who, int32_t rank, int32_t world, 
     if (int r = gsr_set_band(c, world == 1 ? 0 : x0[rank], world == 1 ? 0 : x1[rank])) return r;
     c->slab_w = sw;
     for (int q = 0; q < world; q++) { c->comm_edges.x0[q] = x0[q]; c->comm_edges.x1[q] = x1[q]; }
-    const size_t slab_px = (size_t)sw * c->H;
+    // (a slab = the band's pixels + SLAB_FLAG_WORDS words "this band was not composited"; the assembled frame is followed by
+    //  the word that collects those flags: k_pack_band_rgba8 / k_unpack_slabs_rgba8)
+    const size_t slab_px = (size_t)sw * c->H + SLAB_FLAG_WORDS;
     int r;
     if ((r = dev_alloc(c, &c->slab, slab_px)) || (r = dev_alloc(c, &c->gathered, slab_px * world)) ||
-        (r = dev_alloc(c, &c->frame8, (size_t)c->W * c->H)))
+        (r = dev_alloc(c, &c->frame8, (size_t)c->W * c->H + SLAB_FLAG_WORDS)))
         return r;
     HIP_TRY(c, hipMemsetAsync(c->slab, 0, slab_px * 4, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1565,6 +1609,8 @@ int gsr_comm_share(gsr_ctx* c, gsr_ctx* leader)
     if (int r = comm_setup(c, "gsr_comm_share", leader->comm_rank, leader->comm_world, leader->comm_edges.x0, leader->comm_edges.x1, leader->comm_stream))
         return r;
     c->comm = leader->comm; c->comm_fn = leader->comm_fn; c->comm_fn_user = leader->comm_fn_user;
+    c->comm_leader = leader;
+    leader->comm_followers.push_back(c);
     return GSR_OK;
 }
 
@@ -1598,18 +1644,22 @@ int gsr_allgather_frame_async(gsr_ctx* c)
     const int x0 = g.bx_lo * BIN_PX, x1 = std::min(g.bx_hi * BIN_PX, c->W);
     // render stream: the previous all-gather must have read the slab before it is overwritten; then pack the band
     if (c->frame8_valid) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_slab_free, 0));
-    launch_pack_band_rgba8(c->fb, c->slab, c->W, c->H, x0, x1, c->slab_w, c->stream);
+    // (the pack also records, behind the pixels, whether the frame it packs was composited at all: the frame's overflow word,
+    //  which the next frame's projection resets -- stream order puts this read in front of it)
+    launch_pack_band_rgba8(c->fb, c->slab, c->W, c->H, x0, x1, c->slab_w, c->stream, &c->fstate->overflow);
     HIP_TRY(c, hipEventRecord(c->ev_packed, c->stream));
     // exchange stream: collective + de-slab, overlapping the next frame's kernels on the render stream
     HIP_TRY(c, hipStreamWaitEvent(c->comm_stream, c->ev_packed, 0));
+    const size_t slab_bytes = ((size_t)c->slab_w * c->H + SLAB_FLAG_WORDS) * 4;
     if (c->comm_fn) {
-        if (const int r = c->comm_fn(c->comm_fn_user, c->slab, c->gathered, (uint64_t)c->slab_w * c->H * 4, (void*)c->comm_stream))
+        if (const int r = c->comm_fn(c->comm_fn_user, c->slab, c->gathered, (uint64_t)slab_bytes, (void*)c->comm_stream))
             return fail(c, GSR_ERR_COMM, "the custom all-gather returned %d", r);
     } else {
-        RCCL_TRY(c, rccl().AllGather(c->slab, c->gathered, (size_t)c->slab_w * c->H * 4, ncclUint8, c->comm, c->comm_stream));
+        RCCL_TRY(c, rccl().AllGather(c->slab, c->gathered, slab_bytes, ncclUint8, c->comm, c->comm_stream));
     }
     HIP_TRY(c, hipEventRecord(c->ev_slab_free, c->comm_stream));
-    launch_unpack_slabs_rgba8(c->gathered, c->frame8, c->W, c->H, c->slab_w, c->comm_world, c->comm_edges, c->comm_stream);
+    launch_unpack_slabs_rgba8(c->gathered, c->frame8, c->W, c->H, c->slab_w, c->comm_world, c->comm_edges, c->comm_stream,
+                              c->frame8 + (size_t)c->W * c->H);
     HIP_TRY(c, hipGetLastError());
     c->frame8_valid = true;
     return GSR_OK;
@@ -1620,21 +1670,25 @@ int gsr_read_frame_rgba8(gsr_ctx* c, uint8_t* out)
     if (!c || !out) return c ? fail(c, GSR_ERR_ARG, "out is NULL") : GSR_ERR_ARG;
     if (!c->frame8_valid) return fail(c, GSR_ERR_ARG, "gsr_read_frame_rgba8: no gathered frame yet (gsr_allgather_frame_async)");
     HIP_TRY(c, hipSetDevice(c->device));
-    // The band of the gathered frame was packed right behind a frame that the host had only enqueued: if that frame's lists did
-    // not fit, the compositor drew nothing and the band is the preceding image.  The device has said so by now: wait for
-    // the render stream, and if an overflow is pending (or frames were dropped and not reported yet) repair the context and
-    // refuse the frame instead of handing out a stale band.
+    // A band of the gathered frame may have been packed right behind a frame whose bin lists did not fit: that frame was not
+    // composited and the band is the preceding image.  WHICH gathered frame that concerns is decided on the device and seen by
+    // the whole group: every slab carries its frame's overflow flag through the all-gather and the de-slab kernel collects the
+    // flags of all ranks behind the assembled frame.  So every rank refuses exactly the same frame (GSR_ERR_OVERFLOW) and the
+    // group renders and gathers it again together -- no rank repeats a collective alone -- while frames dropped earlier and
+    // not reported yet (gsr_sync's business) do not make a good frame unreadable.  The rank that overflowed regrows its lists
+    // here, so that the repeated frame fits.
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (overflow_pending(c) || c->dropped_unreported) {
-        if (int r = sync_and_repair(c)) return r;
-        HIP_TRY(c, hipStreamSynchronize(c->comm_stream));
-        c->dropped_unreported = 0;
-        c->frame8_valid = false;
-        return fail(c, GSR_ERR_OVERFLOW, "the gathered frame holds a band that was not composited (its bin lists did not fit); the lists "
-                                         "have been regrown: render and gather the frame again");
-    }
+    if (overflow_pending(c)) { if (int r = sync_and_repair(c)) return r; }
+    uint32_t stale = 0;
     HIP_TRY(c, hipMemcpyAsync(out, c->frame8, (size_t)c->W * c->H * 4, hipMemcpyDeviceToHost, c->comm_stream));
+    HIP_TRY(c, hipMemcpyAsync(&stale, c->frame8 + (size_t)c->W * c->H, 4, hipMemcpyDeviceToHost, c->comm_stream));
     HIP_TRY(c, hipStreamSynchronize(c->comm_stream));
+    if (stale) {
+        c->frame8_valid = false;
+        return fail(c, GSR_ERR_OVERFLOW, "the gathered frame holds a band that was not composited (the bin lists of rank mask 0x%x did not fit; "
+                                         "they have been regrown there): every rank of the group gets this error for this frame and all of them "
+                                         "render and gather it again", stale);
+    }
     return GSR_OK;
 }
 
@@ -1676,20 +1730,33 @@ void gsplat_sort_host(const float* viewProj, uint32_t vertexCount, const float* 
         c->n = vertexCount;
     }
     c->have_sort = false; c->have_frame = false;
+    // What the call keeps between calls is memory of its own, never the caller's data: the device staging buffer for the
+    // xyz-interleaved positions lives in the process-wide context and grows with the largest scene seen (round 3 allocated and
+    // freed it on every call: two driver round trips of ~0.1 ms each beside a 45 us sort).  The chain of a call: pageable H2D of
+    // 12 N bytes -> repack to the SoA the key kernel reads -> key + min/max -> quantise + 17-bit radix sort -> D2H of 4 N bytes
+    // (+ 4 N for the keys on request), all on the context's stream, one host wait at the end.
+    static float* stage_pos = nullptr;      // (guarded by mu, like ctx)
+    static size_t stage_cap = 0;
     if (vertexCount) {
-        float* d_pos = nullptr;
-        if (dev_alloc(c, &d_pos, (size_t)vertexCount * 3) != GSR_OK) return failed(gsr_last_error(c));
-        hipError_t e1 = hipMemcpyAsync(d_pos, fBuffer, (size_t)vertexCount * 12, hipMemcpyHostToDevice, c->stream);
-        launch_repack_positions(d_pos, vertexCount, c->px, c->py, c->pz, c->stream);
-        hipError_t e2 = hipStreamSynchronize(c->stream);
-        dev_free(&d_pos);
-        for (hipError_t e : {e1, e2, hipGetLastError()})
+        if ((size_t)vertexCount * 3 > stage_cap) {
+            if (dev_alloc(c, &stage_pos, (size_t)vertexCount * 3) != GSR_OK) { stage_cap = 0; return failed(gsr_last_error(c)); }
+            stage_cap = (size_t)vertexCount * 3;
+        }
+        hipError_t e1 = hipMemcpyAsync(stage_pos, fBuffer, (size_t)vertexCount * 12, hipMemcpyHostToDevice, c->stream);
+        launch_repack_positions(stage_pos, vertexCount, c->px, c->py, c->pz, c->stream);
+        for (hipError_t e : {e1, hipGetLastError()})
             if (e != hipSuccess) return failed(hipGetErrorString(e));
     }
     float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-    if (gsr_set_camera(c, ident, ident, viewProj, 1.f, 1.f) != GSR_OK || gsr_sort(c) != GSR_OK ||
-        gsr_read_depth_index(c, depthIndex) != GSR_OK || (depthBuffer && gsr_read_keys(c, depthBuffer, nullptr) != GSR_OK))
-        return failed(gsr_last_error(c));
+    if (gsr_set_camera(c, ident, ident, viewProj, 1.f, 1.f) != GSR_OK) return failed(gsr_last_error(c));
+    if (hipSetDevice(c->device) != hipSuccess || enqueue_frame(c, false) != GSR_OK) return failed(gsr_last_error(c));
+    if (vertexCount) {
+        hipError_t e1 = hipMemcpyAsync(depthIndex, c->depth_index, (size_t)vertexCount * 4, hipMemcpyDeviceToHost, c->stream);
+        hipError_t e2 = depthBuffer ? hipMemcpyAsync(depthBuffer, c->keys, (size_t)vertexCount * 4, hipMemcpyDeviceToHost, c->stream) : hipSuccess;
+        for (hipError_t e : {e1, e2})
+            if (e != hipSuccess) return failed(hipGetErrorString(e));
+    }
+    if (finish_frame(c) != GSR_OK) return failed(gsr_last_error(c));
 }
 
 // Identifies the device code this library was built from (a hash of the kernel sources, set by the Makefile):

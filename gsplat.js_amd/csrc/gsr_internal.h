@@ -127,9 +127,7 @@ __device__ __forceinline__ uint32_t xcd_group_remap(uint32_t bid, uint32_t nwg)
 #define GSR_BOUND(name, site, idx, limit) do { } while (0)
 #endif
 
-// Compositor work items: bin | segment << 16.  Segment codes from ITEM_TILE0 on mean "the whole (single-segment) bin, but
-// only its 16x16 tile code - ITEM_TILE0": a heavy bin handed to four workgroups, one 8x8 quadrant per wave (k_blend).
-constexpr uint32_t ITEM_TILE0 = 0xfff0u;
+// Compositor work items: bin | segment << 16.
 constexpr uint32_t PROJ_THREADS = 256;
 constexpr int FRAME_SLOTS = 64;
 constexpr int FRAME_SLOT_WORDS = 32;   // words per slot (one 128-byte line): [0] min depth, [1] max depth, [2] visible, [3] tiles,
@@ -139,10 +137,10 @@ void launch_depth_key(const SceneSoA& sc, uint32_t n, const CamParams& cam, int3
 // The projection kernel's launch as a value: its arguments and the pointer array hipLaunchKernel / a graph kernel node take.
 // (One struct for both, so that the graph replay rewrites exactly what a direct launch passes: the camera.)
 struct ProjectLaunch {
-    SceneSoA sc; uint32_t n; CamParams cam; int do_project;   // do_project: 1 = project (render frames)
+    SceneSoA sc; uint32_t n; CamParams cam; int do_project;   // do_project: 1 = project (render frames), 2 = records and pixel boxes only (read-back)
     int32_t* depth;
     int32_t* slots;      // FRAME_SLOTS * FRAME_SLOT_WORDS, clean at the start of the frame (the finalize step resets them)
-    Record* rec; uint2* bbox;
+    Record* rec; uint2* bbox;   // bbox may be null (frames: nothing on the path reads the pixel boxes)
     uint32_t* rect;      // n: packed bin rectangle per splat
     uint32_t* overflow;  // the frame's overflow word, zeroed by the kernel
     void* ptrs[10];
@@ -212,18 +210,16 @@ struct BinBuffers {
     uint32_t max_items;
     uint32_t seg_len;            // minimum list entries per compositor work item (multiple of 256); k_bin_finalize
                                  // raises it for long lists and publishes the frame's value in *seg_len_dev
-    uint32_t* seg_len_dev;       // [0] the frame's segment length, [1] its number of work items, [2] 1 = speculative segments
+    uint32_t* seg_len_dev;       // [0] the frame's segment length, [1] its number of work items, [2] reserved (0)
     int32_t items_by_size;       // order the bins' last segments by size class (one frame at a time) or leave them in raster order
     uint32_t* queue;             // the compositor's work-item counter, set to queue_start (= its grid size) by k_bin_finalize
     uint32_t queue_start;
     uint32_t seg_target_items;   // full segments the frame should be cut into at least (long lists -> longer segments)
     uint32_t nblocks;
     unsigned long long* bin_mask; // nbins: the compositor's per-bin arrival masks (one bit per segment), zeroed by the finalize step (may be null)
-    uint32_t* bin_sat;           // nbins: segments in front of which the bin is known to be saturated (0xffffffff: not known), with bin_mask
     int32_t long_policy;         // work items of at least seg_len_long entries: 1 always, 0 never, -1 where the frame's optical depth >= long_tau
     uint32_t seg_len_long, long_tau;
     uint32_t npix;               // pixels of this context's band (the optical depth is per pixel)
-    uint32_t quad_from;          // single-item bins with at least this many entries become four work items, one per 16x16 tile (0: never)
     uint32_t long_tiles_x2;      // long work items also need this many 16x16 tiles per visible splat, times two (0: no such condition)
     // two-level binning (launch_bin; large bin grids): cells of 4 x 4 bins first, then the cell lists' chunks into the bins
     uint32_t two_level;          // 1: on (nblocks = workgroups of 2048 ranks, rounds = 1; table holds nblocks x (cells + 1) words)
@@ -235,8 +231,6 @@ struct BinBuffers {
     uint32_t* cell_wcnt;         // (capacity / 2048 + cells) x 64 words: per chunk, bin and wave of k_cell_scatter2 one byte: the wave's entries
     uint32_t* cell_table2;       // (capacity / 2048 + cells) x 16: per chunk and bin of its cell: entries, then their first slot
     uint32_t cell_grid;          // workgroups of the level-two kernels (they stride over the frame's chunks)
-    uint32_t spec;               // dense frames (long_policy): 1 = speculative segments -- the plain cut, handed out layer by layer, segments
-                                 // behind a saturated prefix skipped (needs bin_mask) --, 0 = whole-bin work items of seg_len_long entries
 };
 void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s);
 
@@ -252,12 +246,12 @@ struct BlendBuffers {
     float4* partial;            // max_items * 1024 float4: per-segment (colour, transmittance), slot = seg_start[bin] + segment
     uint32_t* queue;            // device-wide work-item counter, zero at frame start
     uint32_t seg_len;           // host's minimum; >= 0x40000000: one item per bin (early termination mode)
-    const uint32_t* seg_len_dev; // [0] the frame's segment length, [1] its number of work items, [2] 1 = speculative segments (k_bin_finalize)
+    const uint32_t* seg_len_dev; // [0] the frame's segment length, [1] its number of work items (k_bin_finalize)
     uint32_t grid;              // persistent workgroups launched
     uint32_t capacity;          // entries the list can hold
     uint32_t nsplats;
     unsigned long long* bin_mask; // nbins arrival masks, zeroed by the finalize step: the workgroup delivering a bin's last
-    uint32_t* bin_sat;          // segment folds the bin inside k_blend; null = the separate k_combine launch does it.  bin_sat: see BinBuffers
+                                // segment folds the bin inside k_blend; null = the separate k_combine launch does it
     uint32_t saturate;          // 1: quadrants whose pixels can no longer change are skipped (bit-identical; k_blend); 0: A/B knob
     uint32_t sub;               // waves per 16x16 tile: 1 (k_blend, 256-thread workgroups) or 2 (k_blend2: halves a wave's serial walk)
 };
@@ -269,8 +263,10 @@ void launch_to_rgba8(const float4* fb, uint32_t* out, uint32_t npix, hipStream_t
 // multi-GPU exchange helpers (RGBA8 slabs of the all-gather)
 constexpr int MAX_SLABS = 16;
 struct SlabEdges { int32_t x0[MAX_SLABS], x1[MAX_SLABS]; };
-void launch_pack_band_rgba8(const float4* fb, uint32_t* slab, int W, int H, int x0, int x1, int slab_w, hipStream_t s);
+// (the library's own slabs carry SLAB_FLAG_WORDS words behind their H x slab_w pixels: "this band was not composited")
+constexpr int SLAB_FLAG_WORDS = 4;   // one flag, padded to 16 bytes
+void launch_pack_band_rgba8(const float4* fb, uint32_t* slab, int W, int H, int x0, int x1, int slab_w, hipStream_t s, const uint32_t* overflow = nullptr);
 void launch_unpack_slabs_rgba8(const uint32_t* gathered, uint32_t* image, int W, int H, int slab_w, int world,
-                               const SlabEdges& e, hipStream_t s);
+                               const SlabEdges& e, hipStream_t s, uint32_t* stale = nullptr);
 
 }  // namespace gsr

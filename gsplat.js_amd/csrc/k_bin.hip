@@ -220,13 +220,12 @@ struct FinalizeArgs {
     uint64_t *visible, *tile_entries, *accum, *report;
     uint32_t* queue; uint32_t queue_start;
     uint64_t* mailbox;
-    unsigned long long* bin_mask; uint32_t* bin_sat;
+    unsigned long long* bin_mask;
     int long_policy; uint32_t seg_len_long, long_tau, npix;   // see BinBuffers
-    uint32_t quad_from, long_tiles_x2;
-    uint32_t spec;   // dense frames: 1 = speculative segments, 0 = whole-bin work items; see BinBuffers
+    uint32_t long_tiles_x2;
 };
 constexpr int FIN_LAYERS = 64;   // segments per bin at most (one bit each in the bin's arrival mask, k_blend)
-constexpr int FIN_SCRATCH_WORDS = FIN_LAYERS * 64;   // LDS words the finalize step needs from its caller: (layer, size class) counters
+constexpr int FIN_SCRATCH_WORDS = 64;   // LDS words the finalize step asks of its caller (none are used any more; kept so that every launch passes a non-zero size)
 
 // One workgroup of FIN_THREADS threads.  It runs as an EXTRA workgroup of k_bin_scatter (the scatter workgroups
 // compute the bin starts they need themselves), so its ~9 us no longer sit between the column scan and the scatter;
@@ -275,50 +274,50 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa, uint32
     // 1.6 M splats: tau 394, 3.6 tiles per splat, long items 8 % slower; C3: 5.3 tiles per splat, 23 % faster)
     const bool dense = optical * (16u * 256u) >= (uint64_t)fa.long_tau * 255u * (uint64_t)fa.npix &&
                        (uint64_t)ctot.v[1] * 2u >= (uint64_t)fa.long_tiles_x2 * ctot.v[0];
-    // How a dense frame is cut (gsr_api.cpp, "Work-item length"):
-    //  * speculative segments (fa.spec, needs the arrival masks): the SAME cut as a frame that does not saturate -- plain
-    //    segments of seg_len entries, every one composited from transmittance 1 -- but handed out layer by layer (every
-    //    bin's first segment, then every second one, ...; heaviest bins first inside a layer), and k_blend skips a segment
-    //    once a folded prefix of its bin is known to be saturated.  Bins that never saturate are composited by as many
-    //    workgroups as they have segments (the one-frame kernel's pole used to be single whole-bin items of 1.5-3.4 k entries
-    //    that never saturate: 195 us each), bins that do saturate cost their front segments only.
-    //  * whole-bin work items (seg_len_long; GSR_SPEC=0 or the separate k_combine launch): one item per bin, which stops
-    //    where the bin saturates.
-    const bool dense_mode = seg_len_min < 0x40000000u && (fa.long_policy > 0 || (fa.long_policy < 0 && dense));
-    const bool spec = dense_mode && fa.spec != 0u && fa.bin_mask != nullptr;
-    uint32_t seg_min = seg_len_min;
-    if (dense_mode && !spec) seg_min = max(seg_len_min, fa.seg_len_long);
-    // segment length of this frame (a multiple of 256; the whole-bin sentinel of early termination passes through)
-    // long items are ordered heaviest first in every mode: the few that run long must not start late (three frames in
-    // flight, C3: 4970 -> 5310 frames/s); short segments in throughput contexts stay in raster order (C2: 11 550 vs 11 250)
-    const bool by_size = fa.by_size != 0 || seg_min > seg_len_min;
+    // Which bins become ONE work item (gsr_api.cpp, "Work-item length").  A whole-bin item stops where the bin saturates, which
+    // pays where the bin holds much more than it takes to saturate it; a bin cut into segments is composited by several
+    // workgroups at once, which pays where it does not saturate.  A frame mixes both: a dense object in front of a sparse
+    // background (the real captures the reference is used with) has bins of either kind.  So the choice is made PER BIN, from
+    // the two figures the frame already has: a bin of c entries has the optical depth
+    //     tau_b = c x (frame's opacity x pixels per list entry) / 1024 = c x tau_frame x pixels / (1024 x E)
+    // (E = the frame's list entries; an entry's share taken as the frame's average), and it becomes one item from
+    // tau_b >= long_tau on, i.e. from  c >= long_from = long_tau x 255 x E / (4 x optical)  entries -- where the frame's splats
+    // cover several tiles each (`tiles`: small splats take many more entries to saturate a pixel than their boxes suggest).
+    // A function of the frame alone: deterministic, no feedback from earlier frames.  long_policy 1 / 0 pin all / no bins.
+    const bool tiles_ok = (uint64_t)ctot.v[1] * 2u >= (uint64_t)fa.long_tiles_x2 * ctot.v[0];
+    (void)dense;
+    uint32_t long_from = 0xffffffffu;                       // bins of at least this many entries are one work item
+    if (seg_len_min < 0x40000000u) {
+        if (fa.long_policy > 0) long_from = 0u;
+        else if (fa.long_policy < 0 && tiles_ok && optical > 0u)
+            long_from = (uint32_t)min((uint64_t)0xfffffff0u, ((uint64_t)fa.long_tau * 255u * (uint64_t)ent_tot.v[0] + 4u * optical - 1u) / (4u * optical));
+    }
+    const uint32_t seg_min = seg_len_min;
+    // segment length of the bins that ARE cut (a multiple of 256; the whole-bin sentinel of early termination passes through)
+    // work items are ordered heaviest first whenever whole-bin items can occur: the few that run long must not start late (three
+    // frames in flight, C3: 4970 -> 5310 frames/s); plain short segments in throughput contexts stay in raster order (C2: 11 550 vs 11 250)
+    const bool by_size = fa.by_size != 0 || long_from != 0xffffffffu;
     uint32_t seg_len = seg_min;
     if (seg_min < 0x40000000u)
         seg_len = min(max(ent_tot.v[0] / seg_target_items / 256u * 256u, seg_min), max(SEG_LEN_MAX, seg_min));
-    // Items are emitted heaviest first -- every full segment, then the bins' last segments (with long work items: the
-    // whole bins) by size class, a counting sort over FIN_CLASSES classes in LDS -- so the compositor's queue hands out
-    // the long items while the chip is still full and only short ones are left for the tail.  The order inside a class
-    // is whatever the atomics give: the item list is a work list, its order changes no pixel.
+    // Items are emitted heaviest first -- by size class (whole bins, full segments, the bins' last segments alike), a counting
+    // sort over FIN_CLASSES classes in LDS -- so the compositor's queue hands out the long items while the chip is still full
+    // and only short ones are left for the tail.  The order inside a class is whatever the atomics give: the item list is a
+    // work list, its order changes no pixel.  (by_size off: every full segment in raster order, then the last segments.)
     // Streams of the scan: entries, segments, full segments.
     __shared__ uint32_t s_cls[FIN_CLASSES];
     if (threadIdx.x < FIN_CLASSES) s_cls[threadIdx.x] = 0;
-    if (spec)
-        for (int k = threadIdx.x; k < FIN_SCRATCH_WORDS; k += FIN_THREADS) scratch[k] = 0;
+    (void)scratch;
     __syncthreads();
-    // Heavy single-item bins as FOUR work items, one per 16x16 tile, each wave of the workgroup that draws one taking one
-    // 8x8 quadrant (k_blend, ITEM_TILE0): meant to shorten the one-frame kernel's tail (its last workgroups hold the
-    // heaviest bins), bit-identical, but measured slower at every threshold -- the bin is staged four times and a wave
-    // that owns one quadrant pays the per-entry costs for a quarter of the pixels.  Off unless GSR_QUAD_FROM is set.
     // the cut of a bin of c entries: nf full segments, and whether a last segment of r entries follows (an empty bin is one
     // item: its pixels are cleared).  At most FIN_LAYERS segments per bin: the last one takes whatever is left.
     auto cut = [&](uint32_t c, uint32_t& nf, uint32_t& r, bool& part) {
-        nf = min(c / seg_len, (uint32_t)FIN_LAYERS - 1u);
+        nf = c >= long_from ? 0u : min(c / seg_len, (uint32_t)FIN_LAYERS - 1u);   // (a whole-bin item is the bin's "last segment")
         r = c - nf * seg_len;
         part = r || !nf;
     };
-    const uint32_t quad_from = (fa.by_size != 0 && fa.quad_from && !spec) ? fa.quad_from : 0xffffffffu;
+    const int cls_full = partial_class(seg_len);
     UN<3> mine = {{0, 0, 0}};   // entries, segments, full segments
-    UN<1> extra = {{0}};        // extra work items (3 per heavy bin)
     for (int b = b0; b < b1; b++) {
         const uint32_t c = bin_total[b];
         uint32_t nf, r; bool part;
@@ -326,29 +325,15 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa, uint32
         mine.v[0] += c;
         mine.v[1] += nf + (part ? 1u : 0u);
         mine.v[2] += nf;
-        const bool quad = !nf && c >= quad_from;
-        extra.v[0] += quad ? 3u : 0u;
-        if (spec) {   // one counter per (layer, size class of the bin, heaviest first)
-            const int col = FIN_CLASSES - 1 - partial_class(c);
-            for (uint32_t k = 0; k < nf + (part ? 1u : 0u); k++) atomicAdd(&scratch[k * FIN_CLASSES + col], 1u);
-        } else if (by_size && part) atomicAdd(&s_cls[partial_class(r)], quad ? 4u : 1u);
+        if (by_size) {
+            if (nf) atomicAdd(&s_cls[cls_full], nf);
+            if (part) atomicAdd(&s_cls[partial_class(r)], 1u);
+        }
     }
     UN<3> tot;
     const UN<3> ex3 = block_exclusive_scan<3>(mine, s_w, &tot);   // (its barriers also order the class counts)
-    UN<1> extra_tot = {{0}};
-    if (quad_from != 0xffffffffu) block_exclusive_scan<1>(extra, s_w, &extra_tot);   // (uniform)
     uint32_t ex = ex3.v[0], sx = ex3.v[1], fx = ex3.v[2];
-    if (spec) {   // (layer, class) counts -> first item index of each: exclusive scan of the 4096 counters, four per thread
-        static_assert(FIN_SCRATCH_WORDS == 4 * FIN_THREADS, "four counters per thread");
-        UN<1> four = {{scratch[4 * threadIdx.x] + scratch[4 * threadIdx.x + 1] + scratch[4 * threadIdx.x + 2] + scratch[4 * threadIdx.x + 3]}}, ftot;
-        uint32_t run = block_exclusive_scan<1>(four, s_w, &ftot).v[0];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t cnt = scratch[4 * threadIdx.x + j];
-            scratch[4 * threadIdx.x + j] = run;
-            run += cnt;
-        }
-    } else if (by_size && threadIdx.x < WAVE) {   // class counts -> first item index of each class, heaviest class first
+    if (by_size && threadIdx.x < WAVE) {   // class counts -> first item index of each class, heaviest class first
         static_assert(FIN_CLASSES == WAVE, "one class per lane");
         const uint32_t cnt = s_cls[FIN_CLASSES - 1 - threadIdx.x];
         uint32_t inc = cnt;
@@ -357,14 +342,14 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa, uint32
             const uint32_t u = __shfl_up(inc, off);
             if ((int)threadIdx.x >= off) inc += u;
         }
-        s_cls[FIN_CLASSES - 1 - threadIdx.x] = tot.v[2] + inc - cnt;
+        s_cls[FIN_CLASSES - 1 - threadIdx.x] = inc - cnt;
     }
     __syncthreads();
     uint32_t p3 = tot.v[2] + (sx - fx);   // raster order of the last segments (by_size off)
     // A frame whose lists do not fit (entries > capacity or items > max_items) must not be composited:
     // it publishes no work items at all (every index the compositor derives stays in range), raises the
     // overflow word, and the host regrows the buffers and renders the frame again (gsr_sync).
-    const uint32_t n_items = tot.v[1] + extra_tot.v[0];
+    const uint32_t n_items = tot.v[1];
     const bool fits = tot.v[0] <= capacity && n_items <= max_items;
     for (int b = b0; b < b1; b++) {
         const uint32_t c = bin_total[b];
@@ -372,21 +357,13 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa, uint32
         cut(c, nf, r, part);
         bin_start[b] = fits ? ex : 0u;
         seg_start[b] = fits ? sx : 0u;
-        if (fa.bin_mask) { fa.bin_mask[b] = 0ull; fa.bin_sat[b] = 0xffffffffu; }
-        if (fits && spec) {
-            const int col = FIN_CLASSES - 1 - partial_class(c);
-            for (uint32_t k = 0; k < nf + (part ? 1u : 0u); k++) items[atomicAdd(&scratch[k * FIN_CLASSES + col], 1u)] = (uint32_t)b | (k << 16);
-        } else if (fits) {
-            for (uint32_t k = 0; k < nf; k++) items[fx + k] = (uint32_t)b | (k << 16);
+        if (fa.bin_mask) fa.bin_mask[b] = 0ull;
+        if (fits) {
+            const uint32_t f0 = (by_size && nf) ? atomicAdd(&s_cls[cls_full], nf) : fx;
+            for (uint32_t k = 0; k < nf; k++) items[f0 + k] = (uint32_t)b | (k << 16);
             if (part) {
-                if (!nf && c >= quad_from) {   // (by_size holds)
-                    const uint32_t pos = atomicAdd(&s_cls[partial_class(r)], 4u);
-#pragma unroll
-                    for (uint32_t t = 0; t < 4; t++) items[pos + t] = (uint32_t)b | ((ITEM_TILE0 + t) << 16);
-                } else {
-                    const uint32_t pos = by_size ? atomicAdd(&s_cls[partial_class(r)], 1u) : p3++;
-                    items[pos] = (uint32_t)b | (nf << 16);
-                }
+                const uint32_t pos = by_size ? atomicAdd(&s_cls[partial_class(r)], 1u) : p3++;
+                items[pos] = (uint32_t)b | (nf << 16);
             }
         }
         ex += c;
@@ -404,7 +381,7 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa, uint32
         *queue = queue_start;  // the compositor's workgroups take items 0..grid-1 by index, later ones from here
         seg_len_out[0] = seg_len;
         seg_len_out[1] = fits ? n_items : 0u;   // the compositor's queue length
-        seg_len_out[2] = spec ? 1u : 0u;        // speculative segments: k_blend tests folded prefixes for saturation and skips behind them
+        seg_len_out[2] = 0u;                    // (reserved)
         bin_start[nbins] = fits ? tot.v[0] : 0u;
         seg_start[nbins] = fits ? tot.v[1] : 0u;
         accum[4] = tot.v[0];  // entries this frame needs (the host sizes the regrowth from it)
@@ -1010,8 +987,7 @@ static FinalizeArgs make_finalize_args(const BinBuffers& b, int nbins, uint32_t 
 {
     return FinalizeArgs{b.bin_total, nbins, b.seg_len, b.seg_target_items, b.items_by_size, b.seg_len_dev, b.max_items, b.capacity,
                         b.slots, n ? 1u : 0u, b.bin_start, b.seg_start, b.items, b.overflow, b.visible, b.tile_entries, b.accum,
-                        b.report, b.queue, b.queue_start, b.mailbox, b.bin_mask, b.bin_sat, b.long_policy, b.seg_len_long, b.long_tau, b.npix, b.quad_from, b.long_tiles_x2,
-                        b.spec};
+                        b.report, b.queue, b.queue_start, b.mailbox, b.bin_mask, b.long_policy, b.seg_len_long, b.long_tau, b.npix, b.long_tiles_x2};
 }
 
 // cells across / down a grid of bins

@@ -132,8 +132,11 @@ __device__ __forceinline__ float eval_sh_texture(const uint32_t* __restrict__ te
 // One thread per splat, original order (fully coalesced SoA reads).
 //   A1  depth key + min/max        wasm/wasm.cpp:14-31
 //   B1-B6 projection               vertex.glsl.ts:130-231 (non-SH colour branch, scalingFactor 1)
-// Writes depth[i] always; rec[i] for splats that survive the culls; bbox[i] always
-// (x0 > x1 marks "nothing to draw").
+// Writes depth[i] and the packed bin rectangle rect[i] always; rec[i] for splats that survive the culls.  The inclusive pixel
+// box bbox[i] (x0 > x1 marks "nothing to draw") is a parity read-back, not an input of any kernel: it is written only when
+// asked for (bbox != null).  gsr_read_records asks by running this kernel once more for the frame's camera with
+// do_project == 2, which writes records and boxes only -- no key, no rectangle, no frame counters -- so a frame does not pay
+// 8 bytes per splat for a buffer nothing on the path reads (C4: 40 MB of the projection's ~400).
 // ---------------------------------------------------------------------------
 // The camera is a kernel argument (scalar loads from the kernarg segment).  It is the one argument of the frame's chain that
 // changes from frame to frame: when the chain is replayed as a HIP graph, the host rewrites this kernel node's parameters
@@ -146,7 +149,8 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_project_key(SceneSoA sc, uint3
                                                               Record* __restrict__ rec, uint2* __restrict__ bbox,
                                                               uint32_t* __restrict__ rect, uint32_t* __restrict__ overflow)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *overflow = 0u;   // (raised by the binning kernels later in this frame)
+    const bool frame = do_project != 2;   // (uniform) false: the read-back re-run
+    if (frame && blockIdx.x == 0 && threadIdx.x == 0) *overflow = 0u;   // (raised by the binning kernels later in this frame)
     __shared__ int32_t s_min[4], s_max[4];
     __shared__ uint32_t s_vis[4], s_til[4], s_oti[4];
     int32_t dmin = 0x7fffffff, dmax = (int32_t)0x80000000;
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_project_key(SceneSoA sc, uint3
         const float f1 = cam.vp6 * y;
         const float f2 = cam.vp10 * z;
         const int32_t d = (int32_t)(((f0 + f1) + f2) * 4096.0f);
-        depth[i] = d;
+        if (frame) depth[i] = d;
         dmin = d; dmax = d;
 
         if (do_project) {
@@ -300,8 +304,8 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_project_key(SceneSoA sc, uint3
                 bb.x = (uint32_t)(int32_t)fx0 | ((uint32_t)(int32_t)fx1 << 16);
                 bb.y = (uint32_t)(int32_t)fy0 | ((uint32_t)(int32_t)fy1 << 16);
             } while (0);
-            bbox[i] = bb;
-            rect[i] = pack_bin_rect(bb.x, bb.y, bx_lo, bx_hi);
+            if (bbox) bbox[i] = bb;
+            if (frame) rect[i] = pack_bin_rect(bb.x, bb.y, bx_lo, bx_hi);
             if ((bb.x & 0xffffu) <= (bb.x >> 16)) {
                 vis++;
                 const int tx0 = max((int)(bb.x & 0xffffu) / TILE, bx_lo * BIN_TILES), tx1 = min((int)(bb.x >> 16) / TILE, bx_hi * BIN_TILES - 1);
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_project_key(SceneSoA sc, uint3
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { s_min[wave] = dmin; s_max[wave] = dmax; s_vis[wave] = vis; s_til[wave] = tiles; s_oti[wave] = otiles; }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && frame) {
         int32_t* slot = slots + (size_t)(blockIdx.x & (FRAME_SLOTS - 1)) * FRAME_SLOT_WORDS;
         atomicMin(&slot[0], min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3])));
         atomicMax(&slot[1], max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));

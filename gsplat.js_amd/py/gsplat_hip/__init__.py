@@ -508,9 +508,8 @@ class HIPRenderer:
         return starts, lst[:int(starts[-1])]
 
     def work_items(self):
-        """How the last frame's bin lists were cut for the compositor: entries per segment, work items, whether the segments
-        were speculative (GSR_SPEC=1: segments behind a saturated prefix of their bin are skipped), the compositor's waves per
-        16x16 tile (which of its two kernels ran), bins."""
+        """How the last frame's bin lists were cut for the compositor: entries per segment, work items, the compositor's waves
+        per 16x16 tile (which of its two kernels ran), bins.  ("speculative" is always False: the option is gone.)"""
         out = np.zeros(5, dtype=np.uint32)
         self._check(self._L.gsr_read_work_items(self._ctx, out.ctypes.data))
         return {"seg_len": int(out[0]), "items": int(out[1]), "speculative": bool(out[2]), "waves_per_tile": int(out[3]), "bins": int(out[4])}

@@ -67,3 +67,39 @@ def synth_rows(n, seed, sigma=1.5, s_lo=0.004, s_hi=0.06, chunk=1 << 20):
 def config_rows(name):
     c = CONFIGS[name]
     return synth_rows(c["n"], c["seed"], c["sigma"], c["s_lo"], c["s_hi"])
+
+
+# ---------------------------------------------------------------------------
+# Scenes that are NOT one centred isotropic blob (scripts/policy_check.py: the per-bin work-item policy must hold where a
+# frame mixes bins that saturate with bins that do not, as real captures -- a dense object in front of a sparse background
+# -- do).  Built from synth_rows by editing the rows' position / alpha fields; same seeded generator underneath.
+# ---------------------------------------------------------------------------
+def _edit(rows, offset=None, alpha_min=None, on_sphere=None):
+    r = np.array(rows, dtype=np.uint8).reshape(-1, ROW)
+    pos = r[:, 0:12].copy().view(np.float32).reshape(-1, 3)
+    if on_sphere is not None:        # points on a sphere of that radius (direction of the blob's sample)
+        ln = np.maximum(np.linalg.norm(pos.astype(np.float64), axis=1, keepdims=True), 1e-9)
+        pos = (pos / ln * on_sphere).astype(np.float32)
+    if offset is not None:
+        pos = (pos + np.asarray(offset, dtype=np.float32)).astype(np.float32)
+    r[:, 0:12] = pos.view(np.uint8).reshape(-1, 12)
+    if alpha_min is not None:
+        r[:, 27] = np.maximum(r[:, 27], alpha_min)
+    return r.reshape(-1)
+
+
+def cluster_in_halo(n_cluster=300_000, n_halo=300_000, seed=21):
+    """A tight cluster (sigma 0.4) inside a sparse halo (sigma 3): dense bins in the middle of the screen, thin ones around."""
+    return np.concatenate([synth_rows(n_cluster, seed, 0.4, 0.004, 0.06), synth_rows(n_halo, seed + 1, 3.0, 0.004, 0.06)])
+
+
+def two_clusters(n_each=400_000, seed=23):
+    """Two clusters at different depths and screen positions (sigma 0.6 each, 3 units apart along x and z)."""
+    a = _edit(synth_rows(n_each, seed, 0.6, 0.004, 0.06), offset=(-1.5, 0.0, -1.5))
+    b = _edit(synth_rows(n_each, seed + 1, 0.6, 0.004, 0.06), offset=(1.5, 0.3, 1.5))
+    return np.concatenate([a, b])
+
+
+def opaque_shell(n=600_000, seed=25, radius=2.5):
+    """A thin opaque shell: points on a sphere, alpha >= 240 -- every pixel inside the silhouette saturates after a few entries."""
+    return _edit(synth_rows(n, seed, 1.0, 0.01, 0.08), on_sphere=radius, alpha_min=240)

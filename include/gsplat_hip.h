@@ -176,8 +176,7 @@ int gsr_read_keys(gsr_ctx *ctx, uint32_t *keys /* n, 17-bit */, int32_t *minmax 
 int gsr_read_records(gsr_ctx *ctx, float *rec /* 8n */, int32_t *bbox /* 4n: x0,y0,x1,y1 */);
 int gsr_read_sh_colors(gsr_ctx *ctx, float *rgba /* 4n: evaluated SH colour of every splat that has one */);
 /* How the last rendered frame's bin lists were handed to the compositor (the choices change no depth order, only f32
- * association): out[0] = list entries per segment, out[1] = work items, out[2] = 1 when the segments were speculative
- * (GSR_SPEC=1: segments behind a saturated prefix of their bin are skipped; same bits as out[2] = 0), out[3] = waves
+ * association): out[0] = list entries per segment, out[1] = work items, out[2] = 0 (reserved), out[3] = waves
  * per 16x16 tile (1: k_blend, 2: k_blend2), out[4] = bins of the context's band. */
 int gsr_read_work_items(gsr_ctx *ctx, uint32_t *out /* 5 */);
 
@@ -223,8 +222,10 @@ int gsr_comm_init(gsr_ctx *ctx, const uint8_t *id, int32_t rank, int32_t world, 
  * leader's communicator and exchange stream (so a rank's collectives are issued on ONE stream, in the order of the
  * gsr_allgather_frame_async calls, which must be the same on every rank) and gets its own slab and frame buffers.
  * Several communicators per device with collectives in flight on different streams are the RCCL/NCCL case that can
- * deadlock when the ranks' collectives are scheduled in different orders; this avoids it.  Destroy the sharing
- * contexts (or gsr_comm_destroy them) before the leader. */
+ * deadlock when the ranks' collectives are scheduled in different orders; this avoids it.  A leader that is destroyed
+ * (or leaves with gsr_comm_destroy) first detaches its sharers: they become plain contexts again and fail
+ * gsr_allgather_frame_async with GSR_ERR_ARG until they join a group anew.  A custom collective's `user` pointer must
+ * outlive every context that uses it. */
 int gsr_comm_share(gsr_ctx *ctx, gsr_ctx *leader);
 /* Test hook: gsr_comm_init with the caller's collective in place of ncclAllGather, for hosts that cannot form an RCCL
  * communicator of more than one rank (RCCL refuses two ranks on one device) but want to run the exchange's choreography
@@ -238,8 +239,11 @@ int gsr_comm_init_custom(gsr_ctx *ctx, int32_t rank, int32_t world, const int32_
                          void *user);
 int gsr_comm_destroy(gsr_ctx *ctx);
 int gsr_allgather_frame_async(gsr_ctx *ctx);
-/* Waits for the exchange AND for the render stream; returns GSR_ERR_OVERFLOW (after regrowing the lists) instead of a frame
- * when the frame behind the gathered band did not fit its bin lists: render and gather it again. */
+/* Waits for the exchange AND for the render stream.  A band packed behind a frame whose bin lists did not fit is the
+ * preceding image: every slab carries its frame's overflow flag through the all-gather, so EVERY rank of the group sees
+ * which gathered frame holds a stale band and gets GSR_ERR_OVERFLOW for that frame (the rank concerned has regrown its
+ * lists by then): all ranks render and gather it again -- the collective is repeated by the whole group, never by one
+ * rank alone.  Frames dropped earlier on this rank (reported once by gsr_sync) do not make a good frame unreadable. */
 int gsr_read_frame_rgba8(gsr_ctx *ctx, uint8_t *out /* w*h*4: the gathered frame */);
 void *gsr_frame8_device_ptr(gsr_ctx *ctx);    /* uint8[h][w][4], the gathered frame on the device */
 void *gsr_comm_stream_handle(gsr_ctx *ctx);   /* hipStream_t the exchange runs on */

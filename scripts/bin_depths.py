@@ -1,12 +1,11 @@
 #!/usr/bin/env python3
 """Per-bin saturation depths of one frame (diagnostic build: scripts/build_exp.sh stamps "-DGSR_BLEND_STAMPS"; whole-bin
-work items, GSR_SPEC=0): entries, entries staged before the item ended, visits per wave, item duration.
+work items): entries, entries staged before the item ended, visits per wave, item duration.
   python scripts/bin_depths.py [config] [pose] -> gpurun_out/bin_depths_<config>_<pose>.npy  (rows: bin; cols: 8 words)"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gsplat.js_amd", "py")]
 import numpy as np
-os.environ["GSR_SPEC"] = "0"
 os.environ["GSR_LONG_ITEMS"] = "1"
 import gsplat_hip as gh
 config = sys.argv[1] if len(sys.argv) > 1 else "C3"

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Does the work-item policy (k_bin_finalize: optical depth, tiles per splat) pick the faster cut?  A few scene families
-beyond the two the thresholds were tuned on; short / long pinned vs automatic, one frame at a time and three in flight."""
+"""Does the work-item policy (k_bin_finalize: per bin, from the frame's optical depth per list entry and its tiles per
+splat) pick the faster cut?  Scene families beyond the two the thresholds were tuned on -- five single blobs and three
+that are not (a tight cluster in a sparse halo, two clusters at different depths, a thin opaque shell: frames that mix
+bins that saturate with bins that do not); every bin cut into segments / every bin one item (pinned) vs the automatic
+per-bin choice, one frame at a time and three in flight."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gsplat.js_amd", "py")]
@@ -10,8 +13,14 @@ W, H, fx = 1920, 1080, 1132.0
 poses = [gh.orbit_camera(k, 120, W, H, fx).f32() for k in range(120)]
 families = [("big sparse", 150_000, 1.5, 0.03, 0.25), ("big dense", 400_000, 1.2, 0.02, 0.12), ("tiny dense", 2_000_000, 1.0, 0.002, 0.012),
             ("wide thin", 800_000, 2.5, 0.004, 0.05), ("C3-like 1.5M", 1_500_000, 1.5, 0.004, 0.06)]
+families += [("cluster+halo", None, gh.synth.cluster_in_halo, 0, 0), ("two clusters", None, gh.synth.two_clusters, 0, 0),
+             ("opaque shell", None, gh.synth.opaque_shell, 0, 0)]
+only = sys.argv[1:]     # optional: substrings of the family names to run
 for name, n, sigma, s_lo, s_hi in families:
-    rows = gh.synth.synth_rows(n, 11, sigma, s_lo, s_hi)
+    if only and not any(o in name for o in only):
+        continue
+    rows = gh.synth.synth_rows(n, 11, sigma, s_lo, s_hi) if n else sigma()
+    n = rows.size // 32
     scene = gh.Scene(); scene.setData(rows)
     res = {}
     for pol in ("0", "1", None):

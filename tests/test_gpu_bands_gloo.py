@@ -133,6 +133,40 @@ def _exchange_worker(rank, world, port, out):
         for k, got in frames:
             cal.render(scene, cams[k])
             ok = ok and np.array_equal(got, cal.readPixels())
+        # A list overflow on ONE rank of the group: its frame is not composited, its slab says so, and the flag reaches every
+        # rank with the all-gather -- ALL ranks refuse that gathered frame (no rank repeats a collective alone) and then render
+        # and gather it again together; the overflowing rank has regrown its lists by then.
+        a.sync(); b.sync()
+        if rank == world - 1:
+            a.set_list_capacity(1024)
+        a.set_camera(cams[1])
+        a.render_async()
+        a.allgather_frame_async()
+        refused = False
+        try:
+            a.read_frame()
+        except gh.GsplatError as e:
+            refused = "not composited" in str(e)
+        ok = ok and refused
+        a.set_camera(cams[1])
+        a.render_async()
+        a.allgather_frame_async()
+        got = a.read_frame()
+        cal.render(scene, cams[1])
+        ok = ok and np.array_equal(got, cal.readPixels())
+        if rank == world - 1:
+            ok = ok and a.stats()["overflow_frames"] >= 1
+        try:
+            a.sync()
+        except gh.GsplatError as e:          # (nothing was dropped: the one overflowing frame was rendered again)
+            ok = False
+        # a leader that leaves first detaches its sharer instead of leaving it with a destroyed stream
+        a.leave_group()
+        try:
+            b.allgather_frame_async()
+            ok = False
+        except gh.GsplatError:
+            pass
         b.dispose(); a.dispose(); cal.dispose()
         res = torch.tensor([1 if ok else 0])
         dist.all_reduce(res, op=dist.ReduceOp.MIN)

@@ -33,9 +33,10 @@ def test_no_index_leaves_its_array(monkeypatch):
     assert os.path.exists(LIB), "the bounds-checked build is missing: run python -c 'import __graft_entry__ as g; g.build()'"
     frames = 0
 
-    def render(cfg_name, poses, size=None, n=None, seed=None, **kw):
+    def render(cfg_name, poses, size=None, n=None, seed=None, fx_div=1, **kw):
         nonlocal frames
-        cfg = gh.synth.CONFIGS[cfg_name]
+        cfg = dict(gh.synth.CONFIGS[cfg_name])
+        cfg["fx"] /= fx_div
         W, H = size or (cfg["width"], cfg["height"])
         rows = gh.synth.config_rows(cfg_name) if n is None else gh.synth.synth_rows(n, seed)
         r = gh.HIPRenderer(W, H, lib_path=LIB, **kw)
@@ -54,9 +55,9 @@ def test_no_index_leaves_its_array(monkeypatch):
     render("C2", (13,), throughput=True).dispose()                     # one wave per tile
     render("C2", (13,), band=(864, 1056)).dispose()                    # survivor sort of a band context
     render("C3", (17,)).dispose()                                      # whole-bin work items with the saturation skip
-    monkeypatch.setenv("GSR_SPEC", "1")
-    render("C3", (17,)).dispose()                                      # speculative segments: prefix folds and skips
-    monkeypatch.delenv("GSR_SPEC")
+    monkeypatch.setenv("GSR_LONG_ITEMS", "0")
+    render("C3", (17,)).dispose()                                      # short segments on a dense frame: the fold of up to ~40 partials per bin
+    monkeypatch.delenv("GSR_LONG_ITEMS")
     monkeypatch.setenv("GSR_SORT_ORDER", "lsd")
     render("C2", (7,)).dispose()                                       # the six-launch radix order
     monkeypatch.delenv("GSR_SORT_ORDER")
@@ -68,6 +69,13 @@ def test_no_index_leaves_its_array(monkeypatch):
     monkeypatch.setenv("GSR_BIN_TWO_LEVEL", "0")
     render("C1", (9,), size=(3840, 2160)).dispose()                    # the one-level large-grid kernels
     monkeypatch.delenv("GSR_BIN_TWO_LEVEL")
+    for sub in ("1", "2"):                                             # bins of more than 64 segments: the last one takes the rest
+        monkeypatch.setenv("GSR_LONG_ITEMS", "0"); monkeypatch.setenv("GSR_SEG_LEN", "256"); monkeypatch.setenv("GSR_SEG_TARGET", "100000"); monkeypatch.setenv("GSR_BLEND_SUB", sub)
+        r = render("C3", (17,), size=(640, 360), fx_div=3)             # (the whole scene on 240 bins: the heaviest hold > 16384 entries)
+        assert r.work_items()["seg_len"] == 256 and int(r.bin_totals().max()) > 64 * 256
+        r.dispose()
+    for k in ("GSR_LONG_ITEMS", "GSR_SEG_LEN", "GSR_SEG_TARGET", "GSR_BLEND_SUB"):
+        monkeypatch.delenv(k)
     r = render("C1", (21,))
     r.set_list_capacity(1024)                                          # overflow: no work published, then regrowth
     r.set_camera(gh.orbit_camera(50, 120, r.width, r.height, gh.synth.CONFIGS["C1"]["fx"]))
@@ -77,4 +85,4 @@ def test_no_index_leaves_its_array(monkeypatch):
     got = _counters(L)
     bad = {(name, SITES[name][k] if k < len(SITES[name]) else k): v for name, vals in got.items() for k, v in enumerate(vals) if v}
     assert not bad, bad
-    assert frames >= 18
+    assert frames >= 20

@@ -1135,108 +1135,43 @@ def test_saturated_quadrants_are_skipped_without_changing_a_bit(gh, monkeypatch,
 
 @pytest.mark.gpu
 def test_long_and_short_work_items_agree(gh, monkeypatch):
-    """The work-item length is chosen per frame from the frame's optical depth (k_bin_finalize): whole bins where the
-    scene saturates (C3, tau 362), short segments where it does not (C2, tau 74).  The two cuts of a bin's list differ in
-    f32 association order only: images within 2e-6, RGBA8 within one step; what the policy picked is read back with
-    gsr_read_work_items (whole bins: as many work items as bins), and the automatic choice equals the pinned one bit for bit."""
-    for name, expect in (("C3", "1"), ("C2", "0")):
+    """Which bins are handed to the compositor as ONE work item is chosen per bin (k_bin_finalize: a bin's optical depth from
+    its entry count and the frame's opacity x pixels per entry; only in frames whose splats cover several tiles each): a
+    dense frame (C3) mixes whole-bin items -- its centre -- with bins cut into segments -- its rim; a frame of small splats
+    (C2, 3.6 tiles per splat) is cut into segments throughout, bit for bit like the pinned short cut.  The cuts of a bin's
+    list differ in f32 association order only: images within 2e-6, RGBA8 within one step; what the policy picked is read
+    back with gsr_read_work_items; the choice is a function of the frame alone (the same frame twice: the same bits)."""
+    for name in ("C3", "C2"):
         cfg = gh.synth.CONFIGS[name]
         W, H = cfg["width"], cfg["height"]
         scene = gh.Scene()
         scene.setData(gh.synth.config_rows(name))
         cam = gh.orbit_camera(17, 120, W, H, cfg["fx"])
-        imgs, whole = {}, {}
-        for mode in ("0", "1", "auto"):
-            if mode == "auto":
+        imgs, items = {}, {}
+        for mode in ("0", "1", "auto", "auto again"):
+            if mode.startswith("auto"):
                 monkeypatch.delenv("GSR_LONG_ITEMS", raising=False)
             else:
                 monkeypatch.setenv("GSR_LONG_ITEMS", mode)
             r = gh.HIPRenderer(W, H)
+            if mode == "auto again":
+                r.render(scene, gh.orbit_camera(63, 120, W, H, cfg["fx"]))      # another frame in between changes nothing
             r.render(scene, cam)
             imgs[mode] = (r.readPixelsFloat(), r.readPixels())
             wi = r.work_items()
-            whole[mode] = wi["items"] == wi["bins"]
+            items[mode] = wi["items"]
+            nbins = wi["bins"]
             assert wi["waves_per_tile"] == 2 and not wi["speculative"]
             r.dispose()
         assert np.abs(imgs["0"][0] - imgs["1"][0]).max() <= 2e-6
         assert np.abs(imgs["0"][1].astype(np.int32) - imgs["1"][1].astype(np.int32)).max() <= 1
-        assert np.array_equal(imgs["auto"][0], imgs[expect][0]), name
-        assert whole["1"] and not whole["0"] and whole["auto"] == (expect == "1"), name
-
-
-@pytest.mark.gpu
-def test_heavy_bins_split_into_tile_items_change_no_bit(gh, monkeypatch):
-    """(An option, off by default: measured slower.)  A heavy whole-bin work item can be handed out as four items, one per
-    16x16 tile; the workgroup that draws one gives every wave a single 8x8 quadrant (k_blend, ITEM_TILE0, GSR_QUAD_FROM).  Per pixel the arithmetic and the order of
-    the splats are the same, so the image equals the unsplit one (GSR_QUAD_FROM=0) bit for bit -- also when nearly every
-    bin is split (GSR_QUAD_FROM=64).  With early termination (approximate by definition: a wave stops when ITS pixels are
-    below the threshold, and a wave's pixels are then a quadrant instead of a tile) the images agree to the threshold."""
-    cfg = gh.synth.CONFIGS["C3"]
-    W, H = cfg["width"], cfg["height"]
-    scene = gh.Scene()
-    scene.setData(gh.synth.config_rows("C3"))
-    monkeypatch.setenv("GSR_BLEND_SUB", "1")   # (tile items give every wave one quadrant: the one-wave-per-tile kernel, for all three)
-    for eps in (0.0, 1e-4):
-        monkeypatch.setenv("GSR_QUAD_FROM", "0")
-        whole = gh.HIPRenderer(W, H, early_out_eps=eps)
-        monkeypatch.setenv("GSR_QUAD_FROM", "3072")
-        split = gh.HIPRenderer(W, H, early_out_eps=eps)
-        monkeypatch.setenv("GSR_QUAD_FROM", "64")
-        split_all = gh.HIPRenderer(W, H, early_out_eps=eps)
-        monkeypatch.delenv("GSR_QUAD_FROM")
-        for k in (11, 58, 103):
-            cam = gh.orbit_camera(k, 120, W, H, cfg["fx"])
-            whole.render(scene, cam)
-            want = whole.readPixelsFloat()
-            for r in (split, split_all):
-                r.render(scene, cam)
-                if eps == 0.0:
-                    assert np.array_equal(r.readPixelsFloat(), want), k
-                else:
-                    assert np.abs(r.readPixelsFloat() - want).max() <= 2 * eps, k
-        for r in (whole, split, split_all):
-            r.dispose()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("sub", ["1", "2"])
-def test_speculative_segments_equal_the_plain_cut_bit_for_bit(gh, monkeypatch, sub):
-    """(An option, GSR_SPEC=1; dense frames are cut into whole-bin work items by default, which measured faster.)  A dense
-    frame cut into the same plain segments as any other frame, handed out layer by layer; the workgroup whose arrival
-    completes a power-of-two prefix of a bin folds it and tests it for saturation, segments behind a saturated prefix are
-    skipped and the final fold stops there (k_bin_finalize, k_blend).  Nothing that is skipped could have changed a bit
-    (every later term is under half an ulp of the folded colour), so the image must EQUAL the plain cut's
-    (GSR_LONG_ITEMS=0), f32 and RGBA8 -- whichever segments happened to be skipped in a given run: rendered twice, and
-    with either compositor kernel (one or two waves per tile).  Whole-bin work items differ by f32 association."""
-    monkeypatch.setenv("GSR_BLEND_SUB", sub)
-    for name, poses in (("C3", (5, 17, 47, 88)), ("C4", (9,))):
-        cfg = gh.synth.CONFIGS[name]
-        W, H = cfg["width"], cfg["height"]
-        scene = gh.Scene()
-        scene.setData(gh.synth.config_rows(name))
-        monkeypatch.setenv("GSR_LONG_ITEMS", "0")
-        plain = gh.HIPRenderer(W, H)
-        monkeypatch.setenv("GSR_LONG_ITEMS", "1")
-        whole = gh.HIPRenderer(W, H)
-        monkeypatch.setenv("GSR_SPEC", "1")
-        spec = gh.HIPRenderer(W, H)
-        monkeypatch.delenv("GSR_SPEC")
-        monkeypatch.delenv("GSR_LONG_ITEMS")
-        for k in poses:
-            cam = gh.orbit_camera(k, 120, W, H, cfg["fx"])
-            plain.render(scene, cam)
-            want, want8 = plain.readPixelsFloat(), plain.readPixels()
-            assert not plain.work_items()["speculative"] and plain.work_items()["waves_per_tile"] == int(sub)
-            for _ in range(2):
-                spec.render(scene, cam)
-                assert spec.work_items() == dict(plain.work_items(), speculative=True)
-                assert np.array_equal(spec.readPixelsFloat(), want), (name, k)
-                assert np.array_equal(spec.readPixels(), want8), (name, k)
-            whole.render(scene, cam)
-            assert not whole.work_items()["speculative"] and whole.work_items()["items"] == whole.work_items()["bins"]
-            assert np.abs(whole.readPixelsFloat() - want).max() <= 2e-6, (name, k)
-        for r in (plain, spec, whole):
-            r.dispose()
+        assert np.array_equal(imgs["auto"][0], imgs["auto again"][0]) and items["auto"] == items["auto again"], name
+        assert items["1"] == nbins < items["0"], name
+        if name == "C3":     # a mix: more items than bins, fewer than the all-segments cut
+            assert nbins < items["auto"] < items["0"], (name, items)
+            assert np.abs(imgs["auto"][0] - imgs["1"][0]).max() <= 2e-6 and np.abs(imgs["auto"][0] - imgs["0"][0]).max() <= 2e-6
+        else:
+            assert items["auto"] == items["0"] and np.array_equal(imgs["auto"][0], imgs["0"][0]), (name, items)
 
 
 @pytest.mark.gpu
@@ -1294,3 +1229,171 @@ def test_two_waves_per_tile_agree_with_one(gh, oracle, scenes, monkeypatch):
     w4.render(scene, gh.orbit_camera(3, 120, 3840, 2160, 2264.0))
     assert w4.work_items()["waves_per_tile"] == 1
     w4.dispose()
+
+
+@pytest.mark.gpu
+def test_c5_workload_as_eight_bands_on_one_gpu(gh, oracle, scenes, monkeypatch):
+    """BASELINE C5's workload on the one GPU a test box has: the C4 scene (5 M splats, 3840x2160, fx 2264) rendered as EIGHT
+    cost-balanced band contexts -- what the eight ranks of a C5 run each do (bench.py split_config: edges from two
+    calibration poses) -- and as one full-frame context.  At this size a band context takes the paths only 5 M splats select:
+    the LSD radix order with the bin rectangles carried through it, survivor sort, and (bands of up to 4096 bins) the
+    one-level binning beside the full frame's two-level binning.  Checked on two poses:
+      * the union of the bands is the full frame: bit for bit when every context cuts its lists alike (work-item length
+        pinned), within f32 association order (2e-6) when each band decides from the optical depth of its own pixels;
+      * a band's per-bin list lengths are the full frame's for its columns, its counters (visible splats, 16x16 tile
+        overlaps, list entries) are what the full frame's records give for the band, and the bands' entries sum to the frame's;
+      * gsr_read_depth_index on a band context (survivor sort in the frame, full sort on demand) is the oracle's permutation."""
+    from gsplat_hip import bands
+    cfg = gh.synth.CONFIGS["C4"]
+    W, H, N = cfg["width"], cfg["height"], cfg["n"]
+    rows, data, pos = scenes("C4")
+    world = 8
+    cal = gh.HIPRenderer(W, H)
+    cal.set_raw_scene(data, pos)
+    cost = np.zeros(-(-W // 32))
+    for k in (0, 60):
+        cal.set_camera(_camera(gh, k, cfg))
+        cal.render_async(); cal.sync()
+        cost += cal.bin_totals().sum(axis=0) + 0.25 * 32 * H
+    cal.dispose()
+    edges = bands.balanced_edges(W, world, cost)
+    assert len(edges) == world and edges[0][0] == 0 and edges[-1][1] == W and all(b > a for a, b in edges)
+    assert max(b - a for a, b in edges) > min(b - a for a, b in edges)      # centre-heavy scene: unequal bands
+    for pinned in ("1", None):
+        # pinned: every context cuts its lists alike AND composites with the same kernel (left alone, the full 4K frame --
+        # 8160 bins -- takes one wave per tile and a band of up to 4096 bins two: the same pixels to f32 association)
+        if pinned is None:
+            monkeypatch.delenv("GSR_LONG_ITEMS", raising=False)
+            monkeypatch.delenv("GSR_BLEND_SUB", raising=False)
+        else:
+            monkeypatch.setenv("GSR_LONG_ITEMS", pinned)
+            monkeypatch.setenv("GSR_BLEND_SUB", "1")
+        full = gh.HIPRenderer(W, H)
+        parts = [gh.HIPRenderer(W, H, band=e) for e in edges]
+        for r in [full] + parts:
+            r.set_raw_scene(data, pos)
+        for k in (50, 110):
+            cam = _camera(gh, k, cfg)
+            full.set_camera(cam)
+            full.render_async(); full.sync()
+            want = full.readPixelsFloat()
+            totals = full.bin_totals()
+            fst = full.stats()
+            assert fst["overflow_frames"] == 0 and fst["bin_entries"] == int(totals.sum())
+            _, bbox = full.read_records()
+            bx0, by0, bx1, by1 = (bbox[:, j].astype(np.int64) for j in range(4))
+            drawn = bx0 <= bx1
+            got = np.zeros_like(want)
+            entries = 0
+            for r, (x0, x1) in zip(parts, edges):
+                r.set_camera(cam)
+                r.render_async(); r.sync()
+                img = r.readPixelsFloat()
+                assert not img[:, :x0].any() and not img[:, x1:].any()
+                got[:, x0:x1] = img[:, x0:x1]
+                lo, hi = x0 // 32, -(-x1 // 32)
+                assert np.array_equal(r.bin_totals(), totals[:, lo:hi]), (k, x0)
+                st = r.stats()
+                touch = drawn & (bx1 >= 32 * lo) & (bx0 < 32 * hi)
+                tx0, tx1 = np.maximum(bx0 // 16, 2 * lo), np.minimum(bx1 // 16, 2 * hi - 1)
+                tiles = ((tx1 - tx0 + 1) * (by1 // 16 - by0 // 16 + 1))[touch].sum()
+                assert st["overflow_frames"] == 0
+                assert (st["visible"], st["tile_entries"], st["bin_entries"]) == (int(touch.sum()), int(tiles), int(totals[:, lo:hi].sum())), (k, x0)
+                entries += st["bin_entries"]
+            assert entries == fst["bin_entries"]
+            if pinned is None:
+                assert np.abs(got - want).max() <= 2e-6, k
+            else:
+                assert np.array_equal(got, want), k
+            del want, got, img
+        if pinned is None:
+            v, p, vp = cam.f32()
+            odi = oracle.sort(vp, pos)[0]
+            for r in (parts[0], parts[4]):
+                assert np.array_equal(r.lastDepthIndex(), odi)
+            assert np.array_equal(full.lastDepthIndex(), odi)
+        for r in [full] + parts:
+            r.dispose()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sub", ["1", "2"])
+def test_bins_with_more_than_64_segments(gh, monkeypatch, sub):
+    """A bin's arrival mask has one bit per segment, so a bin is cut into at most 64 segments and the last one takes
+    whatever is left (k_bin_finalize's cut, k_blend's `seg + 1 == nseg ? bin_end`).  C3 seen at a third of its resolution
+    (the whole scene on 240 bins) has bins of several ten thousand entries: with 256-entry segments well over 64 segments'
+    worth.  The fold inside the compositor (both kernels) must equal the separate k_combine launch bit for bit there, and
+    the whole-bin cut to f32 association."""
+    cfg = dict(gh.synth.CONFIGS["C3"])
+    W, H = 640, 360
+    cfg["fx"] /= 3
+    scene = gh.Scene()
+    scene.setData(gh.synth.config_rows("C3"))
+    monkeypatch.setenv("GSR_LONG_ITEMS", "0")
+    monkeypatch.setenv("GSR_SEG_LEN", "256")
+    monkeypatch.setenv("GSR_SEG_TARGET", "100000")    # (so that the frame's segment length is not raised above the 256 asked for)
+    monkeypatch.setenv("GSR_BLEND_SUB", sub)
+    cam0 = gh.orbit_camera(5, 120, W, H, cfg["fx"])
+    fused = gh.HIPRenderer(W, H)
+    fused.render(scene, cam0)          # (the cut's knobs are read when the scene is set: while they are in the environment)
+    monkeypatch.setenv("GSR_FUSE_COMBINE", "0")
+    separate = gh.HIPRenderer(W, H)
+    separate.render(scene, cam0)
+    monkeypatch.delenv("GSR_FUSE_COMBINE")
+    monkeypatch.delenv("GSR_SEG_LEN")
+    monkeypatch.delenv("GSR_SEG_TARGET")
+    monkeypatch.setenv("GSR_LONG_ITEMS", "1")
+    whole = gh.HIPRenderer(W, H)
+    whole.render(scene, cam0)
+    for k in (17, 71):
+        cam = gh.orbit_camera(k, 120, W, H, cfg["fx"])
+        for r in (fused, separate, whole):
+            r.render(scene, cam)
+        wi = fused.work_items()
+        assert wi["seg_len"] == 256 and int(fused.bin_totals().max()) > 64 * 256 and wi["items"] > 5000
+        a, b, c = fused.readPixelsFloat(), separate.readPixelsFloat(), whole.readPixelsFloat()
+        assert np.array_equal(a, b), k
+        assert np.abs(a - c).max() <= 2e-6, k
+        assert fused.stats()["overflow_frames"] == 0
+    for r in (fused, separate, whole):
+        r.dispose()
+
+
+# Every environment knob the library still reads (DESIGN.md section 6 lists them), at a non-default value: each selects code that
+# otherwise only an A/B run would execute.  C1 rendered twice (the first frame of a scene sorts in LSD order) under the knob,
+# depthIndex bit-exact and image within 2e-4 of the oracle; knobs of the large-grid binning at 3840x2160 (8160 bins).
+_KNOBS = [("GSR_NO_GRAPH", "1", None), ("GSR_SORT_ORDER", "lsd", None), ("GSR_SORT_ORDER", "bucket", None), ("GSR_FUSE_COMBINE", "0", None),
+          ("GSR_SATURATE", "0", None), ("GSR_LONG_ITEMS", "0", None), ("GSR_LONG_ITEMS", "1", None), ("GSR_LONG_TAU", "20", None),
+          ("GSR_BLEND_SUB", "1", None), ("GSR_BLEND_SUB", "2", None), ("GSR_ITEMS_BY_SIZE", "0", None), ("GSR_SEG_TARGET", "200", None),
+          ("GSR_SEG_LEN", "256", None), ("GSR_BLEND_GRID", "64", None), ("GSR_SORT_KPB", "4096", None),
+          ("GSR_RECT_CARRY", "0", None), ("GSR_RECT_CARRY", "2", None), ("GSR_TIMING_EVERY", "3", None), ("GSR_CU_PARTS", "2", None),
+          ("GSR_BIN_TWO_LEVEL", "1", None), ("GSR_BIN_TWO_LEVEL", "0", "4k"), ("GSR_CELL_GRID", "64", "4k"), ("GSR_BIN_BIG", "0", "4k one level"),
+          ("GSR_BIN_BIG", "1", "4k one level"), ("GSR_BIN_ROUNDS", "2", "4k one level")]
+_KNOB_ORACLE = {}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("knob", _KNOBS, ids=["%s=%s%s" % (k, v, " " + w if w else "") for k, v, w in _KNOBS])
+def test_every_knob_at_a_non_default_value_matches_the_oracle(gh, oracle, scenes, monkeypatch, knob):
+    env, val, where = knob
+    cfg = gh.synth.CONFIGS["C1"]
+    rows, data, pos = scenes("C1")
+    W, H = (3840, 2160) if where else (cfg["width"], cfg["height"])
+    if where and "one level" in where and env != "GSR_BIN_TWO_LEVEL":
+        monkeypatch.setenv("GSR_BIN_TWO_LEVEL", "0")
+    monkeypatch.setenv(env, val)
+    r = gh.HIPRenderer(W, H, timing=env == "GSR_TIMING_EVERY")
+    r.set_raw_scene(data, pos)
+    for k in (11, 58):
+        cam = gh.orbit_camera(k, width=W, height=H, fx=cfg["fx"])
+        r.set_camera(cam)
+        r.render_async(); r.sync()
+        if (W, k) not in _KNOB_ORACLE:
+            v, p, vp = cam.f32()
+            _KNOB_ORACLE[(W, k)] = oracle.render_scene(data, pos, v, p, vp, cam.fx, cam.fy, W, H, mode=1)[:2]
+        oimg, odi = _KNOB_ORACLE[(W, k)]
+        assert np.array_equal(r.lastDepthIndex(), odi), (env, val, k)
+        err = np.abs(r.readPixelsFloat().astype(np.float64) - oimg.astype(np.float64)).max()
+        assert err <= TOL_EXACT, (env, val, k, err)
+    assert r.stats()["overflow_frames"] == 0
+    r.dispose()
