@@ -57,7 +57,6 @@ struct FrameState {  // small per-frame device words; initialised once (k_begin_
 struct gsr_ctx {
     int device = 0;
     int cu_count = 256;               // compute units of the device (the compositor's persistent grid is sized from it)
-    int cu_part = 0;                  // GSR_CU_PARTS: compute units of this context's share (0: the whole device)
     hipStream_t stream = nullptr;
     std::string error;
     gsr_options opt{};
@@ -99,7 +98,7 @@ struct gsr_ctx {
     int items_by_size = 1;            // work items heaviest first (k_bin_finalize); GSR_ITEMS_BY_SIZE
     bool fuse_combine = true;
     bool saturate = true;             // skip quadrants that can no longer change (GSR_SATURATE=0: composite every entry)
-    uint32_t long_tau_env = 0;        // GSR_LONG_TAU: the per-bin optical depth from which a bin is one work item (0: the built-in thresholds)
+    uint32_t long_tau_env = 0;        // GSR_LONG_TAU: the per-bin optical depth (true mass) from which a bin is one work item (0: the built-in rule)
     int long_items = -1;              // -1: long work items where the frame's optical depth says so (LONG_TAU), 0 / 1: pinned (GSR_LONG_ITEMS)
     uint32_t blend_sub = 1;           // compositor waves per 16x16 tile: 1 (k_blend) or 2 (k_blend2); alloc_bins, GSR_BLEND_SUB
     int blend_sub_env = 0;
@@ -287,6 +286,9 @@ constexpr uint32_t LOCAL_BUCKET_LIMIT = 48u << 10;
 // 8 % at tau 390), so the threshold there stays high.
 constexpr uint32_t SEG_LEN_LONG = 32768;   // (16384: C4 k_blend 437 instead of 405 us -- its heaviest bins hold 50-100 k entries; 65536 measures the same)
 constexpr uint32_t LONG_TAU_EXACT = 340, LONG_TAU_THROUGHPUT = 120;
+// a frame that is not dense as a whole: bins far past saturation become one item only where a list entry carries at least this
+// optical mass (pixels): C3 14, C2 8, 2 M tiny splats 1.9 -- one frame at a time a 3000-entry serial walk is the frame's tail
+constexpr uint32_t LONG_MASS_MIN_EXACT = 12, LONG_MASS_MIN_THROUGHPUT = 0;
 constexpr uint32_t LONG_TILES_X2_EXACT = 9;   // one frame at a time: and at least 4.5 tiles per visible splat (k_bin_finalize)
 constexpr uint32_t LONG_TILES_X2_THROUGHPUT = 6;   // with frames in flight: 3 (scripts/policy_check.py: 2 M tiny splats, 1.9 tiles each, tau 264:
                                                    // long items -26 %; the C2 generator, 3.6 tiles each: +10 % at the same tau)
@@ -392,7 +394,7 @@ int alloc_bins(gsr_ctx* c)
     const uint32_t want_items = want_segs;
     if (items_dirty || want_items > c->max_items) {
         c->max_items = want_items;
-        if (int r = dev_alloc(c, &c->items, c->max_items)) return r;
+        if (int r = dev_alloc(c, &c->items, (size_t)c->max_items * 4)) return r;   // (four words per work item: k_bin_finalize)
         if (c->seg_len != SEG_LEN_WHOLE_BIN) {
             if (int r = dev_alloc(c, &c->partial, (size_t)want_segs * BIN_PX * BIN_PX)) return r;
         }
@@ -427,7 +429,6 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
         SceneSoA sc{c->px, c->py, c->pz, c->cov0, c->cov1, c->cov2, c->rgba, c->sh_r, c->sh_g, c->sh_b, c->shcol};
         if (render) {
             c->proj = ProjectLaunch{sc, c->n, c->cam, 1, c->depth, c->slots, c->rec, nullptr, c->rect_idx, &c->fstate->overflow, {}};
-            c->cam_frame = c->cam;   // (gsr_read_records projects once more for this camera to get the pixel boxes)
             launch_project_key(c->proj, s);
         }
         else {   // a sort-only frame: its own slots (sets 1 and 2 in turn; set 0 belongs to the render frames and k_begin_frame)
@@ -461,9 +462,10 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
                       c->items, c->bin_list, &c->fstate->overflow, &c->fstate->visible, &c->fstate->tile_entries,
                       c->accum, c->mailbox_dev, c->fstate->report, c->bin_capacity, c->max_items, c->seg_len, &c->fstate->seg_len, c->items_by_size, &c->fstate->queue, std::min<uint32_t>(c->max_items, c->blend_grid), c->seg_target_items, c->bin_blocks, c->bin_mask,
                       c->seg_len == SEG_LEN_WHOLE_BIN ? 0 : c->long_items >= 0 ? c->long_items : c->saturate ? -1 : 0, SEG_LEN_LONG,
-                      c->long_tau_env ? c->long_tau_env : (c->opt.flags & GSR_FLAG_THROUGHPUT) ? LONG_TAU_THROUGHPUT : LONG_TAU_EXACT,
+                      (c->opt.flags & GSR_FLAG_THROUGHPUT) ? LONG_TAU_THROUGHPUT : LONG_TAU_EXACT,
                       (uint32_t)((g.bx_hi - g.bx_lo) * BIN_PX) * (uint32_t)c->H,
                       (c->opt.flags & GSR_FLAG_THROUGHPUT) ? LONG_TILES_X2_THROUGHPUT : LONG_TILES_X2_EXACT,
+                      c->long_tau_env, (c->opt.flags & GSR_FLAG_THROUGHPUT) ? LONG_MASS_MIN_THROUGHPUT : LONG_MASS_MIN_EXACT,
                       c->bin_two_level ? 1u : 0u, c->cell_list, c->cell_total, c->cell_start, c->chunk_start, c->chunk_info, c->cell_wcnt, c->cell_table2, c->cell_grid};
         launch_bin(bb, g, c->n, s);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BIN], s));
@@ -523,7 +525,7 @@ int enqueue_frame(gsr_ctx* c, bool render)
     }
     // stage timing is sampled: every timing_every-th frame carries the six events (each is a packet the command
     // processor has to retire; on short frames they cost more than they measure)
-    const bool timing = c->ev_valid && (c->frame_no++ % c->timing_every) == 0;
+    const bool timing = c->ev_valid && c->timing_every != 0xffffffffu && (c->frame_no++ % c->timing_every) == 0;   // (0xffffffff: no frame)
     if (timing) {
         if (c->ev_pending == gsr_ctx::EV_RING) { if (int r = finish_frame(c)) return r; }
         const int slot = (c->ev_head + c->ev_pending) % gsr_ctx::EV_RING;
@@ -539,6 +541,7 @@ int enqueue_frame(gsr_ctx* c, bool render)
     c->bucket_order_now = use_bucket_order(c);
     c->cam.sh_on = c->sh_count ? 1 : 0;
     c->cam.band[0] = c->band[0]; c->cam.band[1] = c->band[1]; c->cam.band[2] = c->band[2];
+    if (render) c->cam_frame = c->cam;   // (gsr_read_records projects once more for this camera to get the pixel boxes)
     // No kernel in front of the frame: the camera is an argument of the projection kernel (k_project_key; k_depth_key in a
     // sort-only frame), the frame slots are left clean by their last reader, the frame words are stored, not accumulated
     // (the overflow word is zeroed by k_project_key).  The context's first frame initialises all of them, once.
@@ -730,29 +733,10 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
         if (e_ != hipSuccess) { fail(c, GSR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); return bail(GSR_ERR_HIP); } \
     } while (0)
     CREATE_TRY(hipSetDevice(c->device));
-    {
-        // Experiment knob (frames in flight): GSR_CU_PARTS=k gives the process's contexts, in turn, one of k
-        // disjoint sets of compute units (hipExtStreamCreateWithCUMask; mask bits are dealt round-robin over the XCDs, so a
-        // contiguous range of bits is an equal share of every XCD): frames in flight then run side by side instead of taking
-        // turns on the whole chip.  Off by default (measured: profiles/r04_experiments.txt).
-        static int next_part = 0;
-        const char* e = getenv("GSR_CU_PARTS");
-        const int parts = e ? atoi(e) : 0;
-        int cus = 0;
-        if (parts >= 2 && parts <= 16 && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus >= parts) {
-            const int part = next_part++ % parts, per = cus / parts;
-            std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
-            for (int k = part * per; k < (part + 1) * per; k++) mask[(size_t)k / 32] |= 1u << (k % 32);
-            CREATE_TRY(hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data()));
-            c->cu_part = per;   // (the compositor's persistent grid is sized for the CUs the stream may use)
-        } else {
-            CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        }
-    }
+    CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0) c->cu_count = cus;
-        if (c->cu_part) c->cu_count = c->cu_part;
     }
     CREATE_TRY(hipMalloc((void**)&c->fstate, sizeof(FrameState)));
     CREATE_TRY(hipMalloc((void**)&c->cam_dev, sizeof(CamParams)));
@@ -770,7 +754,7 @@ int gsr_create(gsr_ctx** out, const gsr_options* opt)
     if (const char* e = getenv("GSR_BIN_BIG")) c->bin_big = (uint32_t)std::min(2, std::max(0, atoi(e)));
     if (const char* e = getenv("GSR_BIN_TWO_LEVEL")) c->bin_two_level_env = atoi(e) ? 1 : 0;
     if (const char* e = getenv("GSR_RECT_CARRY")) { c->rect_carry = atoi(e) != 0; c->rect_carry_bucket = atoi(e) == 2; }
-    if (const char* e = getenv("GSR_BLEND_SUB")) c->blend_sub_env = atoi(e) >= 1 && atoi(e) <= 3 ? atoi(e) : 0;   // (3: the first form of the two-waves-per-tile kernel, for A/B)
+    if (const char* e = getenv("GSR_BLEND_SUB")) c->blend_sub_env = atoi(e) == 2 ? 2 : atoi(e) == 1 ? 1 : 0;
     CREATE_TRY(hipMalloc((void**)&c->accum, 8 * sizeof(uint64_t)));
     CREATE_TRY(hipMemset(c->accum, 0, 8 * sizeof(uint64_t)));
     CREATE_TRY(hipHostMalloc((void**)&c->mailbox, 64, hipHostMallocMapped));

@@ -127,11 +127,12 @@ __device__ __forceinline__ uint32_t xcd_group_remap(uint32_t bid, uint32_t nwg)
 #define GSR_BOUND(name, site, idx, limit) do { } while (0)
 #endif
 
-// Compositor work items: bin | segment << 16.
+// Compositor work items: four words, (bin | segment << 16, first list entry, end, first partial slot of the bin | its segments << 25).
 constexpr uint32_t PROJ_THREADS = 256;
 constexpr int FRAME_SLOTS = 64;
 constexpr int FRAME_SLOT_WORDS = 32;   // words per slot (one 128-byte line): [0] min depth, [1] max depth, [2] visible, [3] tiles,
-                                       // [4] sum of opacity byte x tiles / 16 (the frame's optical depth, k_bin_finalize)
+                                       // [4] sum of opacity byte x tiles / 16 (the frame's optical depth over the splats' boxes, k_bin_finalize),
+                                       // [5] sum of opacity byte x footprint pixels / 256 (the optical mass the splats really carry)
 // the depth key and the min / max alone (sort-only frames): camera by value, its own frame slots, the next frame's reset
 void launch_depth_key(const SceneSoA& sc, uint32_t n, const CamParams& cam, int32_t* depth, int32_t* slots, int32_t* slots_next, hipStream_t s);
 // The projection kernel's launch as a value: its arguments and the pointer array hipLaunchKernel / a graph kernel node take.
@@ -197,7 +198,7 @@ struct BinBuffers {
     uint32_t big;                // large bin grids: 1 = k_bin_scatter_big (finalize as its first workgroup, rounds of 2048 ranks),
                                  // 2 = the same with rounds of 1024 ranks (half the step loops); 0 = the 64-register kernel (A/B knob)
     uint32_t* seg_start;         // nbins + 1: first compositor work item of each bin; [nbins] = item count
-    uint32_t* items;             // max_items: bin | segment << 16
+    uint32_t* items;             // max_items x 4 words: (bin | segment << 16, first list entry, end, first partial slot of the bin | its segments << 25)
     uint32_t* list;              // capacity entries (splat indices, depth order inside each bin)
     uint32_t* overflow;          // bit 0: list too small, bit 1: item table too small
     uint64_t* visible;           // V counter
@@ -221,6 +222,8 @@ struct BinBuffers {
     uint32_t seg_len_long, long_tau;
     uint32_t npix;               // pixels of this context's band (the optical depth is per pixel)
     uint32_t long_tiles_x2;      // long work items also need this many 16x16 tiles per visible splat, times two (0: no such condition)
+    uint32_t long_tau_bin;       // 0: the built-in per-bin thresholds (k_bin_finalize); else: bins from this optical depth on are one item (GSR_LONG_TAU)
+    uint32_t long_mass_min;      // a frame that is not dense as a whole: its saturated bins become items only from this optical mass per list entry on (pixels)
     // two-level binning (launch_bin; large bin grids): cells of 4 x 4 bins first, then the cell lists' chunks into the bins
     uint32_t two_level;          // 1: on (nblocks = workgroups of 2048 ranks, rounds = 1; table holds nblocks x (cells + 1) words)
     uint32_t* cell_list;         // 2 x capacity words: (splat index, rectangle in bins) per cell-list entry
@@ -235,7 +238,7 @@ struct BinBuffers {
 void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s);
 
 struct BlendBuffers {
-    const uint32_t* items;      // work items: bin | segment << 16
+    const uint32_t* items;      // work items, four words each (BinBuffers::items)
     const uint32_t* seg_start;  // nbins + 1
     const uint32_t* bin_start;  // nbins + 1
     const uint32_t* list;

@@ -222,7 +222,7 @@ struct FinalizeArgs {
     uint64_t* mailbox;
     unsigned long long* bin_mask;
     int long_policy; uint32_t seg_len_long, long_tau, npix;   // see BinBuffers
-    uint32_t long_tiles_x2;
+    uint32_t long_tiles_x2, long_tau_bin, long_mass_min;
 };
 constexpr int FIN_LAYERS = 64;   // segments per bin at most (one bit each in the bin's arrival mask, k_blend)
 constexpr int FIN_SCRATCH_WORDS = 64;   // LDS words the finalize step asks of its caller (none are used any more; kept so that every launch passes a non-zero size)
@@ -246,57 +246,77 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa, uint32
     __shared__ uint32_t s_w[5][FIN_WAVES];
     const int per = (nbins + FIN_THREADS - 1) / FIN_THREADS;
     const int b0 = threadIdx.x * per, b1 = min(b0 + per, nbins);
-    // two sums in one pass: the frame's list entries, and the projection's optical-depth figure (slots [4]: opacity byte x
-    // tiles / 16), which decides below whether this frame's work items are long
-    // (the optical-depth slots are summed as two 16-bit halves: a slot word holds up to 2^32 and there are 64 of them)
-    UN<3> ent = {{0, 0, 0}}, ent_tot;
-    for (int b = b0; b < b1; b++) ent.v[0] += bin_total[b];
+    // The frame's totals, in ONE exchange through LDS (this workgroup runs beside the scatter workgroups and must not be the last
+    // to finish; round 3 took three block-wide scans here -- six barriers -- where only sums were needed): list entries and the
+    // longest list over the bins (all threads), and the projection's slot sums (wave 0, one slot per lane): optical depth over
+    // the splats' boxes [4], optical mass [5], visible splats [2], tile overlaps [3].
+    __shared__ unsigned long long s_tot[FIN_WAVES];
+    __shared__ uint32_t s_mxb[FIN_WAVES];
+    __shared__ unsigned long long s_slot[4];
+    unsigned long long ent = 0;
+    uint32_t mxbin = 0;   // the longest bin list of the frame
+    for (int b = b0; b < b1; b++) { ent += bin_total[b]; mxbin = max(mxbin, bin_total[b]); }
+    unsigned long long sv[4] = {0, 0, 0, 0};
     if (have_counts && threadIdx.x < FRAME_SLOTS) {
-        const uint32_t od = (uint32_t)slots[(size_t)threadIdx.x * FRAME_SLOT_WORDS + 4];
-        ent.v[1] = od & 0xffffu; ent.v[2] = od >> 16;
+        const int32_t* sl = slots + (size_t)threadIdx.x * FRAME_SLOT_WORDS;
+        sv[0] = (uint32_t)sl[4]; sv[1] = (uint32_t)sl[5]; sv[2] = (uint32_t)sl[2]; sv[3] = (uint32_t)sl[3];
     }
-    block_exclusive_scan<3>(ent, s_w, &ent_tot);
-    const uint64_t optical = ((uint64_t)ent_tot.v[2] << 16) + ent_tot.v[1];
-    // Long work items where the frame saturates (gsr_api.cpp, "Work-item length"): the frame's optical depth
-    // tau = sum(opacity x tiles) x 256 / pixels from the projection's slots ([4] holds opacity byte x tiles / 16)
-    // frame counters: the projection's visible-splat and tile-overlap sums (scans of two or three streams keep this
-    // workgroup inside the 64 registers of k_bin_scatter, which it is an extra workgroup of; four-stream scans made it
-    // spill 60 registers and the bin stage 5 us longer on C2)
-    UN<2> cnt = {{0, 0}};
-    if (have_counts && threadIdx.x < FRAME_SLOTS) {
-        cnt.v[0] = (uint32_t)slots[(size_t)threadIdx.x * FRAME_SLOT_WORDS + 2];
-        cnt.v[1] = (uint32_t)slots[(size_t)threadIdx.x * FRAME_SLOT_WORDS + 3];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        ent += __shfl_xor(ent, off);
+        mxbin = max(mxbin, (uint32_t)__shfl_xor((int)mxbin, off));
+        if (threadIdx.x < WAVE) {   // (wave 0 only: uniform per wave)
+#pragma unroll
+            for (int k = 0; k < 4; k++) sv[k] += __shfl_xor(sv[k], off);
+        }
     }
-    UN<2> ctot;
-    block_exclusive_scan<2>(cnt, s_w, &ctot);
+    if ((threadIdx.x & 63) == 0) { s_tot[threadIdx.x >> 6] = ent; s_mxb[threadIdx.x >> 6] = mxbin; }
+    if (threadIdx.x == 0) { s_slot[0] = sv[0]; s_slot[1] = sv[1]; s_slot[2] = sv[2]; s_slot[3] = sv[3]; }
+    __syncthreads();
+    ent = 0;
+#pragma unroll
+    for (int w = 0; w < FIN_WAVES; w++) { ent += s_tot[w]; mxbin = max(mxbin, s_mxb[w]); }
+    struct { uint32_t v[3]; } ent_tot = {{(uint32_t)min(ent, 0xffffffffull), 0u, 0u}};
+    const uint64_t optical = s_slot[0];
+    const uint64_t mass = s_slot[1] * 256u / 255u;   // sum of opacity x footprint, in pixels
+    struct { uint32_t v[2]; } ctot = {{(uint32_t)s_slot[2], (uint32_t)s_slot[3]}};
     // dense enough to saturate: optical depth, and (one frame at a time, where the long items are the frame's tail) splats
     // that cover several tiles each -- small splats take many more entries to saturate a pixel (the C2 generator at
     // 1.6 M splats: tau 394, 3.6 tiles per splat, long items 8 % slower; C3: 5.3 tiles per splat, 23 % faster)
     const bool dense = optical * (16u * 256u) >= (uint64_t)fa.long_tau * 255u * (uint64_t)fa.npix &&
                        (uint64_t)ctot.v[1] * 2u >= (uint64_t)fa.long_tiles_x2 * ctot.v[0];
     // Which bins become ONE work item (gsr_api.cpp, "Work-item length").  A whole-bin item stops where the bin saturates, which
-    // pays where the bin holds much more than it takes to saturate it; a bin cut into segments is composited by several
-    // workgroups at once, which pays where it does not saturate.  A frame mixes both: a dense object in front of a sparse
-    // background (the real captures the reference is used with) has bins of either kind.  So the choice is made PER BIN, from
-    // the two figures the frame already has: a bin of c entries has the optical depth
-    //     tau_b = c x (frame's opacity x pixels per list entry) / 1024 = c x tau_frame x pixels / (1024 x E)
-    // (E = the frame's list entries; an entry's share taken as the frame's average), and it becomes one item from
-    // tau_b >= long_tau on, i.e. from  c >= long_from = long_tau x 255 x E / (4 x optical)  entries -- where the frame's splats
-    // cover several tiles each (`tiles`: small splats take many more entries to saturate a pixel than their boxes suggest).
-    // A function of the frame alone: deterministic, no feedback from earlier frames.  long_policy 1 / 0 pin all / no bins.
-    const bool tiles_ok = (uint64_t)ctot.v[1] * 2u >= (uint64_t)fa.long_tiles_x2 * ctot.v[0];
-    (void)dense;
+    // pays where the bin holds much more than it takes to saturate it -- and costs a serial pole as long as that takes; a bin cut
+    // into segments is composited by several workgroups at once, every segment in full.  A frame can mix both kinds of bins (a
+    // dense object in front of a sparse background), so the choice is made PER BIN, deterministically from figures of this
+    // frame alone (no feedback from earlier frames):
+    //  * the frame's prior, as before: `dense` (optical depth over the splats' boxes >= long_tau, and splats of several tiles
+    //    each) -- calibrated on the frame-wide choice, which it reproduces on single-blob scenes;
+    //  * a bin's own optical depth tau_b = c x (M / E) / 1024, c its entries, E the frame's entries, M the frame's optical mass
+    //    (sum of opacity x footprint pixels, slot word [5]: what the splats really carry, independent of how coarse their tile
+    //    boxes are) -- C3: up to 131 in the centre, 61 at the ninth decile; C2: 40 / 8; pixels stop changing around 20-25.
+    // In a dense frame every bin is one item except those far from saturating (tau_b < LONG_TAU_B_LO: its sparse rim or
+    // background, which is cut); in a frame that is not dense as a whole, bins that are several times past saturation
+    // (tau_b >= LONG_TAU_B_HI) still become one item -- the dense object in a sparse scene -- provided the frame's entries are
+    // heavy enough (M / E >= mass_min pixels: small splats saturate a pixel only after thousands of entries, a pole no skip
+    // pays for; one frame at a time only).  long_policy 1 / 0 pin all / no bins.
+    constexpr uint32_t LONG_TAU_B_LO = 8, LONG_TAU_B_HI = 60;
     uint32_t long_from = 0xffffffffu;                       // bins of at least this many entries are one work item
     if (seg_len_min < 0x40000000u) {
         if (fa.long_policy > 0) long_from = 0u;
-        else if (fa.long_policy < 0 && tiles_ok && optical > 0u)
-            long_from = (uint32_t)min((uint64_t)0xfffffff0u, ((uint64_t)fa.long_tau * 255u * (uint64_t)ent_tot.v[0] + 4u * optical - 1u) / (4u * optical));
+        else if (fa.long_policy < 0 && mass > 0u) {
+            const uint64_t E = ent_tot.v[0];
+            const uint32_t tb = fa.long_tau_bin ? fa.long_tau_bin : dense ? LONG_TAU_B_LO : LONG_TAU_B_HI;
+            const bool heavy = mass >= (uint64_t)fa.long_mass_min * E;
+            if (dense || heavy || fa.long_tau_bin)
+                long_from = (uint32_t)min((uint64_t)0xfffffff0u, ((uint64_t)tb * 1024u * E + mass - 1u) / mass);
+        }
     }
     const uint32_t seg_min = seg_len_min;
     // segment length of the bins that ARE cut (a multiple of 256; the whole-bin sentinel of early termination passes through)
     // work items are ordered heaviest first whenever whole-bin items can occur: the few that run long must not start late (three
     // frames in flight, C3: 4970 -> 5310 frames/s); plain short segments in throughput contexts stay in raster order (C2: 11 550 vs 11 250)
-    const bool by_size = fa.by_size != 0 || long_from != 0xffffffffu;
+    const bool by_size = fa.by_size != 0 || mxbin >= long_from;
     uint32_t seg_len = seg_min;
     if (seg_min < 0x40000000u)
         seg_len = min(max(ent_tot.v[0] / seg_target_items / 256u * 256u, seg_min), max(SEG_LEN_MAX, seg_min));
@@ -359,11 +379,17 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa, uint32
         seg_start[b] = fits ? sx : 0u;
         if (fa.bin_mask) fa.bin_mask[b] = 0ull;
         if (fits) {
+            // a work item says everything the compositor needs to start on it: (bin | segment << 16, first entry, end, the bin's
+            // first partial slot | its segments << 25) -- one 16-byte load behind the queue's atomic instead of an item word and
+            // then the bin's four table words
+            uint4* items4 = reinterpret_cast<uint4*>(items);
+            const uint32_t nseg = nf + (part ? 1u : 0u), w3 = sx | (nseg << 25);
             const uint32_t f0 = (by_size && nf) ? atomicAdd(&s_cls[cls_full], nf) : fx;
-            for (uint32_t k = 0; k < nf; k++) items[f0 + k] = (uint32_t)b | (k << 16);
+            for (uint32_t k = 0; k < nf; k++)
+                items4[f0 + k] = make_uint4((uint32_t)b | (k << 16), ex + k * seg_len, k + 1u == nseg ? ex + c : ex + (k + 1u) * seg_len, w3);
             if (part) {
                 const uint32_t pos = by_size ? atomicAdd(&s_cls[partial_class(r)], 1u) : p3++;
-                items[pos] = (uint32_t)b | (nf << 16);
+                items4[pos] = make_uint4((uint32_t)b | (nf << 16), ex + nf * seg_len, ex + c, w3);
             }
         }
         ex += c;
@@ -375,7 +401,7 @@ __device__ __forceinline__ void bin_finalize_body(const FinalizeArgs& fa, uint32
     // from), the counters <- 0 -- with its last stores, so that no kernel in front of a frame has to.
     if (have_counts && threadIdx.x < FRAME_SLOTS) {
         int32_t* sl = slots + (size_t)threadIdx.x * FRAME_SLOT_WORDS;
-        sl[0] = 0x7fffffff; sl[1] = (int32_t)0x80000000; sl[2] = 0; sl[3] = 0; sl[4] = 0;
+        sl[0] = 0x7fffffff; sl[1] = (int32_t)0x80000000; sl[2] = 0; sl[3] = 0; sl[4] = 0; sl[5] = 0;
     }
     if (threadIdx.x == 0) {
         *queue = queue_start;  // the compositor's workgroups take items 0..grid-1 by index, later ones from here
@@ -987,7 +1013,7 @@ static FinalizeArgs make_finalize_args(const BinBuffers& b, int nbins, uint32_t 
 {
     return FinalizeArgs{b.bin_total, nbins, b.seg_len, b.seg_target_items, b.items_by_size, b.seg_len_dev, b.max_items, b.capacity,
                         b.slots, n ? 1u : 0u, b.bin_start, b.seg_start, b.items, b.overflow, b.visible, b.tile_entries, b.accum,
-                        b.report, b.queue, b.queue_start, b.mailbox, b.bin_mask, b.long_policy, b.seg_len_long, b.long_tau, b.npix, b.long_tiles_x2};
+                        b.report, b.queue, b.queue_start, b.mailbox, b.bin_mask, b.long_policy, b.seg_len_long, b.long_tau, b.npix, b.long_tiles_x2, b.long_tau_bin, b.long_mass_min};
 }
 
 // cells across / down a grid of bins

@@ -91,7 +91,6 @@ __device__ __forceinline__ void blend_body(const uint32_t* __restrict__ items,
                                                          BinGrid g, float eps, const uint32_t* __restrict__ seg_len_dev, uint32_t capacity,
                                                          uint32_t nsplats, unsigned long long* __restrict__ bin_mask, uint32_t saturate)
 {
-    const uint32_t seg_len = *seg_len_dev;  // this frame's list entries per work item (k_bin_finalize)
     // [0]: ux, uy, -dot(u, c - bin origin), wx   [1]: wy, -dot(w, c - bin origin), log2(opacity), blue   [2]: red, green
     __shared__ float4 s_rec[3][CHUNK];   // one address register serves the three reads of an entry
     __shared__ uint32_t s_mask[CHUNK];
@@ -128,14 +127,15 @@ __device__ __forceinline__ void blend_body(const uint32_t* __restrict__ items,
         __syncthreads();
         const uint32_t qi = s_item;
         if (qi >= total_items) break;
-        const uint32_t it = items[qi];
+        const uint4 it4 = reinterpret_cast<const uint4*>(items)[qi];   // (bin | segment << 16, first entry, end, partial slot | segments << 25)
+        const uint32_t it = it4.x;
         const int bin = (int)(it & 0xffffu);
 #ifdef GSR_BLEND_STAMPS
         a_items++; a_item_t0 = (unsigned int)__builtin_amdgcn_s_memrealtime(); a_last_start = a_item_t0; a_item_vis0 = a_entries; a_item_bin = (unsigned int)bin; a_staged = 0;
 #endif
         const uint32_t seg = it >> 16;
         const int tile = wave;
-        const uint32_t nseg = seg_start[bin + 1] - seg_start[bin];
+        const uint32_t nseg = it4.w >> 25, slot0 = it4.w & 0x1ffffffu;
         GSR_BOUND(blend, 0, bin, nbxb * g.nby);
         GSR_BOUND(blend, 1, seg, nseg);
         const int by = bin / nbxb, bxl = bin - by * nbxb;
@@ -153,14 +153,12 @@ __device__ __forceinline__ void blend_body(const uint32_t* __restrict__ items,
         float g00 = 0.f, g10 = 0.f, g01 = 0.f, g11 = 0.f;
         float b00 = 0.f, b10 = 0.f, b01 = 0.f, b11 = 0.f;
 
-        const uint32_t bin_end = min(bin_start[bin + 1], capacity);
-        const uint32_t begin = min(bin_start[bin] + seg * seg_len, bin_end);
-        const uint32_t end = seg + 1u == nseg ? bin_end : min(begin + seg_len, bin_end);   // (a bin has at most 64 segments: the last takes the rest)
+        const uint32_t end = min(it4.z, capacity), begin = min(it4.y, end);   // (a bin has at most 64 segments: the last takes the rest)
         // only long items test for saturation while they run, and only where the transmittance is the true one: whole bins
         // and a bin's first segment (later segments start from 1)
         const bool sat_item = saturate != 0u && seg == 0u && end - begin > 2u * CHUNK;
-        GSR_BOUND(blend, 4, end, (unsigned long long)bin_end + 1ull);
-        GSR_BOUND(blend, 4, begin, (unsigned long long)end + 1ull);
+        GSR_BOUND(blend, 4, it4.z, (unsigned long long)capacity + 1ull);
+        GSR_BOUND(blend, 4, it4.y, (unsigned long long)it4.z + 1ull);
         // quadrants of mine that can still change (wave-uniform); see the saturation test below.  Quadrants that lie outside
         // the image (the last bin row of 1080p: rows 1080..1087) never could: their pixels are not stored.
         uint32_t alive0 = 0;
@@ -441,7 +439,7 @@ __device__ __forceinline__ void blend_body(const uint32_t* __restrict__ items,
         bool write_fb = nseg == 1u;
         if (nseg > 1u) {
             // ---- partial (colour, transmittance) of this segment, slot-major: fully coalesced ----
-            float4* p0 = partial + (size_t)seg_start[bin] * BIN_PIXELS + wave * (TILE * TILE) + lane;
+            float4* p0 = partial + (size_t)slot0 * BIN_PIXELS + wave * (TILE * TILE) + lane;
             float4* p = p0 + (size_t)seg * BIN_PIXELS;
             if (!FUSED) {   // k_combine folds the bin after this kernel
                 if (part == 0) {
@@ -531,485 +529,6 @@ __device__ __forceinline__ void blend_body(const uint32_t* __restrict__ items,
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Two waves per tile, second form (round 4): the same arithmetic, the same split of a chunk's hits between the two waves of
-// a tile and the same fold order as blend_body<2> -- the image is the same bit for bit -- with the workgroup's
-// synchronisation rebuilt around what the in-kernel stamps of the first form showed (profiles/r03_blend_stamps.txt: 62.7 %
-// of a wave's time in the composite loop, 13.4 % at the chunk-start barrier, 9.1 % staging, 2.1 % at the staged barrier,
-// 12.7 % between items):
-//  * TWO chunk buffers and ONE barrier per chunk.  While a chunk is composited the next one is staged into the other
-//    buffer, and the staging is not dealt out in advance: a wave that has finished its tile's share of the current chunk
-//    takes units of 64 entries of the next chunk from an LDS counter until none is left.  Waves of light tiles, which used
-//    to wait at the barrier for the heavy tile's wave, do the staging in that time; the heavy tile's wave finds nothing
-//    left to stage and goes straight to the barrier.
-//  * The fold of part 1's chunk partial is a hand-off between the two waves of a tile (an LDS flag part 0 waits for), in
-//    front of the barrier instead of behind it: part 0's saturation test sees the chunk it belongs to, the live quadrants
-//    reach part 1 for the very next chunk, and nothing of it is on the path behind the barrier.
-//  * The next work item is drawn early -- by one thread of a part-1 wave, when the current item is in its last chunk or
-//    half of its tiles have saturated -- so the atomic on the queue and the two dependent loads behind it (item, list
-//    bounds) run beside the compositing; and the next item's first chunk is staged by the part-1 waves, which have nothing
-//    to do in an item's epilogue, while part 0 stores / folds / writes the pixels.  An item boundary is one barrier.
-//    (Reserving at item START lost balance in the tail, round 1; this reserves for the length of a chunk or two.)
-// ---------------------------------------------------------------------------------------------------------------------
-struct ChunkLds {
-    float4 a[CHUNK];        // ux, uy, -dot(u, c - bin origin), wx
-    float4 b[CHUNK];        // wy, -dot(w, c - bin origin), log2(opacity), blue
-    float4 c[CHUNK];        // red, green (second half unused: one address register serves the three reads of an entry)
-    uint32_t mask[CHUNK];   // bit tile * 4 + quadrant: the bin's 8x8-pixel quadrants the splat can touch
-};
-enum { IT_QI = 0, IT_BIN, IT_SEG, IT_NSEG, IT_BEGIN, IT_END, IT_SLOT0, IT_WORDS = 8 };
-
-// one thread: work item qi -> its description in LDS (the compositor's view of k_bin_finalize's tables)
-__device__ __forceinline__ void fetch_item(uint32_t qi, uint32_t total_items, uint32_t* __restrict__ dst, const uint32_t* __restrict__ items,
-                                           const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ bin_start,
-                                           uint32_t seg_len, uint32_t capacity)
-{
-    if (qi < total_items) {
-        const uint32_t it = items[qi];
-        const uint32_t bin = it & 0xffffu, seg = it >> 16;
-        const uint32_t s0 = seg_start[bin], s1 = seg_start[bin + 1], b0 = bin_start[bin], b1 = bin_start[bin + 1];
-        const uint32_t nseg = s1 - s0;
-        const uint32_t bin_end = min(b1, capacity);
-        const uint32_t begin = min(b0 + seg * seg_len, bin_end);
-        const uint32_t end = seg + 1u == nseg ? bin_end : min(begin + seg_len, bin_end);   // (a bin has at most 64 segments: the last takes the rest)
-        GSR_BOUND(blend, 1, seg, nseg);
-        GSR_BOUND(blend, 4, end, (unsigned long long)bin_end + 1ull);
-        GSR_BOUND(blend, 4, begin, (unsigned long long)end + 1ull);
-        dst[IT_BIN] = bin; dst[IT_SEG] = seg; dst[IT_NSEG] = nseg; dst[IT_BEGIN] = begin; dst[IT_END] = end; dst[IT_SLOT0] = s0;
-    }
-    dst[IT_QI] = qi;
-}
-
-// one thread stages one list entry e (< end, else an empty slot) of a bin whose first pixel is (binX0, binY0) into `slot`:
-// the record in bin-relative form, the unpacked colour, and the 16-bit mask of the bin's quadrants the splat can touch -- a
-// conservative cull: a quadrant is dropped when it lies outside the oriented box |vPosition.x|, |vPosition.y| <= 2
-// (separating axes u, w) or farther from the centre than the longer semi-axis; pixels that pass are tested exactly (q <= 4)
-// in the walk.  (Same expressions as blend_body's staging.)
-// half < 0: the whole entry by one thread; half = 0 / 1: two threads per entry, each testing quadrant rows 2*half, 2*half + 1
-// (one byte of the mask) and writing its share of the record.
-__device__ __forceinline__ void stage_entry(ChunkLds& buf, uint32_t slot, uint32_t e, uint32_t end, int binX0, int binY0,
-                                            const uint32_t* __restrict__ list, const Record* __restrict__ rec,
-                                            const float4* __restrict__ shcol, uint32_t capacity, uint32_t nsplats, int half = -1)
-{
-    uint32_t mask = 0;
-    if (e < end) {
-        GSR_BOUND(blend, 2, e, capacity);
-        GSR_BOUND(blend, 3, list[e], nsplats);
-        const uint32_t i = min(list[e], nsplats - 1u);
-        const float4* rp = reinterpret_cast<const float4*>(rec + i);
-        const float4 ra = rp[0], rb = rp[1];
-        const float eu = 3.5f * (fabsf(ra.z) + fabsf(ra.w)) + 2.0005f;
-        const float ew = 3.5f * (fabsf(rb.x) + fabsf(rb.y)) + 2.0005f;
-        const float minlen2 = fminf(ra.z * ra.z + ra.w * ra.w, rb.x * rb.x + rb.y * rb.y);
-        float ucol[4], wcol[4], dcol[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const float dc = (float)(binX0 + 8 * k + 4) - ra.x;
-            ucol[k] = ra.z * dc; wcol[k] = rb.x * dc;
-            const float dd = fmaxf(fabsf(dc) - 3.5f, 0.0f);
-            dcol[k] = dd * dd;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            if (half >= 0 && (r >> 1) != half) continue;   // (uniform)
-            const float dc = (float)(binY0 + 8 * r + 4) - ra.y;
-            const float ur = ra.w * dc, wr = rb.y * dc;
-            const float dd = fmaxf(fabsf(dc) - 3.5f, 0.0f);
-            const float d2 = dd * dd;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const bool hit = fabsf(ucol[k] + ur) <= eu && fabsf(wcol[k] + wr) <= ew && (dcol[k] + d2) * minlen2 <= 4.002f;
-                // quadrant (k, r) of the bin -> tile (k>>1, r>>1), quadrant (k&1, r&1): bit tile*4 + quadrant
-                if (hit) mask |= 1u << (((((r >> 1) * 2) + (k >> 1)) << 2) + ((r & 1) * 2 + (k & 1)));
-            }
-        }
-        const float bx0c = (float)binX0 + 0.5f, by0c = (float)binY0 + 0.5f;
-        const float cxr = ra.x - bx0c, cyr = ra.y - by0c;
-        const uint32_t rgb8 = __float_as_uint(rb.w);
-        float cr = (float)(rgb8 & 0xffu) * (1.0f / 255.0f), cg = (float)((rgb8 >> 8) & 0xffu) * (1.0f / 255.0f),
-              cb = (float)((rgb8 >> 16) & 0xffu) * (1.0f / 255.0f);
-        if (rgb8 & RGB8_IN_SHCOL) {  // SH-coloured splat: the projection kernel evaluated its colour for this view
-            const float4 sc = shcol[i];
-            cr = sc.x; cg = sc.y; cb = sc.z;
-        }
-        if (half <= 0) {
-            const float ncw = -__builtin_fmaf(rb.y, cyr, rb.x * cxr);
-            buf.b[slot] = make_float4(rb.y, ncw, rb.z, cb);
-            *reinterpret_cast<float2*>(&buf.c[slot]) = make_float2(cr, cg);
-        }
-        if (half != 0) {
-            const float ncu = -__builtin_fmaf(ra.w, cyr, ra.z * cxr);
-            buf.a[slot] = make_float4(ra.z, ra.w, ncu, rb.x);
-        }
-    }
-    if (half < 0) buf.mask[slot] = mask;
-    else reinterpret_cast<uint8_t*>(buf.mask)[slot * 4u + (uint32_t)half] = (uint8_t)(mask >> (8 * half));   // (bytes 2, 3 are never read)
-}
-
-template <bool FUSED>
-__device__ __forceinline__ void blend2_body(const uint32_t* __restrict__ items, const uint32_t* __restrict__ seg_start,
-                                            const uint32_t* __restrict__ bin_start, const uint32_t* __restrict__ list,
-                                            const Record* __restrict__ rec, const float4* __restrict__ shcol, float4* __restrict__ fb,
-                                            float4* __restrict__ partial, uint32_t* __restrict__ queue, BinGrid g, float eps,
-                                            const uint32_t* __restrict__ seg_len_dev, uint32_t capacity, uint32_t nsplats,
-                                            unsigned long long* __restrict__ bin_mask, uint32_t saturate)
-{
-    const uint32_t seg_len = seg_len_dev[0];       // this frame's list entries per work item (k_bin_finalize)
-    const uint32_t total_items = seg_len_dev[1];   // the frame's work items
-    __shared__ ChunkLds s_buf[2];
-    __shared__ float s_part[4 * 16 * WAVE];        // part 1's chunk partial: [tile][4 pixels x (r, g, b, T)][lane]
-    __shared__ uint32_t s_it[2][IT_WORDS];         // the current work item and the one drawn ahead
-    __shared__ uint32_t s_unit[2];                 // per chunk buffer: the next unit of 64 entries to stage into it
-    __shared__ uint32_t s_state[2][4];             // per chunk parity and tile: part 0's live quadrants | done << 4, after the chunk's fold
-    __shared__ uint32_t s_ready[4];                // per tile: chunks whose part-1 partial is in s_part (counted over the workgroup's life)
-    __shared__ uint32_t s_last;
-
-    const int nbxb = g.bx_hi - g.bx_lo;
-    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, part = (int)(threadIdx.x >> 8);   // (tile, half of a chunk's hits)
-    const int lx = lane & 7, ly = lane >> 3;
-    const int mask_shift = wave * 4;               // my tile's nibble of an entry's quadrant mask
-    uint32_t gen = 0;                              // chunks this pair of waves has composited (the hand-off flag's value)
-#ifdef GSR_BLEND_STAMPS
-    unsigned int a_waitA = 0, a_stage = 0, a_waitB = 0, a_comp = 0, a_entries = 0, a_staged = 0;
-    unsigned int a_items = 0, a_last_start = 0, a_max_dur = 0, a_max_len = 0, a_max_vis = 0, a_max_bin = 0, a_item_t0 = 0, a_item_vis0 = 0, a_item_len = 0, a_item_bin = 0;
-    const unsigned int t_kernel0 = (unsigned int)__builtin_readcyclecounter();
-    const unsigned int t_real0 = (unsigned int)__builtin_amdgcn_s_memrealtime();
-#endif
-    // The first item of a workgroup is its own index (the queue starts at gridDim.x, k_bin_finalize sets it).
-    if (threadIdx.x == 0) {
-        fetch_item(blockIdx.x, total_items, s_it[0], items, seg_start, bin_start, seg_len, capacity);
-        s_unit[0] = 0; s_unit[1] = 0;
-    }
-    if (threadIdx.x < 4) s_ready[threadIdx.x] = 0;
-    __syncthreads();
-    if (s_it[0][IT_QI] < total_items) {   // its first chunk: two threads per entry
-        const int bin0 = (int)s_it[0][IT_BIN];
-        const int by0 = bin0 / nbxb;
-        stage_entry(s_buf[0], threadIdx.x & (CHUNK - 1), s_it[0][IT_BEGIN] + (threadIdx.x & (CHUNK - 1)), s_it[0][IT_END],
-                    (g.bx_lo + bin0 - by0 * nbxb) * BIN_PX, by0 * BIN_PX, list, rec, shcol, capacity, nsplats, part);
-    }
-    __syncthreads();
-
-    int cur = 0;
-    for (;;) {
-        const uint32_t qi = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_it[cur][IT_QI]);
-        if (qi >= total_items) break;
-        const int bin = __builtin_amdgcn_readfirstlane((int)s_it[cur][IT_BIN]);
-        const uint32_t seg = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_it[cur][IT_SEG]);
-        const uint32_t nseg = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_it[cur][IT_NSEG]);
-        const uint32_t begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_it[cur][IT_BEGIN]);
-        const uint32_t end = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_it[cur][IT_END]);
-        const uint32_t slot0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_it[cur][IT_SLOT0]);
-        GSR_BOUND(blend, 0, bin, nbxb * g.nby);
-        const int by = bin / nbxb, bxl = bin - by * nbxb;
-        const int binX0 = (g.bx_lo + bxl) * BIN_PX, binY0 = by * BIN_PX;
-        const int ox = (wave & 1) * TILE, oy = (wave >> 1) * TILE;
-        const int X0 = binX0 + ox, Y0 = binY0 + oy;
-        // pixel centres relative to the centre of the bin's first pixel: small exact integers
-        const float pxf0 = (float)(ox + lx), pxf1 = pxf0 + 8.0f;
-        const float pyf0 = (float)(oy + ly), pyf1 = pyf0 + 8.0f;
-#ifdef GSR_BLEND_STAMPS
-        a_items++; a_item_t0 = (unsigned int)__builtin_amdgcn_s_memrealtime(); a_last_start = a_item_t0; a_item_vis0 = a_entries; a_item_bin = (unsigned int)bin; a_staged = 0;
-        a_item_len = end - begin;
-#endif
-        float T00 = 1.f, T10 = 1.f, T01 = 1.f, T11 = 1.f;  // Tij: pixel (x+8i, y+8j); 1 - alpha
-        float r00 = 0.f, r10 = 0.f, r01 = 0.f, r11 = 0.f;
-        float g00 = 0.f, g10 = 0.f, g01 = 0.f, g11 = 0.f;
-        float b00 = 0.f, b10 = 0.f, b01 = 0.f, b11 = 0.f;
-        // only long items test for saturation while they run, and only where the transmittance is the true one: whole bins
-        // and a bin's first segment (later segments start from 1)
-        const bool sat_item = saturate != 0u && seg == 0u && end - begin > 2u * CHUNK;
-        // quadrants of mine that can still change (wave-uniform).  Quadrants that lie outside the image (the last bin row of
-        // 1080p: rows 1080..1087) never could: their pixels are not stored.
-        uint32_t alive0 = 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (X0 + 8 * (q & 1) < g.W && Y0 + 8 * (q >> 1) < g.H) alive0 |= 1u << q;
-        uint32_t alive = alive0;
-        bool done = alive0 == 0u;
-        // tiles of the bin that have nothing to draw from the start (outside the image)
-        uint32_t ndone = 0;
-#pragma unroll
-        for (int t = 0; t < 4; t++) ndone += (binX0 + (t & 1) * TILE < g.W && binY0 + (t >> 1) * TILE < g.H) ? 0u : 1u;
-
-        // fold part 1's chunk partial (LDS) behind part 0's state: C += T*C', T *= T'
-#define GSR_FOLD_PART()                                                                                                  \
-    {                                                                                                                    \
-        const float* sp_ = s_part + wave * (16 * WAVE) + lane;                                                           \
-        r00 = __builtin_fmaf(T00, sp_[0 * WAVE], r00); g00 = __builtin_fmaf(T00, sp_[1 * WAVE], g00); b00 = __builtin_fmaf(T00, sp_[2 * WAVE], b00); T00 = T00 * sp_[3 * WAVE];       \
-        r10 = __builtin_fmaf(T10, sp_[4 * WAVE], r10); g10 = __builtin_fmaf(T10, sp_[5 * WAVE], g10); b10 = __builtin_fmaf(T10, sp_[6 * WAVE], b10); T10 = T10 * sp_[7 * WAVE];       \
-        r01 = __builtin_fmaf(T01, sp_[8 * WAVE], r01); g01 = __builtin_fmaf(T01, sp_[9 * WAVE], g01); b01 = __builtin_fmaf(T01, sp_[10 * WAVE], b01); T01 = T01 * sp_[11 * WAVE];    \
-        r11 = __builtin_fmaf(T11, sp_[12 * WAVE], r11); g11 = __builtin_fmaf(T11, sp_[13 * WAVE], g11); b11 = __builtin_fmaf(T11, sp_[14 * WAVE], b11); T11 = T11 * sp_[15 * WAVE];  \
-    }
-        // the saturation test of blend_body (see there): a quadrant whose 64 pixels can no longer change a bit leaves `alive`
-#define GSR_FINISHED(BIT, T, R, G, B_)                                                                          \
-    if ((alive & (BIT)) && __ballot((T) >= NEAR) == 0ull &&                                                      \
-        __ballot(!((T) < K * fminf((R), fminf((G), (B_))) || (T) == 0.0f)) == 0ull)                              \
-        alive &= ~(BIT);
-#define GSR_SAT_TEST()                                                                                           \
-    {                                                                                                            \
-        constexpr float K = 0x1p-27f, NEAR = 1e-6f;   /* nothing above NEAR can pass the test: a cheap filter first */ \
-        GSR_FINISHED(1u, T00, r00, g00, b00)                                                                     \
-        GSR_FINISHED(2u, T10, r10, g10, b10)                                                                     \
-        GSR_FINISHED(4u, T01, r01, g01, b01)                                                                     \
-        GSR_FINISHED(8u, T11, r11, g11, b11)                                                                     \
-    }
-        const uint32_t nch = (end - begin + CHUNK - 1u) / CHUNK;
-        bool fetched = false;   // the next work item has been drawn (uniform)
-        int bi = 0;             // the buffer that holds the chunk being composited
-        for (uint32_t c = 0; c < nch; c++) {
-            STAMP(t_c0);
-            // ---- behind the barrier that ended the previous chunk: every tile's state after that chunk is in s_state ----
-            if (c > 0) {
-                const uint32_t s0 = s_state[(c - 1u) & 1u][0], s1 = s_state[(c - 1u) & 1u][1], s2 = s_state[(c - 1u) & 1u][2], s3 = s_state[(c - 1u) & 1u][3];
-                ndone = (uint32_t)__builtin_amdgcn_readfirstlane((int)((s0 >> 4) + (s1 >> 4) + (s2 >> 4) + (s3 >> 4)));
-                if (part == 1) {   // my tile's live quadrants, as its part-0 wave left them after the previous chunk
-                    const uint32_t st = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave == 0 ? s0 : wave == 1 ? s1 : wave == 2 ? s2 : s3));
-                    alive = st & 15u;
-                    done = (st >> 4) != 0u;
-                }
-            }
-            if (ndone == 4u) break;   // every tile of the bin is saturated (the chunk just staged is not needed)
-            if (threadIdx.x == 0) s_unit[bi] = 0;   // (the counter of the buffer composited now: staged into again in the next iteration)
-#ifdef GSR_BLEND_STAMPS
-            a_staged = min((c + 1u) * CHUNK, end - begin);
-#endif
-            const ChunkLds& cb = s_buf[bi];
-            const uint32_t base = begin + c * CHUNK;
-            STAMP(t_cA);
-            if (!done) {
-                const uint32_t cnt = min((uint32_t)CHUNK, end - base);
-                // part 0 takes the first half of the chunk's entries that touch the tile, part 1 the second half -- by count, so
-                // that the two waves walk about equally long, and by the entries' masks ALONE: were the live quadrants taken into
-                // account, the cut -- and with it the f32 association of pixels that are still live -- would depend on what the
-                // saturation skip has dropped, which must not change a bit
-                uint32_t hits_half = 0, hits_before = 0;
-                {
-                    uint32_t h = 0;
-#pragma unroll
-                    for (uint32_t c0 = 0; c0 < CHUNK; c0 += WAVE) h += (uint32_t)__popcll(__ballot(((cb.mask[c0 + lane] >> mask_shift) & alive0) != 0u));
-                    hits_half = (h + 1u) >> 1;
-                }
-                for (uint32_t c0 = 0; c0 < cnt; c0 += WAVE) {
-                    const uint32_t touch = (cb.mask[c0 + lane] >> mask_shift) & alive0;
-                    const uint32_t mine = touch & alive;  // entry (c0+lane) vs my live quadrants
-                    const uint64_t all = __ballot(touch != 0u);
-                    const uint32_t rank = hits_before + __builtin_amdgcn_mbcnt_hi((uint32_t)(all >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)all, 0u));
-                    hits_before += (uint32_t)__popcll(all);
-                    uint64_t bal = __ballot(mine != 0u && (rank < hits_half) == (part == 0));
-#ifdef GSR_BLEND_STAMPS
-                    a_entries += __popcll(bal);
-#endif
-#define GSR_QUAD(BIT, PX, UR, WR, T, R, G, B_)                                                     \
-    if (GSR_QUAD_HIT(BIT)) {                                                                       \
-        const float vx_ = __builtin_fmaf(ux, (PX), (UR)), vy_ = __builtin_fmaf(wx, (PX), (WR));    \
-        const float q_ = __builtin_fmaf(vy_, vy_, vx_ * vx_);                                      \
-        if (q_ <= 4.0f) {                                                                          \
-            const float w_ = (T) * __builtin_amdgcn_exp2f(__builtin_fmaf(q_, -LOG2E, la));         \
-            (T) = (T) - w_;                                                                        \
-            (R) = __builtin_fmaf(w_, cr, (R));                                                     \
-            (G) = __builtin_fmaf(w_, cg, (G));                                                     \
-            (B_) = __builtin_fmaf(w_, cb_, (B_));                                                  \
-        }                                                                                          \
-    }
-                    // vPosition = (ux*px + (uy*py - dot(u,c)), wx*px + (wy*py - dot(w,c))), all bin-relative (frag.glsl.ts:15-20)
-                    const uint64_t bq0 = __ballot((mine & 1u) != 0u), bq1 = __ballot((mine & 2u) != 0u),
-                                   bq2 = __ballot((mine & 4u) != 0u), bq3 = __ballot((mine & 8u) != 0u);
-#define GSR_QUAD_HIT(BIT) ((((BIT) == 1u ? bq0 : (BIT) == 2u ? bq1 : (BIT) == 4u ? bq2 : bq3) >> j) & 1ull)
-                    while (bal) {
-                        const int j = __builtin_ctzll(bal);
-                        bal &= ~(1ull << j);
-                        const float4 RA = cb.a[c0 + j], RB = cb.b[c0 + j];
-                        const float2 RC = *reinterpret_cast<const float2*>(&cb.c[c0 + j]);
-                        const float ux = RA.x, uy = RA.y, ncu = RA.z, wx = RA.w, wy = RB.x, ncw = RB.y, la = RB.z;
-                        const float cr = RC.x, cg = RC.y, cb_ = RB.w;
-                        const float ur0 = __builtin_fmaf(uy, pyf0, ncu), ur1 = __builtin_fmaf(uy, pyf1, ncu);
-                        const float wr0 = __builtin_fmaf(wy, pyf0, ncw), wr1 = __builtin_fmaf(wy, pyf1, ncw);
-                        GSR_QUAD(1u, pxf0, ur0, wr0, T00, r00, g00, b00)
-                        GSR_QUAD(2u, pxf1, ur0, wr0, T10, r10, g10, b10)
-                        GSR_QUAD(4u, pxf0, ur1, wr1, T01, r01, g01, b01)
-                        GSR_QUAD(8u, pxf1, ur1, wr1, T11, r11, g11, b11)
-                    }
-#undef GSR_QUAD_HIT
-#undef GSR_QUAD
-                }
-            }
-            STAMP(t_cS);
-            // ---- the hand-off inside the tile: part 1's half of the chunk, from (colour 0, transmittance 1), goes through LDS;
-            //      part 0 folds it behind its own state, runs the tests that need the true state, and publishes the tile's state ----
-            gen++;
-            if (part == 1) {
-                float* sp = s_part + wave * (16 * WAVE) + lane;
-                sp[0 * WAVE] = r00; sp[1 * WAVE] = g00; sp[2 * WAVE] = b00; sp[3 * WAVE] = T00;
-                sp[4 * WAVE] = r10; sp[5 * WAVE] = g10; sp[6 * WAVE] = b10; sp[7 * WAVE] = T10;
-                sp[8 * WAVE] = r01; sp[9 * WAVE] = g01; sp[10 * WAVE] = b01; sp[11 * WAVE] = T01;
-                sp[12 * WAVE] = r11; sp[13 * WAVE] = g11; sp[14 * WAVE] = b11; sp[15 * WAVE] = T11;
-                r00 = r10 = r01 = r11 = 0.f; g00 = g10 = g01 = g11 = 0.f; b00 = b10 = b01 = b11 = 0.f;
-                T00 = T10 = T01 = T11 = 1.f;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the partial is in LDS before the flag says so
-                if (lane == 0) __hip_atomic_store(&s_ready[wave], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            } else {
-                while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&s_ready[wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != gen)
-                    __builtin_amdgcn_s_sleep(1);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                if (!done) {
-                    GSR_FOLD_PART()
-                    if (eps > 0.0f) {
-                        const float tmax = fmaxf(fmaxf(T00, T10), fmaxf(T01, T11));
-                        if (__ballot(tmax >= eps) == 0ull) alive = 0u;
-                    }
-                    // (not after an item's first chunk -- nothing saturates within SAT_FROM entries -- and not after its last)
-                    if (sat_item && c > 0u && c + 1u < nch) GSR_SAT_TEST()
-                    if (alive == 0u) done = true;
-                }
-                if (lane == 0) s_state[c & 1u][wave] = alive | (done ? 16u : 0u);
-            }
-            STAMP(t_cB);
-            // ---- draw the next work item early -- when the item is within two chunks of its end or half of its tiles have
-            //      saturated --: one wave's first lane walks the chain atomic -> item -> list bounds (three round trips) while the
-            //      other waves stage the next chunk; that wave takes no staging unit this time ----
-            const bool draw_now = !fetched && (c + 2u >= nch || ndone >= 2u);
-            if (draw_now) {
-                if (threadIdx.x == CHUNK) fetch_item(atomicAdd(queue, 1u), total_items, s_it[cur ^ 1], items, seg_start, bin_start, seg_len, capacity);
-                fetched = true;
-            }
-            // ---- stage the next chunk into the other buffer: whoever is free takes the next unit -- 64 entries, two of the four
-            //      quadrant rows (8 units per chunk, as many as waves) ----
-            if (c + 1u < nch && !(draw_now && part == 1 && wave == 0)) {
-                ChunkLds& nb = s_buf[bi ^ 1];
-                for (;;) {
-                    uint32_t u = 0;
-                    if (lane == 0) u = atomicAdd(&s_unit[bi ^ 1], 1u);
-                    u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
-                    if (u >= 2u * (uint32_t)(CHUNK / WAVE)) break;
-                    const uint32_t grp = u >> 1;
-                    if (u & 1u) stage_entry(nb, grp * WAVE + lane, base + CHUNK + grp * WAVE + lane, end, binX0, binY0, list, rec, shcol, capacity, nsplats, 1);
-                    else stage_entry(nb, grp * WAVE + lane, base + CHUNK + grp * WAVE + lane, end, binX0, binY0, list, rec, shcol, capacity, nsplats, 0);
-                }
-            }
-            STAMP(t_cC);
-            __syncthreads();
-#ifdef GSR_BLEND_STAMPS
-            {
-                const unsigned int t_cD = (unsigned int)__builtin_readcyclecounter();
-                a_waitA += t_cD - t_cC; a_stage += t_cC - t_cB; a_waitB += t_cB - t_cS; a_comp += t_cS - t_cA;
-                (void)t_c0;
-            }
-#endif
-            bi ^= 1;
-        }
-#undef GSR_SAT_TEST
-#undef GSR_FINISHED
-#undef GSR_FOLD_PART
-        // ---- the item is over (every wave is behind a barrier; part 0's state holds the folded result) ----
-        // Part 1 has nothing to do in the epilogue: it gets the next item going -- its first chunk staged into buffer 0 when the
-        // item was drawn early, the draw itself otherwise (then the chunk is staged behind the barrier below).
-        const uint32_t nqi = fetched ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_it[cur ^ 1][IT_QI]) : 0xffffffffu;
-        if (part == 1) {
-            if (!fetched) {
-                if (threadIdx.x == CHUNK) fetch_item(atomicAdd(queue, 1u), total_items, s_it[cur ^ 1], items, seg_start, bin_start, seg_len, capacity);
-            } else if (nqi < total_items) {
-                const int nbin = (int)s_it[cur ^ 1][IT_BIN];
-                const int nby_ = nbin / nbxb;
-                stage_entry(s_buf[0], threadIdx.x & (CHUNK - 1), s_it[cur ^ 1][IT_BEGIN] + (threadIdx.x & (CHUNK - 1)), s_it[cur ^ 1][IT_END],
-                            (g.bx_lo + nbin - nby_ * nbxb) * BIN_PX, nby_ * BIN_PX, list, rec, shcol, capacity, nsplats);
-            }
-        }
-#ifdef GSR_BLEND_STAMPS
-        {
-            const unsigned int d = (unsigned int)__builtin_amdgcn_s_memrealtime() - a_item_t0;
-            if (d > a_max_dur) { a_max_dur = d; a_max_len = a_item_len; a_max_vis = a_entries - a_item_vis0; a_max_bin = a_item_bin; }
-            if (nseg == 1u && bin < 16384 && lane == 0 && part == 0) {
-                unsigned int* bi_ = g_bin_info + (size_t)bin * 8;
-                bi_[2 + wave] = a_entries - a_item_vis0;
-                if (wave == 0) { bi_[0] = end - begin; bi_[1] = a_staged; bi_[6] = d; bi_[7] = a_item_t0; }
-            }
-        }
-#endif
-        bool write_fb = nseg == 1u;
-        if (nseg > 1u) {   // (uniform) see blend_body: partial of this segment; the workgroup that delivers the bin's last one folds the bin
-            float4* p0 = partial + (size_t)slot0 * BIN_PIXELS + wave * (TILE * TILE) + lane;
-            float4* p = p0 + (size_t)seg * BIN_PIXELS;
-            if (!FUSED) {
-                if (part == 0) {
-                    p[0] = make_float4(r00, g00, b00, T00);
-                    p[64] = make_float4(r10, g10, b10, T10);
-                    p[128] = make_float4(r01, g01, b01, T01);
-                    p[192] = make_float4(r11, g11, b11, T11);
-                }
-            } else {
-                typedef float v4f __attribute__((ext_vector_type(4)));
-                if (part == 0) {
-                    const v4f o0 = {r00, g00, b00, T00}, o1 = {r10, g10, b10, T10}, o2 = {r01, g01, b01, T01}, o3 = {r11, g11, b11, T11};
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:1024 sc1\n\t"
-                                 "global_store_dwordx4 %0, %3, off offset:2048 sc1\n\tglobal_store_dwordx4 %0, %4, off offset:3072 sc1\n\t"
-                                 "s_waitcnt vmcnt(0)"
-                                 :: "v"(p), "v"(o0), "v"(o1), "v"(o2), "v"(o3) : "memory");
-                }
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    const unsigned long long bit = 1ull << seg, all = nseg >= 64u ? ~0ull : (1ull << nseg) - 1ull;
-                    const unsigned long long now = __hip_atomic_fetch_or(&bin_mask[bin], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | bit;
-                    if (now == all) {
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    }
-                    s_last = now == all ? 1u : 0u;
-                }
-                __syncthreads();
-                if (s_last) {   // (uniform) fold, front to back: C = C0 + T0*C1 + T0*T1*C2 + ..., T = T0*T1*...
-                    r00 = r10 = r01 = r11 = 0.f; g00 = g10 = g01 = g11 = 0.f; b00 = b10 = b01 = b11 = 0.f;
-                    T00 = T10 = T01 = T11 = 1.f;
-                    for (uint32_t k = 0; k < (part == 0 ? nseg : 0u); k++) {
-                        v4f v0, v1, v2, v3;
-                        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
-                                     "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:3072 sc1\n\t"
-                                     "s_waitcnt vmcnt(0)"
-                                     : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(p0 + (size_t)k * BIN_PIXELS) : "memory");
-                        r00 = __builtin_fmaf(T00, v0.x, r00); g00 = __builtin_fmaf(T00, v0.y, g00); b00 = __builtin_fmaf(T00, v0.z, b00); T00 = T00 * v0.w;
-                        r10 = __builtin_fmaf(T10, v1.x, r10); g10 = __builtin_fmaf(T10, v1.y, g10); b10 = __builtin_fmaf(T10, v1.z, b10); T10 = T10 * v1.w;
-                        r01 = __builtin_fmaf(T01, v2.x, r01); g01 = __builtin_fmaf(T01, v2.y, g01); b01 = __builtin_fmaf(T01, v2.z, b01); T01 = T01 * v2.w;
-                        r11 = __builtin_fmaf(T11, v3.x, r11); g11 = __builtin_fmaf(T11, v3.y, g11); b11 = __builtin_fmaf(T11, v3.z, b11); T11 = T11 * v3.w;
-                    }
-                    write_fb = true;
-                }
-            }
-        }
-        if (write_fb && part == 0) {
-            // ---- write the tile, premultiplied RGBA, alpha = 1 - T ----
-            const int x0 = X0 + lx, x1 = x0 + 8, y0 = Y0 + ly, y1 = y0 + 8;
-            if (y0 < g.H) {
-                if (x0 < g.W) fb[(size_t)y0 * g.W + x0] = make_float4(r00, g00, b00, 1.0f - T00);
-                if (x1 < g.W) fb[(size_t)y0 * g.W + x1] = make_float4(r10, g10, b10, 1.0f - T10);
-            }
-            if (y1 < g.H) {
-                if (x0 < g.W) fb[(size_t)y1 * g.W + x0] = make_float4(r01, g01, b01, 1.0f - T01);
-                if (x1 < g.W) fb[(size_t)y1 * g.W + x1] = make_float4(r11, g11, b11, 1.0f - T11);
-            }
-        }
-        if (threadIdx.x == 0) { s_unit[0] = 0; s_unit[1] = 0; }
-        __syncthreads();   // the item boundary: the next item's description (and, drawn early, its first chunk) is in LDS
-        cur ^= 1;
-        if (!fetched) {    // (uniform) drawn late: its first chunk now
-            if (s_it[cur][IT_QI] < total_items) {
-                const int nbin = (int)s_it[cur][IT_BIN];
-                const int nby_ = nbin / nbxb;
-                stage_entry(s_buf[0], threadIdx.x & (CHUNK - 1), s_it[cur][IT_BEGIN] + (threadIdx.x & (CHUNK - 1)), s_it[cur][IT_END],
-                            (g.bx_lo + nbin - nby_ * nbxb) * BIN_PX, nby_ * BIN_PX, list, rec, shcol, capacity, nsplats, part);
-            }
-            __syncthreads();
-        }
-    }
-#ifdef GSR_BLEND_STAMPS
-    if (lane == 0 && blockIdx.x < 4096 && part == 0) {
-        unsigned int* o = g_blend_stamps + ((size_t)blockIdx.x * 4 + wave) * 16;
-        o[0] = (unsigned int)__builtin_readcyclecounter() - t_kernel0; o[1] = a_waitA; o[2] = a_stage; o[3] = a_waitB; o[4] = a_comp;
-        o[5] = t_real0; o[6] = (unsigned int)__builtin_amdgcn_s_memrealtime(); o[7] = a_entries;
-        o[8] = a_items; o[9] = a_last_start; o[10] = a_max_dur; o[11] = a_max_len; o[12] = a_max_vis; o[13] = a_max_bin;
-    }
-#endif
-}
-
 // 7 waves per SIMD: the kernel needs 74 VGPRs unconstrained (6 waves); capped at 72 it spills one register pair that is
 // stored once per workgroup and reloaded once per work item, and the seventh wave hides more of the LDS/barrier
 // waits (measured: k_blend -5.7 % alone; 8 waves = 64 VGPRs spills inside the loops and is no better).
@@ -1027,11 +546,6 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
 // two waves per tile: 512-thread workgroups, three per CU (6 waves per SIMD, 80 registers)
 __global__ __launch_bounds__(2 * BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_blend2(GSR_BLEND_PARAMS)
 {
-    blend2_body<true>(GSR_BLEND_ARGS);
-}
-// (the first form of the two-waves-per-tile kernel, for the A/B of the two: GSR_BLEND2_V1=1)
-__global__ __launch_bounds__(2 * BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_blend2_v1(GSR_BLEND_PARAMS)
-{
     blend_body<2, true>(GSR_BLEND_ARGS);
 }
 // the same two with the partials left to k_combine (GSR_FUSE_COMBINE=0; test reference)
@@ -1041,7 +555,7 @@ __global__ __launch_bounds__(BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(7
 }
 __global__ __launch_bounds__(2 * BLEND_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_blend2_unfused(GSR_BLEND_PARAMS)
 {
-    blend2_body<false>(GSR_BLEND_ARGS);
+    blend_body<2, false>(GSR_BLEND_ARGS);
 }
 #undef GSR_BLEND_PARAMS
 #undef GSR_BLEND_ARGS
@@ -1102,8 +616,7 @@ void launch_blend(const BlendBuffers& b, const BinGrid& g, float early_out_eps, 
 #define GSR_LAUNCH_BLEND(K, THREADS)                                                                                      \
     hipLaunchKernelGGL(K, dim3(b.grid), dim3(THREADS), 0, s, b.items, b.seg_start, b.bin_start, b.list, b.rec, b.shcol, b.fb, \
                        b.partial, b.queue, g, early_out_eps, b.seg_len_dev, b.capacity, b.nsplats, b.bin_mask, b.saturate)
-    if (b.sub == 3 && b.bin_mask) GSR_LAUNCH_BLEND(k_blend2_v1, 2 * BLEND_THREADS);
-    else if (b.sub >= 2 && b.bin_mask) GSR_LAUNCH_BLEND(k_blend2, 2 * BLEND_THREADS);
+    if (b.sub >= 2 && b.bin_mask) GSR_LAUNCH_BLEND(k_blend2, 2 * BLEND_THREADS);
     else if (b.sub >= 2) GSR_LAUNCH_BLEND(k_blend2_unfused, 2 * BLEND_THREADS);
     else if (b.bin_mask) GSR_LAUNCH_BLEND(k_blend, BLEND_THREADS);
     else GSR_LAUNCH_BLEND(k_blend_unfused, BLEND_THREADS);

@@ -152,10 +152,11 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_project_key(SceneSoA sc, uint3
     const bool frame = do_project != 2;   // (uniform) false: the read-back re-run
     if (frame && blockIdx.x == 0 && threadIdx.x == 0) *overflow = 0u;   // (raised by the binning kernels later in this frame)
     __shared__ int32_t s_min[4], s_max[4];
-    __shared__ uint32_t s_vis[4], s_til[4], s_oti[4];
+    __shared__ uint32_t s_vis[4], s_til[4], s_oti[4], s_oma[4];
     int32_t dmin = 0x7fffffff, dmax = (int32_t)0x80000000;
     uint32_t vis = 0, tiles = 0;   // this thread's visible splats and the 16x16 tiles their boxes overlap (V and D of the byte model)
     uint32_t otiles = 0;           // sum of opacity byte x tiles / 16 over them
+    uint32_t omass = 0;            // sum of opacity byte x footprint in pixels / 256 over them (below)
     const int bx_lo = cam.band_px0 / BIN_PX, bx_hi = (cam.band_px1 + BIN_PX - 1) / BIN_PX;   // this context's band of bin columns
 
     const uint32_t i = blockIdx.x * PROJ_THREADS + threadIdx.x;
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_project_key(SceneSoA sc, uint3
         if (do_project) {
             uint2 bb = make_uint2(BBOX_INVISIBLE_X, BBOX_INVISIBLE_Y);
             uint32_t op8 = 0;   // the splat's opacity byte (for the frame's optical-depth figure below)
+            float area = 0.0f;  // its footprint: the integral of exp(-|vPosition|^2) over the |vPosition| <= 2 ellipse, in pixels
             do {
                 // :133-136  cam = view * vec4(p,1); pos2d = projection * cam
                 float camv[4], pos2d[4];
@@ -261,6 +263,9 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_project_key(SceneSoA sc, uint3
                 const float m2 = majx * majx + majy * majy;
                 const float n2 = minx * minx + miny * miny;
                 const float im = 2.0f / m2, in = 2.0f / n2;
+                // pi (1 - e^-4) / 4 x |major| x |minor|: what the splat adds to the optical depth of the pixels it covers, summed over
+                // them, per unit of opacity (an estimate for the work-item policy, k_bin_finalize: not a parity quantity)
+                area = fminf(0.77f * __builtin_amdgcn_sqrtf(m2 * n2), 65535.0f);
                 Record r;
                 r.cx = cx; r.cy = cy;
                 r.ux = majx * im; r.uy = -majy * im;
@@ -314,6 +319,7 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_project_key(SceneSoA sc, uint3
                 // opacity x tiles, /16 so that a slot's sum stays inside 32 bits (<= 255 * 4096 / 16 per splat): the frame's
                 // optical depth in the unit k_bin_finalize compares (FinalizeArgs::long_tau)
                 otiles += (op8 * min(nt, 4096u)) >> 4;
+                omass += (op8 * (uint32_t)area) >> 8;   // (<= 65280 per splat: a slot's sum stays inside 32 bits)
             }
         }
     }
@@ -326,9 +332,10 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_project_key(SceneSoA sc, uint3
         vis += __shfl_xor(vis, off);
         tiles += __shfl_xor(tiles, off);
         otiles += __shfl_xor(otiles, off);
+        omass += __shfl_xor(omass, off);
     }
     const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { s_min[wave] = dmin; s_max[wave] = dmax; s_vis[wave] = vis; s_til[wave] = tiles; s_oti[wave] = otiles; }
+    if ((threadIdx.x & 63) == 0) { s_min[wave] = dmin; s_max[wave] = dmax; s_vis[wave] = vis; s_til[wave] = tiles; s_oti[wave] = otiles; s_oma[wave] = omass; }
     __syncthreads();
     if (threadIdx.x == 0 && frame) {
         int32_t* slot = slots + (size_t)(blockIdx.x & (FRAME_SLOTS - 1)) * FRAME_SLOT_WORDS;
@@ -338,6 +345,7 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_project_key(SceneSoA sc, uint3
             atomicAdd(reinterpret_cast<uint32_t*>(&slot[2]), s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3]);
             atomicAdd(reinterpret_cast<uint32_t*>(&slot[3]), s_til[0] + s_til[1] + s_til[2] + s_til[3]);
             atomicAdd(reinterpret_cast<uint32_t*>(&slot[4]), s_oti[0] + s_oti[1] + s_oti[2] + s_oti[3]);
+            atomicAdd(reinterpret_cast<uint32_t*>(&slot[5]), s_oma[0] + s_oma[1] + s_oma[2] + s_oma[3]);
         }
     }
 }

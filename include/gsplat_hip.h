@@ -168,7 +168,8 @@ int gsr_reset_timings(gsr_ctx *ctx);
 /* With GSR_FLAG_TIMING: record the stage events only on every `every`-th frame (default 1).  The six events of a
  * frame are packets the GPU's command processor has to retire; on short frames (small scenes, one band of a
  * multi-GPU frame) timing every frame costs up to 15 % of the frame rate.  gsr_timings averages the sampled frames;
- * the first frame after this call or after gsr_reset_timings is always sampled. */
+ * the first frame after this call or after gsr_reset_timings is always sampled.  every = 0xffffffff: no frame is
+ * sampled (a context created with GSR_FLAG_TIMING then issues frames exactly like one created without). */
 int gsr_set_timing_interval(gsr_ctx *ctx, uint32_t every);
 
 /* ---- parity/debug read-backs (intermediate device buffers of the last frame) ---- */

@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--no-timing", action="store_true", help="contexts without stage events: frames replay the captured graph (frames/s only)")
     ap.add_argument("--n", type=int, default=0, help="splats (default: the configuration's), same generator parameters")
     ap.add_argument("--sort-only", action="store_true", help="time gsr_sort (key + min/max + radix) instead of full frames")
+    ap.add_argument("--exact-contexts", action="store_true", help="contexts without GSR_FLAG_THROUGHPUT even with several frames in flight "
+                    "(a variant may still ask for the throughput kind with KIND=throughput among its knobs)")
     args = ap.parse_args()
     import gsplat_hip as gh
 
@@ -53,10 +55,12 @@ def main():
     ctxs = {}
     for name in args.variants:      # "lib@ENV=value,ENV2=value": tuning knobs the library reads when a context is set up
         envs = dict(kv.split("=") for kv in name.split("@")[1].split(",")) if "@" in name else {}
+        kind = envs.pop("KIND", None)      # KIND=exact|throughput: the context kind of this variant (not an environment knob)
         os.environ.update(envs)
+        tp = (F > 1 and not args.exact_contexts) if kind is None else kind == "throughput"
         rs = []
         for _ in range(F):
-            r = gh.HIPRenderer(W, H, timing=not args.no_timing, throughput=F > 1, lib_path=lib_of(name))
+            r = gh.HIPRenderer(W, H, timing=not args.no_timing, throughput=tp, lib_path=lib_of(name))
             r.render(scene, gh.orbit_camera(0, 120, W, H, cfg["fx"]))
             rs.append(r)
         for k in envs:
