@@ -52,7 +52,7 @@ constexpr uint32_t SAT_FROM = CHUNK;   // entries of a long work item before its
 // 100 MHz, common to all XCDs), [7] entry visits, [8] items, [9] start of the last item, [10] longest item (ticks),
 // [11] its entries, [12] its entry visits, [13] its bin.  Never compiled into the shipped library.
 __device__ unsigned int g_blend_stamps[4096 * 4 * 16];
-// per bin (whole-bin work items: GSR_SPEC=0): [0] entries, [1] entries staged before the item ended (its saturation depth, or
+// per bin (whole-bin work items): [0] entries, [1] entries staged before the item ended (its saturation depth, or
 // all), [2..5] entry visits of the four waves, [6] the item's duration (s_memrealtime ticks, 10 ns), [7] its start tick
 __device__ unsigned int g_bin_info[16384 * 8];
 #define STAMP(v) const unsigned int v = (unsigned int)__builtin_readcyclecounter()
