@@ -1399,3 +1399,34 @@ def test_every_knob_at_a_non_default_value_matches_the_oracle(gh, oracle, scenes
         assert err <= TOL_EXACT, (env, val, k, err)
     assert r.stats()["overflow_frames"] == 0
     r.dispose()
+
+
+@pytest.mark.gpu
+def test_assembly_walk_equals_the_cpp_loop(gh, monkeypatch):
+    """The compositor's innermost loop -- the walk over a tile's entries of a 64-entry step -- ships as a block of assembly
+    (k_blend.hip, GSR_ASM_WALK_STEP: s_ff1 / s_bitset0 / s_bitcmp1 for the walk, v_cmpx for the coverage); the same loop in C++
+    is the `cppwalk` twin of the library (-DGSR_CPP_WALK, built by __graft_entry__.build()).  Same arithmetic instruction for
+    instruction, so every image must be equal bit for bit: both compositor kernels, both cuts of the lists, the separate
+    fold, early termination, SH colours -- and the depthIndex, which the compositor does not touch."""
+    import os
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gsplat.js_amd", "lib_exp", "cppwalk", "libgsplat_hip.so")
+    assert os.path.exists(lib), "the C++-walk build is missing: run python -c 'import __graft_entry__ as g; g.build()'"
+    cases = [("C1", {}, {}), ("C2", {}, {}), ("C3", {}, {}), ("C3", {"GSR_BLEND_SUB": "1"}, {}), ("C3", {"GSR_LONG_ITEMS": "0"}, {}),
+             ("C2", {"GSR_FUSE_COMBINE": "0"}, {}), ("C2", {}, {"early_out_eps": 1e-4}), ("C2", {}, {"throughput": True})]
+    for name, env, kw in cases:
+        cfg = gh.synth.CONFIGS[name]
+        W, H = cfg["width"], cfg["height"]
+        scene = gh.Scene()
+        scene.setData(gh.synth.config_rows(name))
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        a = gh.HIPRenderer(W, H, **kw)
+        b = gh.HIPRenderer(W, H, lib_path=lib, **kw)
+        for k in (9, 77):
+            cam = gh.orbit_camera(k, 120, W, H, cfg["fx"])
+            a.render(scene, cam); b.render(scene, cam)
+            assert np.array_equal(a.readPixelsFloat(), b.readPixelsFloat()), (name, env, kw, k)
+            assert np.array_equal(a.lastDepthIndex(), b.lastDepthIndex())
+        a.dispose(); b.dispose()
+        for k in env:
+            monkeypatch.delenv(k)
