@@ -77,6 +77,9 @@ struct gsr_ctx {
     int32_t band[3] = {-1, -1, -1};
     // per frame, sized by n
     int32_t* depth = nullptr;
+    uint32_t* kept = nullptr;         // band mode: survivors per 256-splat workgroup of k_project_key, packed to the front of its depth slots
+    uint8_t* kept_lane = nullptr;     // band mode: the lane a packed slot's splat came from
+    uint32_t* koff = nullptr;         // band mode: survivors in front of every workgroup's block (k_kept_scan)
     uint32_t *keys = nullptr, *keys_tmp = nullptr, *idx_tmp = nullptr, *depth_index = nullptr;
     uint32_t* block_hist = nullptr;
     Record* rec = nullptr;
@@ -428,7 +431,10 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
     if (c->n) {
         SceneSoA sc{c->px, c->py, c->pz, c->cov0, c->cov1, c->cov2, c->rgba, c->sh_r, c->sh_g, c->sh_b, c->shcol};
         if (render) {
-            c->proj = ProjectLaunch{sc, c->n, c->cam, 1, c->depth, c->slots, c->rec, nullptr, c->rect_idx, &c->fstate->overflow, {}};
+            // (band mode: the workgroups pack their survivors, see k_project_key; the sort below reads the same two arrays)
+            const bool pack = band_is_partial(c);
+            c->proj = ProjectLaunch{sc, c->n, c->cam, 1, c->depth, c->slots, c->rec, nullptr, c->rect_idx, &c->fstate->overflow,
+                                    pack ? c->kept : nullptr, pack ? c->kept_lane : nullptr, {}};
             launch_project_key(c->proj, s);
         }
         else {   // a sort-only frame: its own slots (sets 1 and 2 in turn; set 0 belongs to the render frames and k_begin_frame)
@@ -443,7 +449,7 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
         // touches the band; the full depthIndex is produced on demand (gsr_read_depth_index)
         const bool cull = render && band_is_partial(c);
         SortBuffers sb{c->depth, slots_now, c->fstate->minmax, c->keys, c->keys_tmp, c->idx_tmp, c->depth_index,
-                       c->block_hist, c->fstate->digit_total, c->rect_idx, cull ? 1 : 0, &c->fstate->sorted_count, c->sort_kpb, c->sort_blocks,
+                       c->block_hist, c->fstate->digit_total, c->rect_idx, c->kept, c->kept_lane, cull ? c->koff : nullptr, &c->fstate->sorted_count, c->sort_kpb, c->sort_blocks,
                        c->bucket_order_now ? 1 : 0, reinterpret_cast<uint32_t*>(c->mailbox_dev + 1),
                        c->sort_chunk_tab, c->rect_tmp, (render && c->rect_carry && (c->rect_carry_bucket || !c->bucket_order_now)) ? c->bin_rects : nullptr};
         c->sort_culled = cull;
@@ -496,7 +502,7 @@ static std::vector<uint64_t> chain_signature(const gsr_ctx* c)
     auto P = [&v](const void* p) { v.push_back((uint64_t)(uintptr_t)p); };
     auto U = [&v](uint64_t x) { v.push_back(x); };
     P(c->px); P(c->py); P(c->pz); P(c->cov0); P(c->cov1); P(c->cov2); P(c->rgba); P(c->sh_r); P(c->sh_g); P(c->sh_b); P(c->shcol);
-    P(c->depth); P(c->keys); P(c->keys_tmp); P(c->idx_tmp); P(c->depth_index); P(c->block_hist); P(c->fstate);
+    P(c->depth); P(c->kept); P(c->kept_lane); P(c->koff); P(c->keys); P(c->keys_tmp); P(c->idx_tmp); P(c->depth_index); P(c->block_hist); P(c->fstate);
     P(c->rec); P(c->bbox); P(c->slots); P(c->rect_idx); P(c->bin_table); P(c->bin_rects); P(c->bin_total); P(c->bin_start); P(c->seg_start); P(c->bin_mask);
     P(c->items); P(c->bin_list); P(c->partial); P(c->fb); P(c->accum); P(c->cam_dev);
     U(c->n); U((uint64_t)c->W); U((uint64_t)c->H); U((uint64_t)g.bx_lo); U((uint64_t)g.bx_hi); U(c->sort_kpb); U(c->sort_blocks);
@@ -796,7 +802,7 @@ int gsr_destroy(gsr_ctx* c)
     dev_free(&c->cov0); dev_free(&c->cov1); dev_free(&c->cov2); dev_free(&c->rgba);
     dev_free(&c->sh_r); dev_free(&c->sh_g); dev_free(&c->sh_b); dev_free(&c->shcol);
     dev_free(&c->rotv); dev_free(&c->sclv);
-    dev_free(&c->depth); dev_free(&c->keys); dev_free(&c->keys_tmp); dev_free(&c->idx_tmp); dev_free(&c->depth_index);
+    dev_free(&c->depth); dev_free(&c->kept); dev_free(&c->kept_lane); dev_free(&c->koff); dev_free(&c->keys); dev_free(&c->keys_tmp); dev_free(&c->idx_tmp); dev_free(&c->depth_index);
     dev_free(&c->block_hist); dev_free(&c->rec); dev_free(&c->bbox); dev_free(&c->slots); dev_free(&c->rect_idx);
     dev_free(&c->bin_table); dev_free(&c->bin_total); dev_free(&c->bin_start); dev_free(&c->bin_start_pre); dev_free(&c->bin_list);
     dev_free(&c->cell_list); dev_free(&c->cell_total); dev_free(&c->cell_start); dev_free(&c->chunk_start); dev_free(&c->chunk_info); dev_free(&c->cell_wcnt); dev_free(&c->cell_table2);
@@ -833,7 +839,9 @@ int alloc_scene(gsr_ctx* c, uint32_t n, bool with_rows)
         (r = dev_alloc(c, &c->keys_tmp, n)) || (r = dev_alloc(c, &c->idx_tmp, n)) ||
         (r = dev_alloc(c, &c->depth_index, n)) || (r = dev_alloc(c, &c->rec, n)) ||
         (r = dev_alloc(c, &c->bin_rects, n)) || (r = dev_alloc(c, &c->rect_idx, n)) || (r = dev_alloc(c, &c->rect_tmp, n)) ||
-        (r = dev_alloc(c, &c->sort_chunk_tab, 4 * ((size_t)n / 4096 + 260))))
+        (r = dev_alloc(c, &c->sort_chunk_tab, 4 * ((size_t)n / 4096 + 260))) ||
+        (r = dev_alloc(c, &c->kept, (size_t)n / PROJ_THREADS + 1)) || (r = dev_alloc(c, &c->kept_lane, n)) ||
+        (r = dev_alloc(c, &c->koff, (size_t)n / PROJ_THREADS + 2)))
         return r;
     if (with_rows && ((r = dev_alloc(c, &c->rotv, n)) || (r = dev_alloc(c, &c->sclv, n)))) return r;
     // keys per radix workgroup: the scatter stores runs of keys_per_block / 2^bits keys, so larger scenes take larger
@@ -1290,7 +1298,7 @@ int gsr_read_records(gsr_ctx* c, float* rec, int32_t* bbox)
         if (c->n) {
             if (int r = dev_alloc(c, &c->bbox, c->n)) return r;
             SceneSoA sc{c->px, c->py, c->pz, c->cov0, c->cov1, c->cov2, c->rgba, c->sh_r, c->sh_g, c->sh_b, c->shcol};
-            ProjectLaunch again{sc, c->n, c->cam_frame, 2, c->depth, c->slots, c->rec, c->bbox, c->rect_idx, &c->fstate->overflow, {}};
+            ProjectLaunch again{sc, c->n, c->cam_frame, 2, c->depth, c->slots, c->rec, c->bbox, c->rect_idx, &c->fstate->overflow, nullptr, nullptr, {}};
             launch_project_key(again, c->stream);
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipMemcpyAsync(tmp.data(), c->bbox, (size_t)c->n * 8, hipMemcpyDeviceToHost, c->stream));

@@ -144,7 +144,9 @@ struct ProjectLaunch {
     Record* rec; uint2* bbox;   // bbox may be null (frames: nothing on the path reads the pixel boxes)
     uint32_t* rect;      // n: packed bin rectangle per splat
     uint32_t* overflow;  // the frame's overflow word, zeroed by the kernel
-    void* ptrs[10];
+    uint32_t* kept;      // band mode: per 256-splat workgroup, the survivors it packed to the front of its depth slots (null: no packing)
+    uint8_t* kept_lane;  // band mode: n: the lane (index & 255) a packed slot's splat came from
+    void* ptrs[12];
     void bind();
 };
 const void* project_key_kernel();
@@ -162,8 +164,10 @@ struct SortBuffers {
     uint32_t* depth_index;     // n   result
     uint32_t* block_hist;      // nblocks * RADIX_HI_BINS
     uint32_t* digit_total;     // RADIX_LO_BINS + RADIX_HI_BINS
-    const uint32_t* rect;      // per splat: packed bin rectangle of the projection (read only when cull is set)
-    int cull;                  // band mode: splats with rect == RECT_NONE are absent from the sort
+    const uint32_t* rect;      // per splat: packed bin rectangle of the projection (carried with the keys when rects_out is set)
+    const uint32_t* kept;      // band mode (koff set): per 256 splats, the survivors k_project_key packed to the front of their
+    const uint8_t* kept_lane;  //   depth slots, and the lane each came from: everybody else is absent from the sort
+    uint32_t* koff;            // band mode: n / 256 + 2 words: the survivors in front of every block (k_kept_scan); null otherwise
     uint32_t* count;           // out: keys the first pass kept (n, or the band's survivors) = entries of depth_index
     uint32_t keys_per_block;
     uint32_t nblocks;
@@ -175,7 +179,8 @@ struct SortBuffers {
 };
 void launch_sort(const SortBuffers& b, uint32_t n, hipStream_t s);
 // column scan (k_sort.hip), shared with the binning
-void launch_column_scan(uint32_t* table, uint32_t* total, int ncols, uint32_t nrows, hipStream_t s);
+// (live: the frame holds *live keys or ranks, live_unit of them per table row: the rows behind are neither written nor scanned)
+void launch_column_scan(uint32_t* table, uint32_t* total, int ncols, uint32_t nrows, hipStream_t s, const uint32_t* live = nullptr, uint32_t live_unit = 1);
 
 struct BinGrid {
     int32_t nbx, nby;          // bins across / down the whole image

@@ -74,6 +74,9 @@ __global__ __launch_bounds__(CNT_THREADS) void k_bin_count(const uint32_t* __res
                                                            uint32_t rounds, uint32_t* __restrict__ table, uint32_t* __restrict__ rects, int shift, int sorted)
 {
     const uint32_t n = *count;  // ranks the sort produced (all splats, or the band's survivors)
+    // (band mode: the grid is the scene's, the ranks are the band's: a workgroup past them leaves no row -- the scan and the
+    //  scatter stop at the last row that has ranks, launch_column_scan's `live`)
+    if ((unsigned long long)blockIdx.x * rounds * BIN_RANKS_PER_BLOCK >= n) return;
     extern __shared__ uint32_t s_cnt[];  // this slice's bins
     const int nbxb = g.bx_hi - g.bx_lo, nbins = nbxb * g.nby;
     const int y_lo = blockIdx.y * slice_rows, y_hi = min(y_lo + slice_rows, g.nby);  // bin rows of this slice
@@ -590,6 +593,7 @@ __device__ __forceinline__ void bin_scatter_body(const uint32_t* __restrict__ de
     const int shift = CELLS ? ca.shift : 0;
     const int table_stride = (g.bx_hi - g.bx_lo) * g.nby + (CELLS ? 1 : 0);   // (the cell pass's table has the area column, k_bin_count)
     const uint32_t blk = xcd_group_remap(blockIdx.x - (BIG ? 1u : 0u), gridDim.x - (EXTRA ? 1u : 0u));   // neighbouring rank blocks on one XCD (gsr_internal.h)
+    if ((unsigned long long)blk * (BIG ? rounds : 1u) * BIN_RANKS_PER_BLOCK >= *count) return;   // (band mode: no ranks here, no table row either)
     constexpr int WAVES_PER_GROUP = SCAT_WAVES / GROUPS;            // 4 or 2
     constexpr int STEPS = SCAT_WAVES * SPW;                         // steps of a round: 32 (2048 ranks) or 16 (1024)
     constexpr int GROUP_STEPS = STEPS / GROUPS;                     // 8 or 4
@@ -1038,7 +1042,7 @@ static void launch_bin_two_level(const BinBuffers& b, const BinGrid& g, hipStrea
     // level one (b.nblocks workgroups of 2048 ranks; the table's last column sums the rectangles' areas in bins)
     hipLaunchKernelGGL(k_bin_count, dim3(b.nblocks), dim3(CNT_THREADS), (size_t)(ncells + 1) * sizeof(uint32_t), s, b.depth_index, b.rect_idx,
                        b.count, gc, ncy, 1u, b.table, b.rects, CELL_SHIFT, (int)b.rects_sorted);
-    launch_column_scan(b.table, b.cell_total, ncells + 1, b.nblocks, s);
+    launch_column_scan(b.table, b.cell_total, ncells + 1, b.nblocks, s, b.count, BIN_RANKS_PER_BLOCK);
     {
         const dim3 grid(b.nblocks + 1), block(SCAT_THREADS);
 #define GSR_LAUNCH_CELLS(K)                                                                                                          \
@@ -1083,7 +1087,7 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
     if (n) {
         hipLaunchKernelGGL(k_bin_count, dim3(b.nblocks, (g.nby + cnt_rows - 1) / cnt_rows), dim3(CNT_THREADS),
                            (size_t)cnt_rows * nbxb * sizeof(uint32_t), s, b.depth_index, b.rect_idx, b.count, g, cnt_rows, b.rounds, b.table, b.rects, 0, (int)b.rects_sorted);
-        launch_column_scan(b.table, b.bin_total, nbins, b.nblocks, s);
+        launch_column_scan(b.table, b.bin_total, nbins, b.nblocks, s, b.count, b.rounds * BIN_RANKS_PER_BLOCK);
     }
     const FinalizeArgs fa = make_finalize_args(b, nbins, n);
     const bool fused = n && nbins <= 4096;   // see bin_scatter_body

@@ -147,12 +147,22 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_project_key(SceneSoA sc, uint3
                                                               int do_project, int32_t* __restrict__ depth,
                                                               int32_t* __restrict__ slots,
                                                               Record* __restrict__ rec, uint2* __restrict__ bbox,
-                                                              uint32_t* __restrict__ rect, uint32_t* __restrict__ overflow)
+                                                              uint32_t* __restrict__ rect, uint32_t* __restrict__ overflow,
+                                                              uint32_t* __restrict__ kept, uint8_t* __restrict__ kept_lane)
 {
     const bool frame = do_project != 2;   // (uniform) false: the read-back re-run
+    // Band mode (a context that composites a column band of the screen: multi-GPU) with `kept` set: most splats
+    // are somebody else's, and everything after this kernel wants the band's survivors only.  The workgroup packs its
+    // survivors' depths to the front of ITS OWN 256 slots of depth[], in index order, with the lane each came from in
+    // kept_lane[] and their number in kept[workgroup]; the key pass and the first radix pass read kept[] and touch only those
+    // slots (k_sort.hip).  Nothing is written for the others: 12 bytes read per splat that is not the band's, instead of
+    // 12 read + 8 written here and 12 + 4 + 4 in the two passes behind.  The rectangle stays at the splat's own index.
+    const bool pack = frame && kept != nullptr;   // (uniform)
     if (frame && blockIdx.x == 0 && threadIdx.x == 0) *overflow = 0u;   // (raised by the binning kernels later in this frame)
     __shared__ int32_t s_min[4], s_max[4];
-    __shared__ uint32_t s_vis[4], s_til[4], s_oti[4], s_oma[4];
+    __shared__ uint32_t s_vis[4], s_til[4], s_oti[4], s_oma[4], s_keep[4];
+    int32_t mydepth = 0;
+    bool keep = false;
     int32_t dmin = 0x7fffffff, dmax = (int32_t)0x80000000;
     uint32_t vis = 0, tiles = 0;   // this thread's visible splats and the 16x16 tiles their boxes overlap (V and D of the byte model)
     uint32_t otiles = 0;           // sum of opacity byte x tiles / 16 over them
@@ -167,7 +177,8 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_project_key(SceneSoA sc, uint3
         const float f1 = cam.vp6 * y;
         const float f2 = cam.vp10 * z;
         const int32_t d = (int32_t)(((f0 + f1) + f2) * 4096.0f);
-        if (frame) depth[i] = d;
+        if (frame && !pack) depth[i] = d;
+        mydepth = d;
         dmin = d; dmax = d;
 
         if (do_project) {
@@ -310,7 +321,11 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_project_key(SceneSoA sc, uint3
                 bb.y = (uint32_t)(int32_t)fy0 | ((uint32_t)(int32_t)fy1 << 16);
             } while (0);
             if (bbox) bbox[i] = bb;
-            if (frame) rect[i] = pack_bin_rect(bb.x, bb.y, bx_lo, bx_hi);
+            if (frame) {
+                const uint32_t rv = pack_bin_rect(bb.x, bb.y, bx_lo, bx_hi);
+                keep = rv != RECT_NONE;
+                if (!pack || keep) rect[i] = rv;
+            }
             if ((bb.x & 0xffffu) <= (bb.x >> 16)) {
                 vis++;
                 const int tx0 = max((int)(bb.x & 0xffffu) / TILE, bx_lo * BIN_TILES), tx1 = min((int)(bb.x >> 16) / TILE, bx_hi * BIN_TILES - 1);
@@ -335,8 +350,24 @@ __global__ __launch_bounds__(PROJ_THREADS) void k_project_key(SceneSoA sc, uint3
         omass += __shfl_xor(omass, off);
     }
     const int wave = threadIdx.x >> 6;
+    uint32_t keep_rank = 0;
+    if (pack) {
+        const unsigned long long kb = __ballot(keep);
+        keep_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(kb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)kb, 0u));
+        if ((threadIdx.x & 63) == 0) s_keep[wave] = (uint32_t)__popcll(kb);
+    }
     if ((threadIdx.x & 63) == 0) { s_min[wave] = dmin; s_max[wave] = dmax; s_vis[wave] = vis; s_til[wave] = tiles; s_oti[wave] = otiles; s_oma[wave] = omass; }
     __syncthreads();
+    if (pack) {
+        uint32_t before = 0;
+        for (int w = 0; w < wave; w++) before += s_keep[w];
+        if (keep) {
+            const uint32_t slot = blockIdx.x * PROJ_THREADS + before + keep_rank;   // <= my own index: inside the scene
+            depth[slot] = mydepth;
+            kept_lane[slot] = (uint8_t)threadIdx.x;
+        }
+        if (threadIdx.x == 0) kept[blockIdx.x] = s_keep[0] + s_keep[1] + s_keep[2] + s_keep[3];
+    }
     if (threadIdx.x == 0 && frame) {
         int32_t* slot = slots + (size_t)(blockIdx.x & (FRAME_SLOTS - 1)) * FRAME_SLOT_WORDS;
         atomicMin(&slot[0], min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3])));
@@ -414,7 +445,7 @@ void launch_depth_key(const SceneSoA& sc, uint32_t n, const CamParams& cam, int3
 
 void ProjectLaunch::bind()
 {
-    void* p[] = {&sc, &n, &cam, &do_project, &depth, &slots, &rec, &bbox, &rect, &overflow};
+    void* p[] = {&sc, &n, &cam, &do_project, &depth, &slots, &rec, &bbox, &rect, &overflow, &kept, &kept_lane};
     static_assert(sizeof p == sizeof ptrs, "one pointer per kernel argument");
     for (size_t k = 0; k < sizeof p / sizeof p[0]; k++) ptrs[k] = p[k];
 }

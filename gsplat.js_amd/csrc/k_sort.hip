@@ -16,7 +16,7 @@
 
 namespace gsr {
 
-GSR_BOUNDS_DECL(sort)   // sites: 0 destination of a radix pass, 1 its LDS position, 2 destination of the bucket sort, 3 key above 65536
+GSR_BOUNDS_DECL(sort)   // sites: 0 destination of a radix pass, 1 its LDS position, 2 destination of the bucket sort, 3 key above 65536, 4 band mode: a survivor's packed slot / original index
 constexpr int SORT_THREADS = 256;
 
 #ifdef GSR_KSTAMPS
@@ -56,15 +56,107 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t digit, bool valid)
 // them itself (64 loads that hit L2) instead of waiting for a one-workgroup reduction kernel, and workgroup 0 stores
 // the result for read-backs.
 //
-// Band mode (multi-GPU, `cull`): a splat whose bin rectangle is empty for this context's band (culled, or
-// outside the band) gets the key 0xffffffff = "absent".  The first scatter drops absent keys, so everything after
-// it -- second radix pass, binning -- runs on the survivors only; their order is the restriction of the global
-// order, so the band's pixels are unchanged.
+// Band mode (multi-GPU, `live` set): a splat whose bin rectangle is empty for this context's band (culled, or outside
+// the band) is absent from the band's frame.  k_project_key has packed every 256-splat block's survivors to the front
+// of the block's depth slots and counted them; k_kept_scan turns the counts into offsets (koff[block]; the survivors S
+// = the frame's *count), k_band_gather moves the survivors' depths and original indices to [0, S), in index order, and
+// everything behind -- this pass, both radix passes, their scans, the binning -- runs on S keys: workgroups and table
+// rows past S do nothing.  The survivors' sorted order is the restriction of the global order, so the band's pixels
+// are unchanged.
+// ---------------------------------------------------------------------------
+constexpr int KS_THREADS = 1024;
+constexpr int KS_WAVES = KS_THREADS / WAVE;
+constexpr int KS_BATCH = 4;
+// One workgroup.  A wave takes 64 consecutive counts per load (coalesced; one thread per run of counts made the single CU
+// fetch 64 lines per load: 20 us for C4's 19 532 blocks): pass 1 leaves the total of every 64 blocks in LDS, wave 0 scans
+// those, pass 2 adds the scan inside the 64.
+__global__ __launch_bounds__(KS_THREADS) void k_kept_scan(const uint32_t* __restrict__ kept, uint32_t nb, uint32_t* __restrict__ koff,
+                                                          uint32_t* __restrict__ count)
+{
+    extern __shared__ uint32_t s_sup[];   // (nb + 63) / 64 words
+    const uint32_t nsup = (nb + WAVE - 1u) / WAVE;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t sb = wave; sb < nsup; sb += KS_WAVES * KS_BATCH) {
+        uint32_t v[KS_BATCH];
+#pragma unroll
+        for (int k = 0; k < KS_BATCH; k++) {
+            const uint32_t b = (sb + k * KS_WAVES) * WAVE + lane;
+            v[k] = b < nb ? kept[b] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < KS_BATCH; k++) {
+            uint32_t t = v[k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+            if (lane == 0 && sb + k * KS_WAVES < nsup) s_sup[sb + k * KS_WAVES] = t;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < nsup; base += WAVE) {
+            const uint32_t v = base + lane < nsup ? s_sup[base + lane] : 0u;
+            uint32_t inc = v;
+#pragma unroll
+            for (int off = 1; off < WAVE; off <<= 1) {
+                const uint32_t u = __shfl_up(inc, off);
+                if ((int)lane >= off) inc += u;
+            }
+            if (base + lane < nsup) s_sup[base + lane] = carry + inc - v;
+            carry += __shfl(inc, WAVE - 1);
+        }
+        if (lane == 0) { koff[nb] = carry; *count = carry; }
+    }
+    __syncthreads();
+    for (uint32_t sb = wave; sb < nsup; sb += KS_WAVES * KS_BATCH) {
+        uint32_t v[KS_BATCH];
+#pragma unroll
+        for (int k = 0; k < KS_BATCH; k++) {
+            const uint32_t b = (sb + k * KS_WAVES) * WAVE + lane;
+            v[k] = b < nb ? kept[b] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < KS_BATCH; k++) {
+            const uint32_t b = (sb + k * KS_WAVES) * WAVE + lane;
+            uint32_t inc = v[k];
+#pragma unroll
+            for (int off = 1; off < WAVE; off <<= 1) {
+                const uint32_t u = __shfl_up(inc, off);
+                if ((int)lane >= off) inc += u;
+            }
+            if (b < nb) koff[b] = s_sup[sb + k * KS_WAVES] + inc - v[k];
+        }
+    }
+}
+
+// survivor t of block b (its packed slot b * 256 + t) -> position koff[b] + t: depth and original index, dense
+constexpr int BG_BLOCKS = 4;   // blocks of k_project_key per workgroup: one wave each, four slots per lane
+__global__ __launch_bounds__(BG_BLOCKS * WAVE) void k_band_gather(const int32_t* __restrict__ depth, const uint8_t* __restrict__ kept_lane,
+                                                                 const uint32_t* __restrict__ kept, const uint32_t* __restrict__ koff,
+                                                                 uint32_t n, uint32_t nb, int32_t* __restrict__ depth_out,
+                                                                 uint32_t* __restrict__ idx_out)
+{
+    const uint32_t b = blockIdx.x * BG_BLOCKS + (threadIdx.x >> 6);
+    if (b >= nb) return;
+    const uint32_t c = kept[b], o = koff[b];
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (uint32_t k = 0; k < PROJ_THREADS / WAVE; k++) {
+        const uint32_t t = k * WAVE + lane;
+        if (t < c) {
+            const uint32_t slot = b * PROJ_THREADS + t;
+            GSR_BOUND(sort, 4, slot, n);
+            depth_out[o + t] = depth[slot];
+            idx_out[o + t] = b * PROJ_THREADS + kept_lane[slot];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(SORT_THREADS) void k_quantise_hist(const int32_t* __restrict__ depth,
                                                                 const int32_t* __restrict__ slots,
                                                                 int32_t* __restrict__ minmax_out, uint32_t n,
-                                                                uint32_t keys_per_block, const uint32_t* __restrict__ rect, int cull,
+                                                                uint32_t keys_per_block, const uint32_t* __restrict__ live,
                                                                 uint32_t* __restrict__ keys,
                                                                 uint32_t* __restrict__ block_hist, int hist_shift, int hist_bins)
 {
@@ -95,15 +187,15 @@ __global__ __launch_bounds__(SORT_THREADS) void k_quantise_hist(const int32_t* _
     const float depthInv = degenerate ? 0.0f : (float)DEPTH_RANGE / (float)(maxDepth - minDepth);
 
     const uint32_t begin = blockIdx.x * keys_per_block;
+    if (live) n = *live;   // (band mode: depth[] holds the survivors, dense: k_band_gather)
     const uint32_t end = min(begin + keys_per_block, n);
     for (uint32_t i = begin + threadIdx.x; i < end; i += SORT_THREADS) {
         // wasm.cpp:38: u32 wrap-around subtract, u32->f32 RNE, f32 multiply, truncate
         const uint32_t rel = (uint32_t)depth[i] - (uint32_t)minDepth;
         uint32_t q = degenerate ? 0u : (uint32_t)((float)rel * depthInv);
         q = min(q, DEPTH_RANGE);
-        if (cull && rect[i] == RECT_NONE) q = 0xffffffffu;  // nothing to draw in this band: absent from its frame
         keys[i] = q;
-        if (q != 0xffffffffu) atomicAdd(&h_lo[(q >> hist_shift) & (uint32_t)(hist_bins - 1)], 1u);
+        atomicAdd(&h_lo[(q >> hist_shift) & (uint32_t)(hist_bins - 1)], 1u);
     }
     __syncthreads();
     for (int d = threadIdx.x; d < hist_bins; d += SORT_THREADS) block_hist[(size_t)blockIdx.x * hist_bins + d] = h_lo[d];
@@ -149,8 +241,10 @@ constexpr int CS_KEEP = 16;
 
 template <bool KEEP>
 __global__ __launch_bounds__(CS_THREADS) void k_column_scan(uint32_t* __restrict__ table, uint32_t* __restrict__ total,
-                                                            int ncols, uint32_t nrows)
+                                                            int ncols, uint32_t nrows, const uint32_t* __restrict__ live, uint32_t live_unit)
 {
+    // (band mode: the frame holds *live keys or ranks, live_unit per row: the rows behind them were not written and are not read)
+    if (live) nrows = min(nrows, (*live + live_unit - 1u) / live_unit);
     __shared__ uint32_t s_sum[CS_SLOTS][CS_COLS];
     const int c = threadIdx.x & (CS_COLS - 1);
     const int slot = threadIdx.x / CS_COLS;
@@ -209,11 +303,11 @@ __global__ __launch_bounds__(CS_THREADS) void k_column_scan(uint32_t* __restrict
     }
 }
 
-void launch_column_scan(uint32_t* table, uint32_t* total, int ncols, uint32_t nrows, hipStream_t s)
+void launch_column_scan(uint32_t* table, uint32_t* total, int ncols, uint32_t nrows, hipStream_t s, const uint32_t* live, uint32_t live_unit)
 {
     const dim3 grid((ncols + CS_COLS - 1) / CS_COLS), block(CS_THREADS);
-    if (nrows <= (uint32_t)CS_SLOTS * CS_KEEP) hipLaunchKernelGGL(k_column_scan<true>, grid, block, 0, s, table, total, ncols, nrows);
-    else hipLaunchKernelGGL(k_column_scan<false>, grid, block, 0, s, table, total, ncols, nrows);
+    if (nrows <= (uint32_t)CS_SLOTS * CS_KEEP) hipLaunchKernelGGL(k_column_scan<true>, grid, block, 0, s, table, total, ncols, nrows, live, live_unit);
+    else hipLaunchKernelGGL(k_column_scan<false>, grid, block, 0, s, table, total, ncols, nrows, live, live_unit);
 }
 
 // ---------------------------------------------------------------------------
@@ -264,9 +358,11 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter(const uint32_t* __rest
 {
     constexpr int BINS = 1 << BITS;
     static_assert(BINS <= SCAT_THREADS, "one digit per thread");
-    // the first pass reads all n_in keys (absent ones are skipped) and publishes how many it kept;
-    // the second pass runs on that many
-    const uint32_t n = FIRST ? n_in : *count;
+    // the first pass runs on all n_in keys (their indices are their positions) and publishes the number as *count -- or, in
+    // band mode (idx_in set), on the *count survivors k_quantise_hist left dense, with their original indices in idx_in;
+    // the second pass runs on *count
+    const bool band = FIRST && idx_in != nullptr;   // (uniform)
+    const uint32_t n = (FIRST && !band) ? n_in : *count;
     extern __shared__ uint32_t s_scat[];
     uint32_t (*cnt)[BINS] = reinterpret_cast<uint32_t (*)[BINS]>(s_scat);   // [wave][digit]: counts, then local positions
     uint32_t* gdelta = s_scat + SCAT_WAVES * BINS;   // [digit]: global destination of local position p is gdelta[digit] + p
@@ -276,6 +372,9 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter(const uint32_t* __rest
     uint32_t* lidx = lkey + keys_per_block;          // [keys_per_block]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t blk = xcd_group_remap(blockIdx.x, gridDim.x);   // neighbouring key blocks on one XCD (gsr_internal.h)
+    // (band mode: the grid is the scene's, the keys are the band's -- a workgroup past them has nothing to place; workgroup 0
+    //  stays for the frame-wide words it publishes)
+    if ((unsigned long long)blk * keys_per_block >= n && blockIdx.x != 0) return;
     KSTAMP(0);
     // the two table reads of this workgroup do not depend on its keys: issued first
     uint32_t tot = 0, wg_base = 0;
@@ -300,8 +399,9 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter(const uint32_t* __rest
         const uint32_t i = wbegin + k * WAVE + lane;
         const bool in = (uint32_t)k < steps && i < wend;
         key[k] = in ? keys_in[i] : 0xffffffffu;
-        src[k] = FIRST ? i : (in ? idx_in[i] : 0u);
-        if (PAY) pay[k] = in ? pay_in[i] : 0u;
+        src[k] = (FIRST && !band) ? i : (in ? idx_in[i] : 0u);
+        if (band) GSR_BOUND(sort, 4, src[k], n_in);
+        if (PAY) pay[k] = in ? pay_in[band ? src[k] : i] : 0u;   // (band mode: the rectangle stayed at the splat's own index)
     }
 #pragma unroll
     for (int k = 0; k < SCAT_MAX_STEPS; k++)
@@ -572,39 +672,50 @@ void launch_sort(const SortBuffers& b, uint32_t n, hipStream_t s)
             (void)hipGetLastError();   // a failure shows up as the launch error
         });
     }
+    // band mode: the survivors' offsets from the projection's per-block counts, then their depths and original indices dense
+    // in keys_tmp[] / depth_index[] (both free: the first radix pass writes the one, the last kernel of the sort the other)
+    uint32_t* band_idx = b.koff ? b.depth_index : nullptr;
+    const uint32_t* live = b.koff ? b.count : nullptr;
+    const int32_t* depth_in = b.koff ? reinterpret_cast<const int32_t*>(b.keys_tmp) : b.depth;
+    if (b.koff) {
+        const uint32_t nb = (n + PROJ_THREADS - 1u) / PROJ_THREADS;
+        hipLaunchKernelGGL(k_kept_scan, dim3(1), dim3(KS_THREADS), (size_t)((nb + WAVE - 1u) / WAVE) * sizeof(uint32_t), s, b.kept, nb, b.koff, b.count);
+        hipLaunchKernelGGL(k_band_gather, dim3((nb + BG_BLOCKS - 1) / BG_BLOCKS), dim3(BG_BLOCKS * WAVE), 0, s, b.depth, b.kept_lane, b.kept,
+                           (const uint32_t*)b.koff, n, nb, reinterpret_cast<int32_t*>(b.keys_tmp), band_idx);
+    }
     if (b.bucket_order) {
         // bucket order: partition by the high 9 bits, then one workgroup per bucket sorts by the low 8 (k_local_sort)
-        hipLaunchKernelGGL(k_quantise_hist, grid, block, 0, s, b.depth, b.slots, b.minmax, n, b.keys_per_block,
-                           b.rect, b.cull, b.keys, b.block_hist, RADIX_LO_BITS, RADIX_HI_BINS);
-        launch_column_scan(b.block_hist, total_hi, RADIX_HI_BINS, b.nblocks, s);
+        hipLaunchKernelGGL(k_quantise_hist, grid, block, 0, s, depth_in, b.slots, b.minmax, n, b.keys_per_block,
+                           live, b.keys, b.block_hist, RADIX_LO_BITS, RADIX_HI_BINS);
+        launch_column_scan(b.block_hist, total_hi, RADIX_HI_BINS, b.nblocks, s, live, b.keys_per_block);
         uint4* tab = reinterpret_cast<uint4*>(b.chunk_tab);   // k_local_sort's work list, written by the partition pass's first workgroup
         if (b.rects_out)
             hipLaunchKernelGGL((k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, true, true>), grid, dim3(SCAT_THREADS), lds_hi, s, (const uint32_t*)b.keys,
-                               (const uint32_t*)nullptr, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
+                               (const uint32_t*)band_idx, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
                                (const uint32_t*)total_hi, b.keys_tmp, b.idx_tmp, b.max_bucket, b.rect, b.rect_tmp, tab);
         else
             hipLaunchKernelGGL((k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, true>), grid, dim3(SCAT_THREADS), lds_hi, s, (const uint32_t*)b.keys,
-                               (const uint32_t*)nullptr, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
+                               (const uint32_t*)band_idx, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
                                (const uint32_t*)total_hi, b.keys_tmp, b.idx_tmp, b.max_bucket, (const uint32_t*)nullptr, (uint32_t*)nullptr, tab);
         hipLaunchKernelGGL(k_local_sort, dim3(local_sort_grid(n)), dim3(LOCAL_THREADS), 0, s, (const uint32_t*)b.keys_tmp,
                            (const uint32_t*)b.idx_tmp, (const uint4*)tab, b.depth_index, (const uint32_t*)b.rect_tmp, b.rects_out);
         return;
     }
-    hipLaunchKernelGGL(k_quantise_hist, grid, block, 0, s, b.depth, b.slots, b.minmax, n, b.keys_per_block,
-                       b.rect, b.cull, b.keys, b.block_hist, 0, RADIX_LO_BINS);
-    launch_column_scan(b.block_hist, total_lo, RADIX_LO_BINS, b.nblocks, s);
+    hipLaunchKernelGGL(k_quantise_hist, grid, block, 0, s, depth_in, b.slots, b.minmax, n, b.keys_per_block,
+                       live, b.keys, b.block_hist, 0, RADIX_LO_BINS);
+    launch_column_scan(b.block_hist, total_lo, RADIX_LO_BINS, b.nblocks, s, live, b.keys_per_block);
     const bool carry = b.rects_out != nullptr;   // the packed rectangles travel with the keys (k_scatter, PAY)
     if (carry)
         hipLaunchKernelGGL((k_scatter<RADIX_LO_BITS, 0, true, true>), grid, dim3(SCAT_THREADS), lds_lo, s, (const uint32_t*)b.keys,
-                           (const uint32_t*)nullptr, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
+                           (const uint32_t*)band_idx, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
                            (const uint32_t*)total_lo, b.keys_tmp, b.idx_tmp, (uint32_t*)nullptr, b.rect, b.rect_tmp);
     else
         hipLaunchKernelGGL((k_scatter<RADIX_LO_BITS, 0, true>), grid, dim3(SCAT_THREADS), lds_lo, s, (const uint32_t*)b.keys,
-                           (const uint32_t*)nullptr, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
+                           (const uint32_t*)band_idx, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,
                            (const uint32_t*)total_lo, b.keys_tmp, b.idx_tmp, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
     hipLaunchKernelGGL(k_hist_hi, grid, block, 0, s, (const uint32_t*)b.keys_tmp, (const uint32_t*)b.count, b.keys_per_block,
                        b.block_hist);
-    launch_column_scan(b.block_hist, total_hi, RADIX_HI_BINS, b.nblocks, s);
+    launch_column_scan(b.block_hist, total_hi, RADIX_HI_BINS, b.nblocks, s, live, b.keys_per_block);
     if (carry)
         hipLaunchKernelGGL((k_scatter<RADIX_HI_BITS, RADIX_LO_BITS, false, true>), grid, dim3(SCAT_THREADS), lds_hi, s, (const uint32_t*)b.keys_tmp,
                            (const uint32_t*)b.idx_tmp, n, b.count, b.keys_per_block, (const uint32_t*)b.block_hist,

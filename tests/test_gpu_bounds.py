@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "gsplat.js_amd", "lib_exp", "bounds", "libgsplat_hip.so")
 SITES = {"blend": ["work item's bin", "its segment", "list position", "splat index in a list", "item range inside the bin"],
          "bin": ["splat index of a rank", "rectangle inside the bin grid", "LDS cell of the scatter", "table row", "count cell"],
-         "sort": ["destination of a radix pass", "its LDS position", "destination of the bucket sort", "key above 65536"]}
+         "sort": ["destination of a radix pass", "its LDS position", "destination of the bucket sort", "key above 65536",
+                  "band mode: a survivor's packed slot / original index"]}
 
 
 def _counters(L):
@@ -60,7 +61,10 @@ def test_no_index_leaves_its_array(monkeypatch):
     monkeypatch.delenv("GSR_LONG_ITEMS")
     monkeypatch.setenv("GSR_SORT_ORDER", "lsd")
     render("C2", (7,)).dispose()                                       # the six-launch radix order
+    render("C2", (7,), band=(0, 64)).dispose()                         # ... on a band's few survivors: most workgroups and table rows idle
+    render("C2", (9,), size=(3840, 2160), band=(1728, 2208)).dispose() # ... with the rectangles carried, a 4K band
     monkeypatch.delenv("GSR_SORT_ORDER")
+    render("C1", (5,), n=300, seed=17, band=(0, 32)).dispose()         # a band nothing touches: zero survivors
     render("C1", (9,), size=(3840, 2160)).dispose()                    # 8160 bins: two-level binning (cells, then chunks)
     render("C2", (9,), size=(3840, 2160)).dispose()                    # ... with cell lists of several chunks
     monkeypatch.setenv("GSR_SORT_ORDER", "lsd")

@@ -1026,6 +1026,57 @@ def test_band_contexts_with_multi_segment_bins_equal_the_full_frame(gh, monkeypa
             r.dispose()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", ["bucket", "lsd", "lsd gather"])
+def test_band_lists_are_the_full_frames_lists_of_the_band(gh, monkeypatch, order):
+    """A band context sorts and bins only its survivors: k_project_key packs them per workgroup, k_kept_scan / k_band_gather
+    leave them dense in index order, and every kernel behind runs on that many keys (workgroups and table rows past them do
+    nothing).  Their sorted order must be the restriction of the frame's order: the band's bin lists equal, entry for entry,
+    the lists the full-frame context builds for the same bin columns -- in both sort orders, with the rectangles carried
+    through the sort or gathered, for bands that keep most splats, few, and none at all."""
+    monkeypatch.setenv("GSR_SORT_ORDER", order.split()[0])
+    if "gather" in order:
+        monkeypatch.setenv("GSR_RECT_CARRY", "0")
+    W, H, n = 1280, 736, 150_001            # (a last projection workgroup of 241 splats)
+    scene = gh.Scene()
+    scene.setData(gh.synth.synth_rows(n, 77, 2.0, 0.004, 0.05))
+    full = gh.HIPRenderer(W, H)
+    bands = [(0, 32), (32, 608), (608, 672), (672, 1248), (1248, W)]
+    parts = [gh.HIPRenderer(W, H, band=b) for b in bands]
+    nbx, nby = (W + 31) // 32, (H + 31) // 32
+    for k in (3, 41):
+        cam = gh.orbit_camera(k, 120, W, H, 900.0)
+        full.render(scene, cam)
+        fs, fl = full.bin_lists()
+        want_img = full.readPixelsFloat()
+        survivors = []
+        for r, (x0, x1) in zip(parts, bands):
+            r.render(scene, cam)
+            st, lst = r.bin_lists()
+            bx0, bx1 = x0 // 32, (x1 + 31) // 32
+            w = bx1 - bx0
+            assert st.size == w * nby + 1
+            for by in range(nby):
+                for bx in range(w):
+                    a = fl[fs[by * nbx + bx0 + bx]:fs[by * nbx + bx0 + bx + 1]]
+                    b = lst[st[by * w + bx]:st[by * w + bx + 1]]
+                    assert np.array_equal(a, b), (order, k, x0, bx, by)
+            assert np.array_equal(r.readPixelsFloat()[:, x0:x1], want_img[:, x0:x1])
+            survivors.append(r.stats()["visible"])
+            assert np.array_equal(r.lastDepthIndex(), full.lastDepthIndex())   # (the whole permutation, on demand)
+        assert 0 < min(survivors) < max(survivors) < full.stats()["visible"]
+    # a band no splat touches: a small blob in the middle of the screen, the band at the left edge
+    off = gh.Scene()
+    off.setData(gh.synth.synth_rows(20_000, 78, 0.1, 0.004, 0.02))
+    cam = gh.orbit_camera(0, 120, W, H, 900.0)
+    parts[0].render(off, cam)
+    assert parts[0].stats()["visible"] == 0 and not parts[0].readPixelsFloat().any()
+    full.render(off, cam)
+    assert full.stats()["visible"] > 0
+    for r in [full] + parts:
+        r.dispose()
+
+
 def _lists_of(gh, size, scene, cams, env, monkeypatch, band=None):
     for k in ("GSR_BIN_TWO_LEVEL", "GSR_RECT_CARRY", "GSR_SORT_ORDER"):
         monkeypatch.delenv(k, raising=False)
