@@ -60,7 +60,7 @@ doc = {
     "kernel": "k_blend (frames_in_flight) / k_blend2 (one_frame)",
     "build_id": build_id,
     "workload": "C3 exact mode, bench.py --timed-only --steps 24 --warmup 4 under rocprofv3 --pmc (kernels serialised by the profiler); medians per configuration",
-    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ counters, separate passes (scripts/gpu.sh pmc); summary of all kernels in profiles/r03_pmc_c3.txt",
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ counters, separate passes (scripts/gpu.sh pmc); summary of all kernels in profiles/r04_pmc_c3.txt",
     "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for 16-B-per-lane reads -> doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact; rocprofv3 reports both in KB (x1024); for this kernel's 32-byte record gathers the doubling is an upper bound: true traffic lies between fetch_raw + write and 2 x fetch_raw + write",
     "frames_in_flight": leg(0, "GSR_FLAG_THROUGHPUT contexts, three frames in flight (the timed region of the default bench)"),
     "one_frame": leg(1, "exact context, one frame at a time (bench.py --frames-in-flight 1; the one_frame_in_flight leg uses the same)"),
