@@ -42,4 +42,26 @@ print("one-level, gathered: project %.3f sort %.3f bin %.3f blend %.3f" % (st2["
 s2, l2 = r2.bin_lists()
 assert np.array_equal(starts, s2) and np.array_equal(lst, l2), "bin lists differ"
 assert np.array_equal(img, r2.readPixelsFloat())
+r2.dispose()
+# a band context of the same frame (one rank of a multi-GPU run): it sorts and bins its survivors only (k_project_key packs them,
+# k_kept_scan / k_band_gather make them dense); its lists must be the full frame's lists of its bin columns, its pixels the frame's
+x0, x1 = (W // 2 // 32) * 32, (W // 2 // 32) * 32 + 8 * 32
+rb = gh.HIPRenderer(W, H, timing=True, band=(x0, x1))
+rb.set_raw_scene(data, pos)
+rb.set_camera(cam)
+rb.render_async(); rb.sync()
+rb.render_async(); rb.sync()           # (the second frame: sort order settled, graph replayed)
+stb = rb.stats()
+sb, lb = rb.bin_lists()
+nbx, nby, w = (W + 31) // 32, (H + 31) // 32, 8
+for by in range(nby):
+    for bx in range(w):
+        a = lst[starts[by * nbx + x0 // 32 + bx]:starts[by * nbx + x0 // 32 + bx + 1]]
+        b = lb[sb[by * w + bx]:sb[by * w + bx + 1]]
+        assert np.array_equal(a, b), ("band list differs", bx, by)
+# (same lists, same order; the band cuts its work items for its own pixels, so the sums associate differently: DESIGN 4)
+band_err = float(np.abs(rb.readPixelsFloat()[:, x0:x1].astype(np.float64) - img[:, x0:x1].astype(np.float64)).max())
+assert band_err <= 2e-6, band_err
+print("band [%d, %d): %d survivors of %d visible, project %.3f sort %.3f bin %.3f blend %.3f ms; lists equal the frame's, pixels within %.1e" % (
+    x0, x1, stb["visible"], st["visible"], stb["ms_project_key"], stb["ms_sort"], stb["ms_bin"], stb["ms_blend"], band_err))
 print("ok: depthIndex bit-exact at n=%d, %dx%d, lists and image equal to the one-level / gathered path, %.0f s total" % (n, W, H, time.time() - t0))
