@@ -11,22 +11,34 @@
  *                                 source (oracle/_ref, tests/test_oracle_ref.py)
  *                                 and against tests/golden/ fixtures generated
  *                                 from it (tests/golden/make_golden.py).
- *   scene pack  (orc_scene_pack)  pinned by fixtures produced by running the
- *                                 reference's floatToHalf text under Node
- *                                 (tests/golden/make_golden_half.js).
- *   render path (orc_project, orc_render)
- *                                 PARITY UNPINNED: the reference renders with
- *                                 GLSL on a WebGL2 context, which cannot run in
- *                                 this container (no GL, no GPU) and its repo
- *                                 holds no test images.  These functions restate
- *                                 vertex.glsl.ts / frag.glsl.ts / the GL blend
- *                                 state line by line.  What stands in for a pin:
- *                                 tests/independent_math.py, a float64 statement
- *                                 of the MATHEMATICS (numpy linear algebra, no
- *                                 shared operation sequence with this file),
- *                                 checked on off-axis, rotated, anisotropic
- *                                 splats (tests/test_oracle_render.py), plus
- *                                 closed-form known-answer tests.
+ *   scene pack / build / transforms (orc_scene_*)
+ *                                 PINNED by fixtures produced by running the
+ *                                 reference's own TypeScript under Node
+ *                                 (tests/golden/make_golden_half.js,
+ *                                 make_golden_host.js; tests/test_host_golden.py).
+ *   render path (orc_project*, the fragment weight of orc_render, orc_eval_sh)
+ *                                 PINNED BY EXECUTION OF THE SHADER TEXT, under
+ *                                 stated float semantics: the reference renders
+ *                                 with GLSL on a WebGL2 context, which cannot run
+ *                                 in this container (no GL, no GPU), and its repo
+ *                                 holds no test images.  tests/golden/
+ *                                 make_golden_shader.py reads vertex.glsl.ts /
+ *                                 frag.glsl.ts where they lie, translates the GLSL
+ *                                 statement by statement (glsl_eval.py) and RUNS
+ *                                 it in IEEE binary32 (left-to-right evaluation,
+ *                                 no contraction, the rules DESIGN.md 4 states);
+ *                                 tests/test_shader_golden.py: the quad's axes,
+ *                                 centre, colour, opacity and gl_Position of every
+ *                                 sample splat, every exit of the shader and
+ *                                 eval_sh_rgb are reproduced BIT FOR BIT, the
+ *                                 fragment colour to f32 rounding.  What remains
+ *                                 unpinned, structurally: a GPU's own rounding of
+ *                                 GLSL's divisions, square roots and exp, and the
+ *                                 rasteriser / RGBA8 blend (orc_render's
+ *                                 accumulation).  Also kept: tests/
+ *                                 independent_math.py, a float64 statement of the
+ *                                 MATHEMATICS (numpy linear algebra, no shared
+ *                                 operation sequence with this file).
  *
  * Build: gcc -O2 -ffp-contract=off -fPIC -shared (see oracle/Makefile).
  * -ffp-contract=off is REQUIRED: FMA contraction changes the sort result
@@ -390,6 +402,15 @@ static void orc_eval_sh(const uint32_t *const sh[3], uint32_t t, uint32_t deg, c
     }
 }
 
+/* eval_sh_rgb alone (vertex.glsl.ts:57-104 + the min(rgb, 1) of :200), for the fixture produced by running the reference's
+ * own shader text (tests/golden/shader_golden.json, tests/test_shader_golden.py) */
+void orc_eval_sh_rgb(const uint32_t *sh_r, const uint32_t *sh_g, const uint32_t *sh_b, uint32_t t, uint32_t deg,
+                     const float *dir, float *rgb)
+{
+    const uint32_t *const sh[3] = { sh_r, sh_g, sh_b };
+    orc_eval_sh(sh, t, deg, dir, rgb);
+}
+
 #define ORC_INVISIBLE(bb) do { (bb)[0] = 1; (bb)[1] = 1; (bb)[2] = 0; (bb)[3] = 0; } while (0)
 
 /* sh_r/g/b (nullable together): the three SH textures; band[3] = Scene.bandsIndices (index of the last splat with
@@ -599,6 +620,28 @@ void orc_tile_stats(const int32_t *bbox, uint32_t n, int tile, uint64_t *V, uint
  * out: W*H*4 floats, premultiplied RGBA, row 0 = top.
  * y_begin/y_end restrict rows (lets callers thread over row bands).
  * ---------------------------------------------------------------------- */
+/* frag.glsl.ts:13-20 for one fragment: A = -dot(vPosition, vPosition); discard below -4; B = clamp(exp(A) * opacity, 0, 1).
+ * Returns 0 when the fragment is discarded.  (f64: the modes of orc_render that follow the shader's own geometry use it.) */
+static inline int orc_frag_weight(double vx, double vy, double opacity, double *B)
+{
+    double A = -(vx * vx + vy * vy);
+    if (A < -4.0) return 0;
+    double b = exp(A) * opacity;
+    if (b > 1.0) b = 1.0;
+    if (b < 0.0) b = 0.0;
+    *B = b;
+    return 1;
+}
+
+/* the same for the fixture of the reference's executed fragment shader: out = (B * rgb, B); returns 0 on discard */
+int orc_fragment(const float *vpos, const float *color, float *out)
+{
+    double B;
+    if (!orc_frag_weight((double)vpos[0], (double)vpos[1], (double)color[3], &B)) return 0;
+    out[0] = (float)(B * color[0]); out[1] = (float)(B * color[1]); out[2] = (float)(B * color[2]); out[3] = (float)B;
+    return 1;
+}
+
 void orc_render(uint32_t n, const uint32_t *depth_index, const float *raw, const float *rec,
                 const int32_t *bbox, int W, int H, int mode, int y_begin, int y_end, float *out)
 {
@@ -626,9 +669,7 @@ void orc_render(uint32_t n, const uint32_t *depth_index, const float *raw, const
                     double dy = ((double)H - (y + 0.5)) - (double)rw[1];
                     double vx = 2.0 * (dx * rw[2] + dy * rw[3]) / M2;
                     double vy = 2.0 * (dx * rw[4] + dy * rw[5]) / N2;
-                    double A = -(vx * vx + vy * vy);
-                    if (A < -4.0) continue;
-                    B = exp(A) * opacity;
+                    if (!orc_frag_weight(vx, vy, opacity, &B)) continue;
                 } else {
                     /* k_blend's expression: coordinates relative to the centre of the first pixel of
                      * the 32x32 bin that holds (x, y); the centre is folded into ncu / ncw */

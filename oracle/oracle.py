@@ -68,6 +68,10 @@ def lib():
         L.orc_render.argtypes = [ctypes.c_uint32, u32p, f32p, f32p, i32p, ctypes.c_int, ctypes.c_int,
                                  ctypes.c_int, ctypes.c_int, ctypes.c_int, f32p]
         L.orc_render.restype = None
+        L.orc_eval_sh_rgb.argtypes = [u32p, u32p, u32p, ctypes.c_uint32, ctypes.c_uint32, f32p, f32p]
+        L.orc_eval_sh_rgb.restype = None
+        L.orc_fragment.argtypes = [f32p, f32p, f32p]
+        L.orc_fragment.restype = ctypes.c_int
         _LIB = L
     return _LIB
 
@@ -182,6 +186,23 @@ def project(data, view, proj, fx, fy, W, H, sh=None, band=None, fade=None):
                              _p(sh[0], u32p), _p(sh[1], u32p), _p(sh[2], u32p), _p(band, i32p),
                              _p(rec, f32p), _p(bbox, i32p), _p(raw, f32p))
     return rec, bbox, raw
+
+
+def eval_sh_rgb(sh, index, deg, direction):
+    """eval_sh_rgb of the vertex shader (+ its min(rgb, 1)) for one splat of the three SH textures: f32[3]."""
+    sh = [np.ascontiguousarray(a, dtype=np.uint32) for a in sh]
+    d = np.ascontiguousarray(direction, dtype=np.float32)
+    out = np.zeros(3, dtype=np.float32)
+    lib().orc_eval_sh_rgb(_p(sh[0], u32p), _p(sh[1], u32p), _p(sh[2], u32p), int(index), int(deg), _p(d, f32p), _p(out, f32p))
+    return out
+
+
+def fragment(vpos, color):
+    """The fragment shader for one fragment: premultiplied (B rgb, B) as f32[4], or None when it is discarded."""
+    v = np.ascontiguousarray(vpos, dtype=np.float32)
+    c = np.ascontiguousarray(color, dtype=np.float32)
+    out = np.zeros(4, dtype=np.float32)
+    return out if lib().orc_fragment(_p(v, f32p), _p(c, f32p), _p(out, f32p)) else None
 
 
 def tile_stats(bbox, tile=16):
