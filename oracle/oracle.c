@@ -633,6 +633,28 @@ static inline int orc_frag_weight(double vx, double vy, double opacity, double *
     return 1;
 }
 
+/* WebGLRenderer.ts:139-142,282-285: blendFuncSeparate(ONE_MINUS_DST_ALPHA, ONE, ONE_MINUS_DST_ALPHA, ONE), FUNC_ADD on the
+ * fragment (B rgb, B): dst.rgb += (1 - dst.a) * B rgb; dst.a += (1 - dst.a) * B  -- front-to-back "under" */
+static inline void orc_blend_under(double *px, double B, double cr, double cg, double cb)
+{
+    double t = 1.0 - px[3];
+    px[0] += t * B * cr; px[1] += t * B * cg; px[2] += t * B * cb; px[3] += t * B;
+}
+
+/* k fragments (vPosition xy, colour rgba: 6 floats each) onto one cleared pixel, in order: the fixture of the reference's
+ * blend state applied to its executed fragment shader's outputs (tests/test_shader_golden.py) */
+void orc_composite(const float *frags, uint32_t k, float *out)
+{
+    double px[4] = { 0.0, 0.0, 0.0, 0.0 };
+    for (uint32_t j = 0; j < k; j++) {
+        const float *f = frags + (size_t)6 * j;
+        double B;
+        if (!orc_frag_weight((double)f[0], (double)f[1], (double)f[5], &B)) continue;
+        orc_blend_under(px, B, f[2], f[3], f[4]);
+    }
+    for (int ch = 0; ch < 4; ch++) out[ch] = (float)px[ch];
+}
+
 /* the same for the fixture of the reference's executed fragment shader: out = (B * rgb, B); returns 0 on discard */
 int orc_fragment(const float *vpos, const float *color, float *out)
 {
@@ -687,8 +709,7 @@ void orc_render(uint32_t n, const uint32_t *depth_index, const float *raw, const
                 if (B > 1.0) B = 1.0;
                 if (B < 0.0) B = 0.0;
                 double *px = acc + ((size_t)(y - y_begin) * W + x) * 4;
-                double t = 1.0 - px[3];
-                px[0] += t * B * cr; px[1] += t * B * cg; px[2] += t * B * cb; px[3] += t * B;
+                orc_blend_under(px, B, cr, cg, cb);
                 if (mode == 2)
                     for (int ch = 0; ch < 4; ch++) {
                         double v = px[ch] < 0.0 ? 0.0 : (px[ch] > 1.0 ? 1.0 : px[ch]);

@@ -72,6 +72,8 @@ def lib():
         L.orc_eval_sh_rgb.restype = None
         L.orc_fragment.argtypes = [f32p, f32p, f32p]
         L.orc_fragment.restype = ctypes.c_int
+        L.orc_composite.argtypes = [f32p, ctypes.c_uint32, f32p]
+        L.orc_composite.restype = None
         _LIB = L
     return _LIB
 
@@ -203,6 +205,14 @@ def fragment(vpos, color):
     c = np.ascontiguousarray(color, dtype=np.float32)
     out = np.zeros(4, dtype=np.float32)
     return out if lib().orc_fragment(_p(v, f32p), _p(c, f32p), _p(out, f32p)) else None
+
+
+def composite(frags):
+    """k fragments (vPosition.xy, colour.rgba) blended in order onto one cleared pixel with the reference's blend state: f32[4]."""
+    f = np.ascontiguousarray(frags, dtype=np.float32).reshape(-1, 6)
+    out = np.zeros(4, dtype=np.float32)
+    lib().orc_composite(_p(f, f32p), f.shape[0], _p(out, f32p))
+    return out
 
 
 def tile_stats(bbox, tile=16):

@@ -131,6 +131,50 @@ def main():
             frags.append({"vPosition": [hexf(x) for x in vpos], "vColor": [hexf(x) for x in col], "fragColor": res})
     out["fragments"] = frags
 
+    # The fixed-function state the reference draws with, read from WebGLRenderer.ts (comments removed): blend factors and
+    # equation, clear colour, the quad's vertices and the draw call -- and that state APPLIED, per the OpenGL ES 3.0 blend
+    # equations for the factor names found, to sequences of the executed fragment shader's outputs (f32 destination).
+    import re
+    ts = open("/root/reference/src/renderers/WebGLRenderer.ts").read()
+    ts = re.sub(r"/\*.*?\*/", "", ts, flags=re.S)
+    ts = "\n".join(l for l in ts.split("\n") if not l.lstrip().startswith("//"))
+    names = lambda call: [sorted(set(tuple(a.strip().replace("gl.", "") for a in m.split(","))
+                                     for m in re.findall(r"gl\." + call + r"\(([^)]*)\)", ts)))]
+    state = {"blendFuncSeparate": names("blendFuncSeparate")[0], "blendEquationSeparate": names("blendEquationSeparate")[0],
+             "clearColor": names("clearColor")[0], "drawArraysInstanced": [a[:3] for a in names("drawArraysInstanced")[0]],
+             "quad": [float(x) for x in re.search(r"triangleVertices\s*=\s*new Float32Array\(\[([^\]]*)\]\)", ts).group(1).split(",")]}
+    assert all(len(v) == 1 for k, v in state.items() if k != "quad"), state      # one state for every draw
+    srgb, drgb, sa, da = state["blendFuncSeparate"][0]
+    factor = {"ONE": lambda S, D: F(1.0), "ZERO": lambda S, D: F(0.0), "ONE_MINUS_DST_ALPHA": lambda S, D: F(1.0) - D[3],
+              "ONE_MINUS_SRC_ALPHA": lambda S, D: F(1.0) - S[3], "SRC_ALPHA": lambda S, D: S[3], "DST_ALPHA": lambda S, D: D[3]}
+    assert state["blendEquationSeparate"][0] == ("FUNC_ADD", "FUNC_ADD")
+    seqs = []
+    with np.errstate(all="ignore"):
+        for k in range(24):
+            D = [F(x) for x in state["clearColor"][0]]
+            items = []
+            for j in range(3 + k % 6):
+                r = 1.9 * np.sqrt(rng.random()) if j % 4 else 2.2
+                a = 2.0 * np.pi * rng.random()
+                vpos = (F(r * np.cos(a)), F(r * np.sin(a)))
+                col = [F(x) for x in rng.random(4)]
+                if k % 5 == 0:
+                    col[3] = F(0.97)                    # nearly opaque layers: the destination saturates
+                items.append([hexf(x) for x in vpos] + [hexf(x) for x in col])
+                frag_ns["vPosition"] = frag_ns["vec2"](*vpos)
+                frag_ns["vColor"] = frag_ns["vec4"](*col)
+                try:
+                    frag_ns["main"]()
+                except G.Discard:
+                    continue
+                S = frag_ns["fragColor"].c
+                fs = [factor[srgb](S, D)] * 3 + [factor[sa](S, D)]
+                fd = [factor[drgb](S, D)] * 3 + [factor[da](S, D)]
+                D = [S[c] * fs[c] + D[c] * fd[c] for c in range(4)]
+            seqs.append({"fragments": items, "dst": [hexf(x) for x in D]})
+    out["gl_state"] = {k: [list(t) for t in v] if k != "quad" else v for k, v in state.items()}
+    out["blend_sequences"] = seqs
+
     # eval_sh_rgb: seeded half-packed coefficient textures, degrees 0..3, sample directions
     nsh = 24
     shs = (rng.random(nsh * 48).astype(np.float32) - 0.5) * 1.6

@@ -150,3 +150,24 @@ def test_device_projection_equals_the_executed_vertex_shader(g, oracle):
         assert drawn > 400     # (one of the fade cameras scales every quad to nothing)
     finally:
         r.dispose()
+
+
+def test_blend_state_read_from_the_renderer_and_applied(g, oracle):
+    """C2: the fixed-function state the reference draws with, read from WebGLRenderer.ts at generation time, is the one the
+    oracle (and the kernels) implement -- clear to (0, 0, 0, 0), one instanced TRIANGLE_FAN of 4 vertices at (+-2, +-2),
+    FUNC_ADD with (ONE_MINUS_DST_ALPHA, ONE) for colour and alpha = front-to-back "under" on premultiplied fragments --
+    and that state applied (OpenGL ES 3.0 blend equations, f32 destination) to sequences of the executed fragment
+    shader's outputs gives what orc_render's per-pixel accumulation gives (f64: to f32 rounding)."""
+    st = g["gl_state"]
+    assert st["blendFuncSeparate"] == [["ONE_MINUS_DST_ALPHA", "ONE", "ONE_MINUS_DST_ALPHA", "ONE"]]
+    assert st["blendEquationSeparate"] == [["FUNC_ADD", "FUNC_ADD"]] and st["clearColor"] == [["0", "0", "0", "0"]]
+    assert st["drawArraysInstanced"] == [["TRIANGLE_FAN", "0", "4"]] and st["quad"] == [-2.0, -2.0, 2.0, -2.0, 2.0, 2.0, -2.0, 2.0]
+    assert len(g["blend_sequences"]) == 24
+    alphas = []
+    for seq in g["blend_sequences"]:
+        frags = np.array([f32(it) for it in seq["fragments"]], dtype=np.float32)
+        got = oracle.composite(frags)
+        want = f32(seq["dst"])
+        assert np.abs(got.astype(np.float64) - want.astype(np.float64)).max() <= 1e-6, (got, want)
+        alphas.append(float(want[3]))
+    assert max(alphas) > 0.5 and min(alphas) < 0.5       # thin and thick stacks both
