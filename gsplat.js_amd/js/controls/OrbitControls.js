@@ -29,6 +29,7 @@ class OrbitControls {
             OrbitControls.applyPose(camera, a, b, r, t);
         };
         this.dispose = () => {};
+        this.update();   // (OrbitControls.ts:351: the constructor leaves the camera on the orbit)
     }
     // OrbitControls.ts:275-283
     static applyPose(camera, alpha, beta, radius, target) {

@@ -14,7 +14,7 @@ const fs = require("fs");
 const path = require("path");
 const REF = "/root/reference/src/";
 
-const TYPES = "(?:number|Number|string|boolean|any|void|Event|Matrix3|Matrix4|Quaternion|Vector3|Camera|Scene|Float32Array|Uint8Array|Uint32Array|Int32Array|Int16Array)";
+const TYPES = "(?:number|Number|string|boolean|any|void|null|Event|KeyboardEvent|MouseEvent|WheelEvent|TouchEvent|HTMLElement|Matrix3|Matrix4|Quaternion|Vector3|Camera|Scene|Float32Array|Uint8Array|Uint32Array|Int32Array|Int16Array)";
 const TYPE = TYPES + "(?:\\[\\])?(?:\\s*\\|\\s*" + TYPES + "(?:\\[\\])?)*";
 function strip(name) {
   let s = fs.readFileSync(REF + name, "utf8");
@@ -27,6 +27,8 @@ function strip(name) {
     return true;
   });
   s = lines.join("\n");
+  s = s.replace(/^( {4}[A-Za-z_]\w*)\s*:\s*\([^)]*\)\s*=>\s*\w+\s*=\s*/gm, "$1 = ");       // `attach: (c: Camera) => void = () => {};`
+  s = s.replace(/:\s*\{\s*\[\w+:\s*\w+\]:\s*\w+\s*\}/g, "");                              // `const keys: { [key: string]: boolean } = {}`
   s = s.replace(/new (Map|Set)<.*>\(/g, "new $1(");                                   // generics
   s = s.replace(/\)!(?=[.)])/g, ")");                                                      // non-null assertions
   s = s.replace(/([A-Za-z_]\w*)\s*:\s*\(\w+\s*:\s*\w+\)\s*=>\s*\w+(?=\s*[,)])/g, "$1");    // function-typed parameters
@@ -38,13 +40,14 @@ function strip(name) {
 }
 
 const order = ["utils.ts", "math/Vector3.ts", "math/Quaternion.ts", "math/Matrix3.ts", "math/Matrix4.ts",
-               "core/EventDispatcher.ts", "core/Object3D.ts", "cameras/Camera.ts", "core/Scene.ts"];
+               "core/EventDispatcher.ts", "core/Object3D.ts", "cameras/Camera.ts", "core/Scene.ts", "controls/OrbitControls.ts"];
 const body = order.map(strip).join("\n") +
-  "\nreturn { Vector3, Quaternion, Matrix3, Matrix4, Camera, Scene, packHalf2x16 };";
+  "\nreturn { Vector3, Quaternion, Matrix3, Matrix4, Camera, Scene, OrbitControls, packHalf2x16 };";
 let R;
 try {
   const quiet = { log() {} };   // (Scene.setData and Camera.setFromData print to the console)
-  R = new Function("console", body)(quiet);
+  const fakeWindow = { addEventListener() {}, removeEventListener() {} };   // (OrbitControls registers its key handlers there)
+  R = new Function("console", "window", body)(quiet, fakeWindow);
 } catch (e) {
   console.error("the stripped sources do not evaluate:", e.message);
   process.exit(1);
@@ -153,6 +156,29 @@ const snapshot = (sc) => ({ vertexCount: sc.vertexCount, width: sc.width, height
                    shs_rgb: sc.shs_rgb.map((t) => hexBytes(new Uint32Array(t.buffer, t.byteOffset, 8 * nsh))),
                    tails_are_zero: sc.shs_rgb.every((t) => Array.from(t.subarray(8 * nsh)).every((x) => x === 0)),
                    texture_words: sc.shs_rgb.map((t) => t.length) };
+}
+{
+  // OrbitControls (controls/OrbitControls.ts:20-307) on an element that only records its listeners: the pose the constructor
+  // leaves (it ends with update()), then setCameraTarget and three damped updates -- camera.position / camera.rotation each time
+  const el = { listeners: {}, addEventListener(k, f) { this.listeners[k] = f; }, removeEventListener() {} };
+  const pose = (cam) => ({ position: cam.position.flat().map(hex64), rotation: cam.rotation.flat().map(hex64) });
+  out.orbit = [];
+  for (let k = 0; k < 10; k++) {
+    const alpha = k === 0 ? 0.5 : rndS(3), beta = k === 0 ? 0.5 : rndS(1.4), radius = k === 0 ? 5 : 0.5 + rnd() * 9;
+    const target = k < 2 ? [0, 0, 0] : [rndS(2), rndS(2), rndS(2)];
+    const cam = new R.Camera();
+    const oc = new R.OrbitControls(cam, el, alpha, beta, radius, false, new R.Vector3(target[0], target[1], target[2]));
+    const rec = { alpha: hex64(alpha), beta: hex64(beta), radius: hex64(radius), target: target.map(hex64), dampening: hex64(oc.dampening),
+                  after_constructor: pose(cam), steps: [] };
+    oc.update();
+    rec.steps.push(pose(cam));
+    const nt = [rndS(1.5), rndS(1.5), rndS(1.5)];
+    oc.setCameraTarget(new R.Vector3(nt[0], nt[1], nt[2]));
+    rec.new_target = nt.map(hex64);
+    for (let j = 0; j < 3; j++) { oc.update(); rec.steps.push(pose(cam)); }
+    out.orbit.push(rec);
+    oc.dispose();
+  }
 }
 fs.writeFileSync(path.join(__dirname, "host_golden.json"), JSON.stringify(out));
 console.log("wrote host_golden.json:", out.cameras.length, "cameras,", NROWS, "rows");

@@ -170,6 +170,19 @@ if (mode === "pack") {                     // pack <splat> <outprefix> <W> <H> <
         same("sh texture words", sc.shs_rgb.map((t) => t.length), e.texture_words);
         for (let c = 0; c < 3; c++) same("sh channel " + c, hexBytes(new Uint32Array(sc.shs_rgb[c].buffer, sc.shs_rgb[c].byteOffset, 8 * nsh)), e.shs_rgb[c]);
     }
+    (g.orbit || []).forEach((e, k) => {
+        // OrbitControls (controls/OrbitControls.ts:20-307 executed): the pose the constructor leaves, then update / setCameraTarget / updates
+        const t = e.target.map(un), nt = e.new_target.map(un);
+        const cam = new G.Camera();
+        const oc = new G.OrbitControls(cam, null, un(e.alpha), un(e.beta), un(e.radius), false, new G.Vector3(t[0], t[1], t[2]));
+        const pose = () => ({ position: cam.position.flat().map(hex64), rotation: cam.rotation.flat().map(hex64) });
+        same("OrbitControls dampening " + k, hex64(oc.dampening), e.dampening);
+        same("OrbitControls constructor " + k, pose(), e.after_constructor);
+        oc.update();
+        same("OrbitControls update " + k, pose(), e.steps[0]);
+        oc.setCameraTarget(new G.Vector3(nt[0], nt[1], nt[2]));
+        for (let j = 1; j < 4; j++) { oc.update(); same("OrbitControls step " + j + " of " + k, pose(), e.steps[j]); }
+    });
     console.log(JSON.stringify({ compared, mismatches: bad }));
 } else if (mode === "group") {
     // group <splat> <outprefix> <W> <H> <fx> <rank> <world> <idfile>: renderer.render(scene, camera) with the framebuffer
@@ -299,6 +312,15 @@ if (mode === "pack") {                     // pack <splat> <outprefix> <W> <H> <
     writeBin(out + ".splat", scene.toSplatBytes());
     fs.writeFileSync(out + ".json", JSON.stringify({ n: scene.vertexCount, bands: Array.from(scene.bandsIndices), parsedBands: Array.from(parsed[2]),
                                                      shHeight: scene.shHeight }));
+} else if (mode === "plygolden") {        // plygolden <inria.ply> <quantized.ply>: what this package's parsers return, as hex (tests/test_host_golden.py)
+    const ab = (f) => { const b = fs.readFileSync(f); return b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength); };
+    const hex = (buf) => Buffer.from(buf).toString("hex");
+    const inria = ab(a[0]), q = ab(a[1]);
+    const full = G.PLYLoader._parseFull(G.PLYLoader._parseHeader(inria), inria);
+    const quant = G.PLYLoader._parseQuantized(q);
+    console.log(JSON.stringify({ plain: hex(G.PLYLoader._parseRows(inria, "")), polycam: hex(G.PLYLoader._parseRows(inria, "polycam")),
+                                 full_rows: hex(full[0]), full_shs: hex(full[1]),
+                                 q_rows: hex(quant[0]), q_shs: hex(quant[1]), q_bands: Array.from(quant[2]) }));
 } else if (mode === "nodevice") {
     try {
         new G.HIPRenderer({ width: 64, height: 64 });

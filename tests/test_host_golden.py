@@ -41,6 +41,7 @@ def test_fixture_was_made_by_running_the_reference(g):
     assert len(g["cameras"]) == 12 and len(g["quaternions"]) == 24 and g["scene"]["after_setData"]["vertexCount"] == 160
     assert 0 < g["scene"]["limitBox"]["after"]["vertexCount"] < 160
     assert g["scene"]["change_events"] == 5          # setData and the four transforms each dispatch "change"
+    assert len(g["orbit"]) == 10 and all(len(o["steps"]) == 4 for o in g["orbit"])   # the reference's OrbitControls, executed
 
 
 @pytest.mark.skipif(shutil.which("node") is None, reason="node is not installed")
@@ -49,7 +50,7 @@ def test_js_host_equals_the_reference_executed_goldens():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     res = json.loads(r.stdout)
-    assert res["mismatches"] == [] and res["compared"] >= 180
+    assert res["mismatches"] == [] and res["compared"] >= 240     # (incl. OrbitControls: 10 cases x constructor, update, setCameraTarget, 3 damped updates)
 
 
 def test_python_mirror_camera_and_matrices(g):
@@ -141,3 +142,59 @@ def test_device_scene_kernels_equal_the_reference(g):
         _check_state(r.read_scene(), s["limitBox"]["after"], "gsr_scene_limit_box")
     finally:
         r.dispose()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (f) rank 4: the PLY loaders against the reference's own parsers, executed (tests/golden/make_golden_ply.py / .js)
+# ---------------------------------------------------------------------------------------------------------------------
+PLY_GOLDEN = os.path.join(HERE, "golden", "ply_golden.json")
+
+
+@pytest.fixture(scope="module")
+def pg():
+    return json.load(open(PLY_GOLDEN))
+
+
+def _rows_close(got, want, n):
+    """exp / sigmoid go through libm here and through V8 in the reference: scales within an ulp, alpha / rotation bytes within 1."""
+    got, want = got.reshape(n, 32), want.reshape(n, 32)
+    assert np.array_equal(got[:, 0:12], want[:, 0:12])
+    gs, ws = got[:, 12:24].copy().view(np.float32), want[:, 12:24].copy().view(np.float32)
+    assert np.all(np.abs(gs - ws) <= np.spacing(np.abs(ws)))
+    assert np.array_equal(got[:, 24:27], want[:, 24:27])
+    assert np.abs(got[:, 27].astype(int) - want[:, 27].astype(int)).max() <= 1
+    assert np.abs(got[:, 28:32].astype(int) - want[:, 28:32].astype(int)).max() <= 1
+
+
+def test_ply_fixture_was_made_by_running_the_reference_parsers(pg):
+    assert "evaluated under node" in pg["source"] and pg["q_bands"] == [39, 63, 79]
+    assert len(pg["plain"]) == len(pg["polycam"]) == len(pg["full_rows"]) == 96 * 64 and len(pg["q_rows"]) == 100 * 64
+    assert pg["plain"] != pg["polycam"]      # the axis swap
+
+
+def test_python_ply_restatement_equals_the_reference_parsers(pg):
+    from oracle import ply_oracle as P
+    inria, quant = bytes.fromhex(pg["inria_ply"]), bytes.fromhex(pg["quantized_ply"])
+    _rows_close(P.rows_from_ply(inria), arr(pg["plain"], np.uint8), 96)
+    _rows_close(P.rows_from_ply(inria, "polycam"), arr(pg["polycam"], np.uint8), 96)
+    rows, sh = P.rows_and_sh_from_ply(inria)
+    _rows_close(rows, arr(pg["full_rows"], np.uint8), 96)
+    assert np.array_equal(np.asarray(sh, dtype=np.float32).view(np.uint32), arr(pg["full_shs"], np.uint32))
+    rows, sh, bands = P.rows_sh_from_qply(quant)
+    _rows_close(rows, arr(pg["q_rows"], np.uint8), 100)
+    assert np.array_equal(np.asarray(sh, dtype=np.float32).view(np.uint32), arr(pg["q_shs"], np.uint32))
+    assert list(bands) == pg["q_bands"]
+
+
+@pytest.mark.skipif(shutil.which("node") is None, reason="node is not installed")
+def test_js_ply_loader_equals_the_reference_parsers_bit_for_bit(pg, tmp_path):
+    """Same engine on both sides (V8's Math.exp): rows, SH floats and bandsIndices must be identical."""
+    node = shutil.which("node")
+    a, q = tmp_path / "a.ply", tmp_path / "q.ply"
+    a.write_bytes(bytes.fromhex(pg["inria_ply"]))
+    q.write_bytes(bytes.fromhex(pg["quantized_ply"]))
+    r = subprocess.run([node, os.path.join(HERE, "js", "host_check.js"), "plygolden", str(a), str(q)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.loads(r.stdout)
+    for k in ("plain", "polycam", "full_rows", "full_shs", "q_rows", "q_shs", "q_bands"):
+        assert got[k] == pg[k], k
