@@ -472,7 +472,7 @@ static int enqueue_chain(gsr_ctx* c, bool render, bool timing)
                       (uint32_t)((g.bx_hi - g.bx_lo) * BIN_PX) * (uint32_t)c->H,
                       (c->opt.flags & GSR_FLAG_THROUGHPUT) ? LONG_TILES_X2_THROUGHPUT : LONG_TILES_X2_EXACT,
                       c->long_tau_env, (c->opt.flags & GSR_FLAG_THROUGHPUT) ? LONG_MASS_MIN_THROUGHPUT : LONG_MASS_MIN_EXACT,
-                      c->bin_two_level ? 1u : 0u, c->cell_list, c->cell_total, c->cell_start, c->chunk_start, c->chunk_info, c->cell_wcnt, c->cell_table2, c->cell_grid};
+                      c->bin_two_level ? 1u : 0u, c->cell_list, c->cell_total, c->cell_start, c->chunk_start, c->chunk_info, c->cell_wcnt, c->cell_table2, c->cell_grid, band_is_partial(c) ? 1u : 0u, c->n};
         launch_bin(bb, g, c->n, s);
         if (timing) HIP_TRY(c, hipEventRecord(c->ev[EV_BIN], s));
         BlendBuffers bl{c->items, c->seg_start, c->bin_start, c->bin_list, c->rec, c->bbox, c->shcol, c->fb, c->partial,

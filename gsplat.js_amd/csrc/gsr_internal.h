@@ -239,6 +239,8 @@ struct BinBuffers {
     uint32_t* cell_wcnt;         // (capacity / 2048 + cells) x 64 words: per chunk, bin and wave of k_cell_scatter2 one byte: the wave's entries
     uint32_t* cell_table2;       // (capacity / 2048 + cells) x 16: per chunk and bin of its cell: entries, then their first slot
     uint32_t cell_grid;          // workgroups of the level-two kernels (they stride over the frame's chunks)
+    uint32_t band;               // 1: a band context (the frame holds fewer ranks than the scene: scans and workgroups stop at *count's rows)
+    uint32_t n_max;              // entries the rank-ordered buffers hold (the scene's splats): k_bin_count may load that far before it knows *count
 };
 void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s);
 

@@ -71,8 +71,18 @@ constexpr int CNT_MAX_BINS = 12288;  // LDS counters per workgroup (48 KiB); lar
 
 __global__ __launch_bounds__(CNT_THREADS) void k_bin_count(const uint32_t* __restrict__ depth_index, const uint32_t* __restrict__ rect_idx,
                                                            const uint32_t* __restrict__ count, BinGrid g, int slice_rows,
-                                                           uint32_t rounds, uint32_t* __restrict__ table, uint32_t* __restrict__ rects, int shift, int sorted)
+                                                           uint32_t rounds, uint32_t* __restrict__ table, uint32_t* __restrict__ rects, int shift, int sorted,
+                                                           uint32_t n_max)
 {
+    // the first round's ranks (or their rectangles) do not depend on how many ranks the frame holds, only on how many the
+    // buffers do (n_max): their loads go out in front of the count's, one round trip instead of two
+    const uint32_t begin0 = blockIdx.x * rounds * BIN_RANKS_PER_BLOCK;
+    uint32_t first[CNT_STEPS];
+#pragma unroll
+    for (int st = 0; st < CNT_STEPS; st++) {
+        const uint32_t r = begin0 + st * CNT_THREADS + threadIdx.x;
+        first[st] = r < n_max ? (sorted ? rects[r] : depth_index[r]) : 0u;
+    }
     const uint32_t n = *count;  // ranks the sort produced (all splats, or the band's survivors)
     // (band mode: the grid is the scene's, the ranks are the band's: a workgroup past them leaves no row -- the scan and the
     //  scatter stop at the last row that has ranks, launch_column_scan's `live`)
@@ -97,13 +107,13 @@ __global__ __launch_bounds__(CNT_THREADS) void k_bin_count(const uint32_t* __res
 #pragma unroll
         for (int st = 0; st < CNT_STEPS; st++) {
             const uint32_t r = begin + st * CNT_THREADS + threadIdx.x;
-            rc[st] = (r < n) ? rects[r] : RECT_NONE;
+            rc[st] = (r < n) ? (rd == 0 ? first[st] : rects[r]) : RECT_NONE;
         }
     } else {
 #pragma unroll
         for (int st = 0; st < CNT_STEPS; st++) {
             const uint32_t r = begin + st * CNT_THREADS + threadIdx.x;
-            idx[st] = (r < n) ? depth_index[r] : 0xffffffffu;
+            idx[st] = (r < n) ? (rd == 0 ? first[st] : depth_index[r]) : 0xffffffffu;
         }
 #pragma unroll
         for (int st = 0; st < CNT_STEPS; st++) rc[st] = (idx[st] != 0xffffffffu) ? rect_idx[idx[st]] : RECT_NONE;
@@ -1041,8 +1051,8 @@ static void launch_bin_two_level(const BinBuffers& b, const BinGrid& g, hipStrea
     const CellGeom cg{ncx, ncells, nbxb, g.nby};
     // level one (b.nblocks workgroups of 2048 ranks; the table's last column sums the rectangles' areas in bins)
     hipLaunchKernelGGL(k_bin_count, dim3(b.nblocks), dim3(CNT_THREADS), (size_t)(ncells + 1) * sizeof(uint32_t), s, b.depth_index, b.rect_idx,
-                       b.count, gc, ncy, 1u, b.table, b.rects, CELL_SHIFT, (int)b.rects_sorted);
-    launch_column_scan(b.table, b.cell_total, ncells + 1, b.nblocks, s, b.count, BIN_RANKS_PER_BLOCK);
+                       b.count, gc, ncy, 1u, b.table, b.rects, CELL_SHIFT, (int)b.rects_sorted, b.n_max);
+    launch_column_scan(b.table, b.cell_total, ncells + 1, b.nblocks, s, b.band ? b.count : nullptr, BIN_RANKS_PER_BLOCK);
     {
         const dim3 grid(b.nblocks + 1), block(SCAT_THREADS);
 #define GSR_LAUNCH_CELLS(K)                                                                                                          \
@@ -1086,8 +1096,8 @@ void launch_bin(const BinBuffers& b, const BinGrid& g, uint32_t n, hipStream_t s
     const int cnt_rows = (g.nby + cnt_slices - 1) / cnt_slices;
     if (n) {
         hipLaunchKernelGGL(k_bin_count, dim3(b.nblocks, (g.nby + cnt_rows - 1) / cnt_rows), dim3(CNT_THREADS),
-                           (size_t)cnt_rows * nbxb * sizeof(uint32_t), s, b.depth_index, b.rect_idx, b.count, g, cnt_rows, b.rounds, b.table, b.rects, 0, (int)b.rects_sorted);
-        launch_column_scan(b.table, b.bin_total, nbins, b.nblocks, s, b.count, b.rounds * BIN_RANKS_PER_BLOCK);
+                           (size_t)cnt_rows * nbxb * sizeof(uint32_t), s, b.depth_index, b.rect_idx, b.count, g, cnt_rows, b.rounds, b.table, b.rects, 0, (int)b.rects_sorted, b.n_max);
+        launch_column_scan(b.table, b.bin_total, nbins, b.nblocks, s, b.band ? b.count : nullptr, b.rounds * BIN_RANKS_PER_BLOCK);
     }
     const FinalizeArgs fa = make_finalize_args(b, nbins, n);
     const bool fused = n && nbins <= 4096;   // see bin_scatter_body

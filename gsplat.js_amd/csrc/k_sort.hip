@@ -164,6 +164,18 @@ __global__ __launch_bounds__(SORT_THREADS) void k_quantise_hist(const int32_t* _
     __shared__ uint32_t h_lo[RADIX_HI_BINS];
     __shared__ int32_t s_mm[2][SORT_THREADS / WAVE];
     for (int d = threadIdx.x; d < hist_bins; d += SORT_THREADS) h_lo[d] = 0;
+    // the workgroup's first depths do not depend on the bounds: their loads go out in front of the fold below, so that the
+    // two round trips (slots, depths) overlap instead of following each other
+    const uint32_t begin = blockIdx.x * keys_per_block;
+    if (live) n = *live;   // (band mode: depth[] holds the survivors, dense: k_band_gather)
+    const uint32_t end = min(begin + keys_per_block, n);
+    constexpr int QH_PRE = 8;   // (2048 keys per workgroup = 8 per thread: small scenes load everything up front)
+    int32_t pre[QH_PRE];
+#pragma unroll
+    for (int k = 0; k < QH_PRE; k++) {
+        const uint32_t i = begin + threadIdx.x + (uint32_t)k * SORT_THREADS;
+        pre[k] = i < end ? depth[i] : 0;
+    }
     // wasm.cpp:14-31's running min / max over ALL splats: fold the projection's per-workgroup pairs
     int32_t mn = 0x7fffffff, mx = (int32_t)0x80000000;
     if (threadIdx.x < FRAME_SLOTS) {
@@ -186,17 +198,20 @@ __global__ __launch_bounds__(SORT_THREADS) void k_quantise_hist(const int32_t* _
     // wasm.cpp:34: (float)depthRange / (maxDepth - minDepth): int subtract, int->f32 RNE, f32 divide RNE
     const float depthInv = degenerate ? 0.0f : (float)DEPTH_RANGE / (float)(maxDepth - minDepth);
 
-    const uint32_t begin = blockIdx.x * keys_per_block;
-    if (live) n = *live;   // (band mode: depth[] holds the survivors, dense: k_band_gather)
-    const uint32_t end = min(begin + keys_per_block, n);
-    for (uint32_t i = begin + threadIdx.x; i < end; i += SORT_THREADS) {
+    auto quantise = [&](uint32_t i, int32_t d) {
         // wasm.cpp:38: u32 wrap-around subtract, u32->f32 RNE, f32 multiply, truncate
-        const uint32_t rel = (uint32_t)depth[i] - (uint32_t)minDepth;
+        const uint32_t rel = (uint32_t)d - (uint32_t)minDepth;
         uint32_t q = degenerate ? 0u : (uint32_t)((float)rel * depthInv);
         q = min(q, DEPTH_RANGE);
         keys[i] = q;
         atomicAdd(&h_lo[(q >> hist_shift) & (uint32_t)(hist_bins - 1)], 1u);
+    };
+#pragma unroll
+    for (int k = 0; k < QH_PRE; k++) {
+        const uint32_t i = begin + threadIdx.x + (uint32_t)k * SORT_THREADS;
+        if (i < end) quantise(i, pre[k]);
     }
+    for (uint32_t i = begin + threadIdx.x + QH_PRE * SORT_THREADS; i < end; i += SORT_THREADS) quantise(i, depth[i]);
     __syncthreads();
     for (int d = threadIdx.x; d < hist_bins; d += SORT_THREADS) block_hist[(size_t)blockIdx.x * hist_bins + d] = h_lo[d];
 }
