@@ -8,4 +8,4 @@ cp oracle/liboracle.so /tmp/liboracle_orig.so
 trap 'cp /tmp/liboracle_orig.so oracle/liboracle.so' EXIT
 cp /tmp/liboracle_asan.so oracle/liboracle.so
 LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0 \
-  python -m pytest tests/test_oracle_sort.py tests/test_oracle_render.py tests/test_scene_camera.py -x -q
+  python -m pytest tests/test_oracle_sort.py tests/test_oracle_render.py tests/test_scene_camera.py tests/test_shader_golden.py tests/test_host_golden.py -x -q -m "not gpu"
