@@ -253,8 +253,9 @@ constexpr int CS_BATCH = 8;
 // KEEP: a slot holds at most CS_KEEP rows (tables of up to CS_SLOTS * CS_KEEP = 512 rows: every scene up to 1 M splats),
 // which stay in registers between the two sweeps -- one global round trip less in a kernel that is nothing but round trips.
 constexpr int CS_KEEP = 16;
+constexpr int CS_KEEP_LONG = 40;   // ... and tables of up to 1280 rows (C4's radix tables: 1221) with 40 registers: round 4
 
-template <bool KEEP>
+template <int KEEP>
 __global__ __launch_bounds__(CS_THREADS) void k_column_scan(uint32_t* __restrict__ table, uint32_t* __restrict__ total,
                                                             int ncols, uint32_t nrows, const uint32_t* __restrict__ live, uint32_t live_unit)
 {
@@ -270,12 +271,12 @@ __global__ __launch_bounds__(CS_THREADS) void k_column_scan(uint32_t* __restrict
     uint32_t* p = table + (size_t)r0 * ncols + (ok ? col : 0);
 
     uint32_t sum = 0;
-    uint32_t kept[KEEP ? CS_KEEP : 1];
+    uint32_t kept[KEEP ? KEEP : 1];
     if (KEEP) {
 #pragma unroll
-        for (int k = 0; k < CS_KEEP; k++) kept[k] = (ok && r0 + k < r1) ? p[(size_t)k * ncols] : 0u;
+        for (int k = 0; k < KEEP; k++) kept[k] = (ok && r0 + k < r1) ? p[(size_t)k * ncols] : 0u;
 #pragma unroll
-        for (int k = 0; k < CS_KEEP; k++) sum += kept[k];
+        for (int k = 0; k < KEEP; k++) sum += kept[k];
     } else if (ok) {
         for (uint32_t r = r0; r < r1; r += CS_BATCH) {
             uint32_t v[CS_BATCH];
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_column_scan(uint32_t* __restrict
         uint32_t run = base;
         if (KEEP) {
 #pragma unroll
-            for (int k = 0; k < CS_KEEP; k++) {
+            for (int k = 0; k < KEEP; k++) {
                 if (r0 + k < r1) p[(size_t)k * ncols] = run;
                 run += kept[k];
             }
@@ -321,8 +322,9 @@ __global__ __launch_bounds__(CS_THREADS) void k_column_scan(uint32_t* __restrict
 void launch_column_scan(uint32_t* table, uint32_t* total, int ncols, uint32_t nrows, hipStream_t s, const uint32_t* live, uint32_t live_unit)
 {
     const dim3 grid((ncols + CS_COLS - 1) / CS_COLS), block(CS_THREADS);
-    if (nrows <= (uint32_t)CS_SLOTS * CS_KEEP) hipLaunchKernelGGL(k_column_scan<true>, grid, block, 0, s, table, total, ncols, nrows, live, live_unit);
-    else hipLaunchKernelGGL(k_column_scan<false>, grid, block, 0, s, table, total, ncols, nrows, live, live_unit);
+    if (nrows <= (uint32_t)CS_SLOTS * CS_KEEP) hipLaunchKernelGGL(k_column_scan<CS_KEEP>, grid, block, 0, s, table, total, ncols, nrows, live, live_unit);
+    else if (nrows <= (uint32_t)CS_SLOTS * CS_KEEP_LONG) hipLaunchKernelGGL(k_column_scan<CS_KEEP_LONG>, grid, block, 0, s, table, total, ncols, nrows, live, live_unit);
+    else hipLaunchKernelGGL(k_column_scan<0>, grid, block, 0, s, table, total, ncols, nrows, live, live_unit);
 }
 
 // ---------------------------------------------------------------------------
